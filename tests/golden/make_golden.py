@@ -1,0 +1,135 @@
+"""Generate the golden fixtures by running the REFERENCE itself (development container only).
+
+    python -m tests.golden.make_golden
+
+Imports /root/reference through tools/ref_import.py (four shims), loads the
+deterministic synthetic checkpoint (otvm_amd.synth_weights), drives ``EvalModel.forward`` over
+seeded synthetic clips exactly as eval.py:157-228 does, and stores inputs-as-seeds + outputs.
+The fixtures are data only; nothing of the reference's source travels with them.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+from tools.ref_import import build_reference_model, load_reference  # noqa: E402
+from tools.ref_run import frame_inputs  # noqa: E402
+from otvm_amd.synth_weights import synthetic_state_dict  # noqa: E402
+from otvm_amd.synth_data import synthetic_clip, soft_alpha  # noqa: E402
+
+SEQUENCES = [
+    # name, H, W, T, style, skip, max_num, dilate_kernel, clip_seed
+    ("demo_100x150_s5m5", 100, 150, 8, "demo", 5, 5, 12, 1),
+    ("demo_64x96_s3m3", 64, 96, 12, "demo", 3, 3, 12, 2),
+    ("v108_64x96_s3m3", 64, 96, 7, "v108", 3, 3, 5, 3),
+    ("demo_64x64_m0", 64, 64, 4, "demo", 3, 0, 12, 4),
+    ("demo_64x64_m1", 64, 64, 4, "demo", 3, 1, 12, 4),
+    ("demo_64x64_m2_noskip", 64, 64, 5, "demo", 2, 2, 12, 4),
+    ("demo_70x90_single", 70, 90, 1, "demo", 5, 5, 12, 5),
+]
+
+
+def run_sequence(H, W, T, style, skip, max_num, dk, clip_seed, wseed=0):
+    m = build_reference_model(dk)
+    m.load_state_dict(synthetic_state_dict(wseed), strict=True)
+    frames, tri = synthetic_clip(H, W, T, clip_seed)
+    alphas, tris, banks, keys0 = [], [], [], []
+    for t in range(T):
+        if style == "demo":
+            a, fg, bg, tri_gt = frame_inputs(frames, t, trimap=tri)
+        else:
+            a, fg, bg, tri_gt = frame_inputs(frames, t, trimap=None, alpha=soft_alpha(H, W, t))
+        memorize = (t % skip == 0) if skip > 2 else False          # eval.py:188-189
+        out = m(a, fg, bg, tri=None, tri_gt=tri_gt, first_frame=(t == 0), last_frame=(t == T - 1),
+                memorize=memorize, max_memory_num=max_num, large_input=False)
+        alphas.append(out[3][0, 0, 0].numpy().copy())
+        tris.append(out[1][0, 0].numpy().copy())
+        k = m.memories["key"]
+        banks.append(0 if k is None else int(k.shape[3]))
+        # checksum of the bank keys: pins the slot policy (which frames are resident)
+        keys0.append(np.zeros(0, np.float32) if k is None else k[0, 0, :8, :, 0, 0].numpy().copy().ravel())
+    return dict(alpha=np.stack(alphas), trimap=np.stack(tris), bank=np.asarray(banks),
+                tri_gt=out[2][0, 0].numpy().copy(), key_probe=np.concatenate(keys0))
+
+
+def op_fixtures():
+    """Per-function vectors from the reference's own functions."""
+    load_reference()
+    import math
+    from utils.utils import trimap_transform                    # reference utils/utils.py:25-39
+    from models.alpha.FBA.models import fba_fusion              # reference FBA/models.py:279-288
+    from models.alpha.common import pad_divide_by               # reference alpha/common.py:6-27
+    from models.trimap.STM import Memory                        # reference STM.py:140-163
+    from models.alpha.FBA import layers_WS as L                 # reference layers_WS.py
+    out = {}
+    rng = np.random.Generator(np.random.PCG64(7))
+    # trimap_transform on crafted masks: empty fg class, single pixel, full, random blobs
+    H, W = 37, 53
+    masks = np.zeros((4, 2, H, W), np.float32)
+    masks[0, 0] = 1.0                                            # all bg, fg empty
+    masks[1, 0] = 1.0; masks[1, 0, 20, 30] = 0.0; masks[1, 1, 20, 30] = 1.0   # single fg pixel
+    masks[2, 1] = 1.0                                            # all fg, bg empty
+    blob = rng.uniform(0, 1, (H, W))
+    masks[3, 0] = blob < 0.2
+    masks[3, 1] = blob > 0.85
+    out["tt_masks"] = masks
+    out["tt_out"] = np.stack([trimap_transform(torch.from_numpy(m)[None, None])[0, 0].numpy() for m in masks])
+    # fba_fusion
+    a = torch.from_numpy(rng.uniform(-0.2, 1.2, (1, 1, 9, 11)).astype(np.float32)).clamp(0, 1)
+    img = torch.from_numpy(rng.uniform(0, 1, (1, 3, 9, 11)).astype(np.float32))
+    Fg = torch.from_numpy(rng.uniform(0, 1, (1, 3, 9, 11)).astype(np.float32))
+    Bg = torch.from_numpy(rng.uniform(0, 1, (1, 3, 9, 11)).astype(np.float32))
+    fa, fF, fB = fba_fusion(a, img, Fg, Bg)
+    out.update(ff_a=a.numpy(), ff_img=img.numpy(), ff_F=Fg.numpy(), ff_B=Bg.numpy(),
+               ff_out=torch.cat([fa, fF, fB], 1).numpy())
+    # pad_divide_by
+    pads = []
+    for (h, w, d) in [(100, 150, 32), (1080, 1920, 32), (33, 65, 16), (64, 64, 32), (70, 90, 32), (1, 31, 32)]:
+        _, pad = pad_divide_by([torch.zeros(1, 1, h, w)], d, (h, w))
+        pads.append([h, w, d] + list(pad))
+    out["pads"] = np.asarray(pads)
+    # Memory.forward
+    mem = Memory()
+    for T in (1, 2, 5):
+        h, w = 5, 7
+        mk = torch.from_numpy(rng.normal(0, 3, (1, 128, T, h, w)).astype(np.float32))
+        mv = torch.from_numpy(rng.normal(0, 1, (1, 512, T, h, w)).astype(np.float32))
+        qk = torch.from_numpy(rng.normal(0, 3, (1, 128, h, w)).astype(np.float32))
+        qv = torch.from_numpy(rng.normal(0, 1, (1, 512, h, w)).astype(np.float32))
+        out["mem%d_mk" % T], out["mem%d_mv" % T] = mk.numpy(), mv.numpy()
+        out["mem%d_qk" % T], out["mem%d_qv" % T] = qk.numpy(), qv.numpy()
+        out["mem%d_out" % T] = mem(mk, mv, qk, qv).numpy()
+    # weight-standardised conv + GroupNorm(32) block
+    conv = L.Conv2d(24, 64, 3, padding=2, dilation=2, bias=True)
+    gn = L.BatchNorm2d(64)
+    w = rng.normal(0.02, 0.05, (64, 24, 3, 3)).astype(np.float32)
+    b = rng.normal(0, 0.1, 64).astype(np.float32)
+    g = rng.uniform(0.5, 1.5, 64).astype(np.float32)
+    be = rng.normal(0, 0.1, 64).astype(np.float32)
+    conv.weight.data = torch.from_numpy(w); conv.bias.data = torch.from_numpy(b)
+    gn.weight.data = torch.from_numpy(g); gn.bias.data = torch.from_numpy(be)
+    x = torch.from_numpy(rng.normal(0, 1, (1, 24, 13, 17)).astype(np.float32))
+    out.update(ws_w=w, ws_b=b, ws_g=g, ws_be=be, ws_x=x.numpy(), ws_out=gn(conv(x)).detach().numpy())
+    return out
+
+
+def main():
+    torch.set_num_threads(8)
+    meta = {}
+    for (name, H, W, T, style, skip, max_num, dk, cs) in SEQUENCES:
+        res = run_sequence(H, W, T, style, skip, max_num, dk, cs)
+        np.savez_compressed(os.path.join(HERE, "seq_%s.npz" % name), **res)
+        meta[name] = dict(H=H, W=W, T=T, style=style, skip=skip, max_num=max_num, dilate_kernel=dk,
+                          clip_seed=cs, weight_seed=0, bank=res["bank"].tolist())
+        print(name, "bank", res["bank"].tolist(), "alpha mean %.4f" % res["alpha"].mean())
+    np.savez_compressed(os.path.join(HERE, "ops.npz"), **op_fixtures())
+    json.dump(meta, open(os.path.join(HERE, "sequences.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()

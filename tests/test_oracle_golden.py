@@ -1,0 +1,101 @@
+"""CPU: the oracle (oracle/otvm_oracle.py) against fixtures produced by the reference itself."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import otvm_oracle as O
+from tests.common import GOLDEN, clip_inputs, frame_flags, load_golden, load_sequences_meta
+
+META = load_sequences_meta()
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return np.load(os.path.join(GOLDEN, "ops.npz"))
+
+
+def test_state_dict_spec_matches_reference():
+    import json
+    from otvm_amd.state_spec import state_dict_spec
+    gold = json.load(open(os.path.join(GOLDEN, "state_dict_spec.json")))
+    spec = state_dict_spec()
+    assert [k for k, _, _ in gold] == list(spec.keys())
+    for k, shape, dt in gold:
+        assert tuple(shape) == tuple(spec[k][0]) and dt == spec[k][1], k
+    assert len(spec) == 785
+
+
+def test_trimap_transform_vs_reference(ops):
+    for m, ref in zip(ops["tt_masks"], ops["tt_out"]):
+        got = O.trimap_transform(torch.from_numpy(m)).numpy()
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-6)
+    # empty class -> all-zero triple (utils/utils.py:32)
+    assert ops["tt_out"][0][3:].max() == 0 and ops["tt_out"][2][:3].max() == 0
+
+
+def test_exact_edt_is_exact():
+    rng = np.random.Generator(np.random.PCG64(3))
+    for _ in range(5):
+        m = rng.uniform(0, 1, (19, 23)) < 0.9
+        m[3, 4] = False
+        d = O.exact_edt(m)
+        d2 = O.exact_edt_sq_bruteforce(m)
+        np.testing.assert_array_equal(np.round(d.astype(np.float64) ** 2).astype(np.int64), d2)
+        np.testing.assert_array_equal(d, np.sqrt(d2.astype(np.float64)).astype(np.float32))
+
+
+def test_fba_fusion_vs_reference(ops):
+    a, F_, B_ = O.fba_fusion(torch.from_numpy(ops["ff_a"]), torch.from_numpy(ops["ff_img"]),
+                             torch.from_numpy(ops["ff_F"]), torch.from_numpy(ops["ff_B"]))
+    np.testing.assert_allclose(torch.cat([a, F_, B_], 1).numpy(), ops["ff_out"], rtol=0, atol=1e-6)
+
+
+def test_pad_amounts_vs_reference(ops):
+    for h, w, d, lw, uw, lh, uh in ops["pads"]:
+        assert O.pad_amounts(int(h), int(w), int(d)) == (lw, uw, lh, uh)
+
+
+@pytest.mark.parametrize("T", [1, 2, 5])
+def test_memory_read_vs_reference(ops, T):
+    got = O.memory_read(torch.from_numpy(ops["mem%d_mk" % T][0]), torch.from_numpy(ops["mem%d_mv" % T][0]),
+                        torch.from_numpy(ops["mem%d_qk" % T][0]), torch.from_numpy(ops["mem%d_qv" % T][0]))
+    np.testing.assert_allclose(got.numpy(), ops["mem%d_out" % T][0], rtol=1e-5, atol=1e-5)
+
+
+def test_ws_conv_gn_vs_reference(ops):
+    import torch.nn.functional as F
+    w = O.standardise_weight(torch.from_numpy(ops["ws_w"]))
+    y = F.conv2d(torch.from_numpy(ops["ws_x"]), w, torch.from_numpy(ops["ws_b"]), 1, 2, 2)
+    y = F.group_norm(y, 32, torch.from_numpy(ops["ws_g"]), torch.from_numpy(ops["ws_be"]), 1e-5)
+    np.testing.assert_allclose(y.numpy(), ops["ws_out"], rtol=1e-5, atol=1e-5)
+
+
+def test_bank_policy_trajectory():
+    """simulated frame ids resident in the bank, skip=5, max=5."""
+    bank = []
+    seen = {}
+    for t in range(30):
+        seen[t] = [b[2] for b in bank]
+        bank = O.bank_update(bank, (None, None, t), t == 0, t % 5 == 0, 5)
+    assert seen[1] == [0] and seen[2] == [0, 1] and seen[3] == [0, 2] and seen[6] == [0, 4, 5]
+    assert seen[11] == [0, 4, 9, 10] and seen[16] == [0, 4, 9, 14, 15] and seen[21] == [0, 9, 14, 19, 20]
+    assert seen[26] == [0, 14, 19, 24, 25]
+
+
+@pytest.mark.parametrize("name", sorted(META.keys()))
+def test_oracle_sequence_vs_reference(name, synth_sd):
+    meta = META[name]
+    gold = load_golden(name)
+    orc = O.OtvmOracle(synth_sd, dilate_kernel=meta["dilate_kernel"])
+    worst = 0.0
+    for t, (a, fg, bg, tri_gt) in enumerate(clip_inputs(meta)):
+        out = orc.frame(a, fg, bg, tri_gt=tri_gt, frame_id=t, **frame_flags(meta, t))
+        assert len(orc.bank) == gold["bank"][t]
+        da = np.abs(out[3][0, 0, 0].numpy() - gold["alpha"][t]).max()
+        dt = np.abs(out[1][0, 0].numpy() - gold["trimap"][t]).max()
+        worst = max(worst, da, dt)
+        # bitwise on the machine that generated the fixtures; 1e-3 is the fp32 contract elsewhere
+        assert da <= 1e-3 and dt <= 5e-3, (name, t, da, dt)
+    np.testing.assert_array_equal(out[2][0, 0].numpy(), gold["tri_gt"])
