@@ -1,0 +1,156 @@
+/* otvm_hip.h -- C ABI of libotvm_hip.so: the MI355X (gfx950) kernels behind the OTVM per-frame
+ * inference path.
+ *
+ * The reference (Hongje/OTVM) has no FFI: its drop-in boundary is the Python nn.Module call
+ * `EvalModel.forward` (reference models/alpha/model.py:391-512).  The product keeps that Python
+ * surface (otvm_amd/alpha_model.py) and implements every device operation below it through this
+ * C ABI -- plain pointers, sizes and a hipStream_t; no torch types.  Each entry point cites the
+ * reference code whose device work it replaces.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless noted; `stream` is a hipStream_t passed as void*;
+ *   - activations are NHWC fp32 with an explicit pixel stride `ld` (elements), so a tensor may be
+ *     a channel slice of a wider buffer (this is how every torch.cat of the reference disappears);
+ *   - channel counts of device tensors are padded to a multiple of 4 (zero weights on the pad);
+ *   - every function returns 0 on success, non-zero on error; otvm_last_error() describes it.
+ */
+#ifndef OTVM_HIP_H
+#define OTVM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OTVM_ACT_NONE 0
+#define OTVM_ACT_RELU 1
+#define OTVM_ACT_LEAKY 2 /* negative slope 0.01 (nn.LeakyReLU default, FBA/models.py:305) */
+
+const char* otvm_last_error(void);
+int otvm_abi_version(void);
+
+/* ---------------------------------------------------------------- weights (load time) ----------
+ * Pack an OIHW fp32 conv weight into the K-major layout the implicit-GEMM kernel reads:
+ * w_packed[O_pad][K_pad], k = (ky*kw + kx)*I_pad + c, zero padded.
+ *   ws != 0  : apply weight standardisation first (layers_WS.py:15-21: subtract per-filter mean,
+ *              divide by sqrt(unbiased var + 1e-12) + 1e-5) -- done ONCE here instead of per forward.
+ *   scale    : optional per-output-channel multiplier (BatchNorm eval fold gamma/sqrt(var+eps),
+ *              torchvision Bottleneck inside STM.py:43-51,79-87), may be NULL.                    */
+int otvm_pack_conv_weight(const float* w_oihw, int O, int I, int kh, int kw, int ws, const float* scale,
+                          float* w_packed, int O_pad, int I_pad, int K_pad, void* stream);
+
+/* Fold an eval-mode BatchNorm (eps 1e-5, running statistics; torchvision Bottleneck used by
+ * STM.py:43-51,79-87) into a per-channel scale/bias: scale = gamma/sqrt(var+eps),
+ * bias = beta - mean*scale.                                                                       */
+int otvm_fold_bn(const float* gamma, const float* beta, const float* mean, const float* var, float eps, int n,
+                 float* scale, float* bias, void* stream);
+
+/* ---------------------------------------------------------------- convolution ------------------
+ * Implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32), replaces every F.conv2d of
+ * the path (180 per non-first frame).  out = act(conv(in') + bias + residual) where
+ * in' = relu(in) if in_relu (STM.py:23-24 pre-activation ResBlock) else in.                       */
+typedef struct {
+    const float* in;  int H, W, Cin, in_ld;         /* Cin: padded channel count, multiple of 4 */
+    const float* w;   int K_pad;                    /* packed weight from otvm_pack_conv_weight */
+    const float* bias;                              /* [Cout] or NULL                           */
+    const float* residual; int res_ld;              /* [Ho*Wo, Cout] view or NULL               */
+    float* out;       int Ho, Wo, Cout, out_ld;
+    int kh, kw, stride, pad, dil;
+    int in_relu, act;
+} otvm_conv_params;
+int otvm_conv2d(const otvm_conv_params* p, void* stream);
+
+/* ---------------------------------------------------------------- GroupNorm(32) ----------------
+ * nn.GroupNorm(32, C, eps=1e-5, affine) (layers_WS.py:26-27, FBA/models.py:272-276), two passes:
+ * stats accumulates per-group sum / sum-of-squares in fp64 (stats[32][2], must be zeroed before);
+ * apply computes y = act((x-mean)*rstd*gamma + beta + residual).                                  */
+int otvm_gn_stats(const float* x, int64_t P, int C, int ld, double* stats, void* stream);
+int otvm_gn_apply(const float* x, int64_t P, int C, int ld, const double* stats, const float* gamma,
+                  const float* beta, const float* residual, int res_ld, int act,
+                  float* out, int out_ld, void* stream);
+
+/* ---------------------------------------------------------------- pooling / resampling ---------*/
+/* F.max_pool2d(3, 2, 1) (resnet_GN_WS.py:98, torchvision resnet maxpool in STM.py:47,83) */
+int otvm_maxpool3x3s2(const float* in, int H, int W, int C, int ld, float* out, int out_ld, void* stream);
+/* F.interpolate(mode='bilinear', align_corners=False) to (Ho,Wo); out = up(in) [+ add]
+ * (FBA/models.py:358-376, STM.py:115) */
+int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, int in_ld, const float* add, int add_ld,
+                           float* out, int Ho, int Wo, int out_ld, void* stream);
+/* nn.AdaptiveAvgPool2d(s) for s in {1,2,3,6} in one launch (FBA/models.py:300-306);
+ * out = 50 bins x C, bins ordered scale-major then row-major.                                     */
+int otvm_ppm_pool(const float* in, int H, int W, int C, int ld, float* out, void* stream);
+
+/* ---------------------------------------------------------------- memory read (STM.py:140-163) -
+ * mem[q, :] = sum_m softmax_m(K[m,:].Q[q,:] / sqrt(128)) V[m,:], m over T slots x hw positions.
+ * Flash-style: one partial (max, sum, acc) per (query tile, slot), merged by a combine kernel;
+ * the [T*hw, hw] probability matrix of the reference is never materialised.
+ *   keys[t] : [hw,128] fp32, vals[t] : [hw,512] fp32 (device pointer tables live on the HOST)
+ *   out     : [hw, 512] view with pixel stride out_ld (the first half of the 1024-ch m4 tensor)
+ *   ws      : workspace >= otvm_memory_read_ws_bytes(hw, T) bytes                                 */
+int64_t otvm_memory_read_ws_bytes(int hw, int T);
+int otvm_memory_read(const float* q_key, int q_ld, const float* const* keys, const float* const* vals, int T,
+                     int hw, float* out, int out_ld, void* ws, void* stream);
+
+/* ---------------------------------------------------------------- frame glue --------------------
+ * preprocess: alpha/model.py:380-389,408-414 + STM.py:53-57,89-93.  fg,bg: [3,H,W] fp32 BGR 0..255
+ * planes; a: [H,W] in [0,1].  Writes the zero-padded 0..1 RGB composite and its normalised copies
+ * into channel slices of the consumers' input buffers and the un-padded `scaled_imgs` [3,H,W].   */
+typedef struct {
+    const float* fg; const float* bg; const float* a;
+    int H, W, Hp, Wp, lh, lw;
+    float mean[3], std[3];        /* IMG_MEAN / IMG_STD                    */
+    float mean_q[3], std_q[3];    /* trimap.model.Encoder_Q.mean / std     */
+    float mean_m[3], std_m[3];    /* trimap.model.Encoder_M.mean / std     */
+    float* scaled_imgs;           /* [3,H,W] planar RGB 0..1 (returned)    */
+    float* x11; int x11_ld;       /* ch0-2 <- normalised                   */
+    float* sq;  int sq_ld;        /* ch0-2 <- Encoder_Q normalised         */
+    float* sm;  int sm_ld;        /* ch0-2 <- Encoder_M normalised         */
+    float* d80; int d80_ld;       /* ch64-66 <- normalised, ch67-69 <- 0..1 */
+} otvm_preprocess_params;
+int otvm_preprocess(const otvm_preprocess_params* p, void* stream);
+
+/* pad a [3,H,W] one-hot/soft trimap to [3,Hp,Wp] (bg plane padded with 1, others 0;
+ * alpha/model.py:410) */
+int otvm_pad_trimap(const float* tri, int H, int W, float* out, int Hp, int Wp, int lh, int lw, void* stream);
+
+/* STM decoder tail: x4 bilinear upsample of the [h4*w4,3] logits (ld) + softmax over the 3 classes
+ * -> planar probs [3,Hp,Wp] (STM.py:136, alpha/model.py:440) */
+int otvm_upsample4_softmax3(const float* logits, int h4, int w4, int ld, float* probs, void* stream);
+
+/* 8-channel trimap encoding (alpha/model.py:40-53, utils/utils.py:12-39): argmax class map, exact
+ * Euclidean distance transform of the bg / fg classes on device (integer d^2), three Gaussians each,
+ * plus the two soft channels.  probs: planar [3,Hp,Wp].  Writes x11 ch3-10 and d80 ch70-71.
+ *   cls_override: optional u8 class map [Hp*Wp] used INSTEAD of the argmax (tests only), may be NULL
+ *   cls_out     : u8 class map [Hp*Wp] (always written)
+ *   ws          : workspace >= otvm_trimap_encode_ws_bytes(Hp,Wp)                                  */
+int64_t otvm_trimap_encode_ws_bytes(int Hp, int Wp);
+int otvm_trimap_encode(const float* probs, int Hp, int Wp, const uint8_t* cls_override, uint8_t* cls_out,
+                       float* x11, int x11_ld, float* d80, int d80_ld, void* ws, void* stream);
+
+/* FBA / refinement heads: 1x1 conv 16->7 (+3 trimap logits when n_out==10), clamp/sigmoid and
+ * fba_fusion (FBA/models.py:279-288,383-388,425-432), softmax of the trimap logits
+ * (alpha/model.py:460).  hid: [P,16] view (ld).  img: [P,3] view (0..1 RGB).
+ *   alpha_out/alpha_stride : fused alpha written at alpha_out[p*alpha_stride]
+ *   tri_out  : planar [3,P] softmax probs (n_out==10) or NULL
+ *   sm       : Encoder_M input buffer; ch3 <- p_un, ch4 <- p_fg, ch5 <- alpha (n_out==10) or NULL */
+int otvm_fba_head(const float* hid, int hid_ld, const float* w, const float* b, int n_out, const float* img,
+                  int img_ld, int64_t P, float* alpha_out, int alpha_stride, float* tri_out, float* sm, int sm_ld,
+                  void* stream);
+
+/* crop the padding and produce the returned tensors (alpha/model.py:495-508, eval.py:209):
+ * alpha [H,W] fp32, alpha_u8 [H,W] = trunc(alpha*255) (may be NULL), trimap [3,H,W] (may be NULL) */
+int otvm_crop_outputs(const float* alpha_p, const float* tri_p, int Hp, int Wp, int H, int W, int lh, int lw,
+                      float* alpha, uint8_t* alpha_u8, float* tri, void* stream);
+
+/* first-frame trimap from a GT alpha (alpha/model.py:342-362): unknown = dilate(0<a<1) with a
+ * (2r+1)^2 max filter, fg = (a==1), bg = (a==0); out planar one-hot [3,H,W]; ws >= H*W bytes      */
+int otvm_trimap_from_alpha(const float* a, int H, int W, int r, float* out, void* ws, void* stream);
+
+/* one-hot of the argmax of a planar [3,H,W] trimap (alpha/model.py:356-362, returned tri_gt) */
+int otvm_onehot_argmax3(const float* tri, int64_t P, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OTVM_HIP_H */

@@ -1,0 +1,63 @@
+"""Mirror of reference ``models/alpha/model.py::EvalModel`` (lines 314-512): THE drop-in boundary.
+
+Same constructor (``dilate_kernel, trimap, stage``), same 785-key ``state_dict``, same stateful
+``forward(a, fg, bg, tri=None, tri_gt=None, first_frame=False, last_frame=False, memorize=False,
+max_memory_num=2, large_input=False)`` returning the same 5-tuple.  All device work goes through
+``libotvm_hip.so``; there is no PyTorch/CPU fallback -- on a CPU device ``forward`` raises.
+"""
+import torch
+from torch import nn
+
+from .engine import HipEngine
+from .modules import attach_from_spec
+
+
+class EvalModel(nn.Module):
+    def __init__(self, dilate_kernel=None, eps=0, trimap=None, stage=1):
+        super().__init__()
+        if stage != 4 or trimap is None:
+            raise NotImplementedError("otvm_amd implements the stage-4 (joint trimap+alpha) inference path only")
+        self.stage = stage
+        self.refinement = True
+        self.DILATION_KERNEL = dilate_kernel
+        self.EPS = eps
+        self.IMG_SCALE = 1.0 / 255
+        self.TRIMAP_CHANNEL = 8
+        self.memory_update = False
+        attach_from_spec(self, "", "")           # everything except the trimap.* keys ...
+        for k in [k for k in self._modules if k == "trimap"]:
+            del self._modules[k]
+        self.trimap = trimap                      # ... which live in the FullModel_eval passed in (alpha/model.py:37)
+        self._engine = None
+        self._engine_key = None
+
+    # -- engine lifetime: rebuilt when the weights change or the module moves
+    def _get_engine(self):
+        dev = self.IMG_MEAN.device
+        if dev.type != "cuda":
+            raise RuntimeError("otvm_amd.EvalModel: parameters are on %s; move the model to the GPU (.cuda()) -- "
+                               "the HIP path has no CPU fallback" % dev)
+        key = (str(dev), tuple(p._version for p in self.parameters()), tuple(b._version for b in self.buffers()))
+        if self._engine is None or key != self._engine_key:
+            self._engine = HipEngine(self.state_dict(), dev)
+            self._engine_key = key
+        return self._engine
+
+    @property
+    def memories(self):
+        """Bank introspection (reference: self.memories['key'].shape[3] slots)."""
+        eng = self._engine
+        return {"frames": [] if eng is None else [s["frame"] for s in eng.bank]}
+
+    @torch.no_grad()
+    def forward(self, a, fg, bg, tri=None, tri_gt=None, first_frame=False, last_frame=False, memorize=False,
+                max_memory_num=2, large_input=False, _frame_id=0, _cls_override=None):
+        if tri is not None:
+            # alpha/model.py:395-396: unreachable from eval.py (EvalDataset is built with trimap=None, eval.py:133)
+            raise NotImplementedError("per-frame `tri` input is not part of the reference eval path")
+        eng = self._get_engine()
+        out = eng.frame(a, fg, bg, tri_gt=tri_gt, first_frame=bool(first_frame), last_frame=bool(last_frame),
+                        memorize=bool(memorize), max_memory_num=int(max_memory_num),
+                        dilate_kernel=self.DILATION_KERNEL, frame_id=_frame_id, cls_override=_cls_override)
+        self.memory_update = memorize
+        return out

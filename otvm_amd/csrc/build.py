@@ -1,0 +1,60 @@
+"""Build libotvm_hip.so (gfx950) in-tree with hipcc.  No torch extension machinery: the library is a
+plain C-ABI shared object (include/otvm_hip.h) loaded through ctypes, so it is independent of the
+torch wheel's ROCm version."""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.dirname(HERE)
+LIB = os.path.join(PKG, "libotvm_hip.so")
+OBJ = os.path.join(HERE, "build")
+
+SOURCES = [
+    ("error.cpp", []),
+    ("conv_igemm.hip", []),
+    ("groupnorm.hip", []),
+    ("resample.hip", ["-ffp-contract=off"]),
+    ("glue.hip", ["-ffp-contract=off"]),
+    ("edt.hip", ["-ffp-contract=off"]),
+    ("memory_read.hip", []),
+]
+COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    hipcc = _hipcc()
+    deps = [os.path.join(HERE, "common.h"), os.path.join(os.path.dirname(PKG), "include", "otvm_hip.h"), __file__]
+    objs, relink = [], force
+    for src, extra in SOURCES:
+        s = os.path.join(HERE, src)
+        o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        objs.append(o)
+        if force or _newer(s, o) or any(_newer(d, o) for d in deps):
+            cmd = [hipcc] + COMMON + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+            relink = True
+    if relink or not os.path.exists(LIB):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

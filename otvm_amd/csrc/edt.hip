@@ -1,0 +1,173 @@
+// 8-channel trimap encoding on device (reference models/alpha/model.py:40-53, utils/utils.py:12-39).
+//
+// The reference ships every trimap to the host, runs cv2.distanceTransform (exact L2) on one core and
+// uploads the result -- 6-8 times per frame.  Here the exact Euclidean distance transform runs on the
+// GPU in integer arithmetic (squared distances are exact integers):
+//   phase 1 (columns): g[y][x] = distance to the nearest class pixel within the column;
+//   phase 2 (rows)   : d2[x] = min_i (x-i)^2 + g[i]^2 by Meijster's lower-envelope scan (integer
+//                      separator, no floating point), one thread per image row;
+//   encode           : d = sqrtf(d2) (correctly rounded, like OpenCV's float output), then
+//                      exp(-(d*d) / (2 (sigma*320)^2)) for sigma in {0.02, 0.08, 0.16}; an empty class
+//                      produces zeros (utils/utils.py:32).
+// Classes: k=0 background (argmax == 0), k=1 foreground (argmax == 2).
+#include "common.h"
+
+namespace {
+
+constexpr int EDT_INF = 1 << 14;     // > any image side handled (asserted on the host side)
+
+__global__ void classify_kernel(const float* __restrict__ probs, int64_t P, const uint8_t* __restrict__ cls_override,
+                                uint8_t* __restrict__ cls_out, int* __restrict__ flags, float* __restrict__ x11, int x11_ld,
+                                float* __restrict__ d80, int d80_ld) {
+    int has_bg = 0, has_fg = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const float p0 = probs[i], p1 = probs[P + i], p2 = probs[2 * P + i];
+        int cls;
+        if (cls_override) {
+            cls = cls_override[i];
+        } else {                          // tri.max(dim)[1]: first maximal index (alpha/model.py:42)
+            cls = 0;
+            float m = p0;
+            if (p1 > m) { m = p1; cls = 1; }
+            if (p2 > m) { cls = 2; }
+        }
+        cls_out[i] = (uint8_t)cls;
+        has_bg |= (cls == 0);
+        has_fg |= (cls == 2);
+        x11[i * x11_ld + 9] = p0;         // trimap2_soft = [tri[:,0], tri[:,2]] (alpha/model.py:51)
+        x11[i * x11_ld + 10] = p2;
+        d80[i * d80_ld + 70] = p0;        // two_chan_trimap (FBA/models.py:378, :418)
+        d80[i * d80_ld + 71] = p2;
+    }
+    if (__any(has_bg) && (threadIdx.x & 63) == 0) atomicOr(&flags[0], 1);
+    if (__any(has_fg) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
+}
+
+// phase 1: one thread per (class, column)
+__global__ void edt_columns_kernel(const uint8_t* __restrict__ cls, int H, int W, int* __restrict__ g) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * W) return;
+    const int k = t / W, x = t - k * W;
+    const uint8_t target = k == 0 ? 0 : 2;
+    int* gk = g + (int64_t)k * H * W;
+    int d = EDT_INF;
+#pragma unroll 8
+    for (int y = 0; y < H; ++y) {
+        const bool seed = cls[(int64_t)y * W + x] == target;
+        d = seed ? 0 : (d + 1 > EDT_INF ? EDT_INF : d + 1);
+        gk[(int64_t)y * W + x] = d;
+    }
+    d = EDT_INF;
+#pragma unroll 8
+    for (int y = H - 1; y >= 0; --y) {
+        const int gv = gk[(int64_t)y * W + x];
+        d = gv == 0 ? 0 : (d + 1 > EDT_INF ? EDT_INF : d + 1);
+        gk[(int64_t)y * W + x] = gv < d ? gv : d;
+    }
+}
+
+// phase 2: one thread per (class, row); s/t stacks live in global scratch, interleaved by row
+__global__ void edt_rows_kernel(const int* __restrict__ g, int H, int W, int* __restrict__ sbuf, int* __restrict__ tbuf,
+                                int* __restrict__ d2) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= 2 * H) return;
+    const int R = 2 * H;
+    const int* gr = g + (int64_t)r * W;          // (k*H + y) rows are contiguous
+    int* out = d2 + (int64_t)r * W;
+#define S(q) sbuf[(int64_t)(q) * R + r]
+#define T(q) tbuf[(int64_t)(q) * R + r]
+    int q = 0;
+    S(0) = 0;
+    T(0) = 0;
+    int sq = 0, gsq = gr[0], tq = 0;             // cached top of stack: s[q], g[s[q]], t[q]
+    for (int u = 1; u < W; ++u) {
+        const int gu = gr[u];
+        while (q >= 0) {
+            const int a = tq - sq, b = tq - u;
+            if (a * a + gsq * gsq > b * b + gu * gu) {
+                --q;
+                if (q >= 0) { sq = S(q); tq = T(q); gsq = gr[sq]; }
+            } else {
+                break;
+            }
+        }
+        if (q < 0) {
+            q = 0;
+            S(0) = u; T(0) = 0;
+            sq = u; gsq = gu; tq = 0;
+        } else {
+            // Sep(i,u) = (u^2 - i^2 + g(u)^2 - g(i)^2) div (2(u-i)), non-negative here
+            const int w = 1 + (u * u - sq * sq + gu * gu - gsq * gsq) / (2 * (u - sq));
+            if (w < W) {
+                ++q;
+                S(q) = u; T(q) = w;
+                sq = u; gsq = gu; tq = w;
+            }
+        }
+    }
+    for (int u = W - 1; u >= 0; --u) {
+        const int a = u - sq;
+        out[u] = a * a + gsq * gsq;
+        if (u == tq) {
+            --q;
+            if (q >= 0) { sq = S(q); tq = T(q); gsq = gr[sq]; }
+        }
+    }
+#undef S
+#undef T
+}
+
+__global__ void edt_encode_kernel(const int* __restrict__ d2, int64_t P, const int* __restrict__ flags,
+                                  float* __restrict__ x11, int x11_ld) {
+    // 2*((sigma*L)^2), L = 320 (utils/utils.py:33-37), evaluated in double like the Python expression
+    const float den0 = (float)(2.0 * ((0.02 * 320) * (0.02 * 320)));
+    const float den1 = (float)(2.0 * ((0.08 * 320) * (0.08 * 320)));
+    const float den2 = (float)(2.0 * ((0.16 * 320) * (0.16 * 320)));
+    const int f0 = flags[0], f1 = flags[1];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float e0 = 0.f, e1 = 0.f, e2 = 0.f;
+            if (k == 0 ? f0 : f1) {
+                const float d = sqrtf((float)d2[(int64_t)k * P + i]);
+                const float v = -(d * d);                      // -dt(1 - tk)**2
+                e0 = expf(v / den0);
+                e1 = expf(v / den1);
+                e2 = expf(v / den2);
+            }
+            x11[i * x11_ld + 3 + 3 * k] = e0;
+            x11[i * x11_ld + 4 + 3 * k] = e1;
+            x11[i * x11_ld + 5 + 3 * k] = e2;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t otvm_trimap_encode_ws_bytes(int Hp, int Wp) {
+    const int64_t P = (int64_t)Hp * Wp;
+    return 256 + 4 * (2 * P) * 4;     // flags | g | d2 | s | t   (int32 each, 2 classes)
+}
+
+extern "C" int otvm_trimap_encode(const float* probs, int Hp, int Wp, const uint8_t* cls_override, uint8_t* cls_out,
+                                  float* x11, int x11_ld, float* d80, int d80_ld, void* ws, void* stream) {
+    OTVM_REQUIRE(probs && cls_out && x11 && d80 && ws, "otvm_trimap_encode: null pointer");
+    OTVM_REQUIRE(Hp < EDT_INF / 2 && Wp < EDT_INF / 2, "otvm_trimap_encode: image too large (%dx%d)", Hp, Wp);
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t P = (int64_t)Hp * Wp;
+    int* flags = (int*)ws;
+    int* g = (int*)((char*)ws + 256);
+    int* d2 = g + 2 * P;
+    int* sb = d2 + 2 * P;
+    int* tb = sb + 2 * P;
+    if (hipMemsetAsync(flags, 0, 256, s) != hipSuccess) { otvm_set_error("otvm_trimap_encode: memset failed"); return 2; }
+    int64_t nb = (P + 255) / 256;
+    const int grid = (int)(nb > 4096 ? 4096 : nb);
+    hipLaunchKernelGGL(classify_kernel, dim3(grid), dim3(256), 0, s, probs, P, cls_override, cls_out, flags, x11, x11_ld, d80,
+                       d80_ld);
+    hipLaunchKernelGGL(edt_columns_kernel, dim3(otvm_ceil_div(2 * Wp, 64)), dim3(64), 0, s, cls_out, Hp, Wp, g);
+    hipLaunchKernelGGL(edt_rows_kernel, dim3(otvm_ceil_div(2 * Hp, 64)), dim3(64), 0, s, g, Hp, Wp, sb, tb, d2);
+    hipLaunchKernelGGL(edt_encode_kernel, dim3(grid), dim3(256), 0, s, d2, P, flags, x11, x11_ld);
+    OTVM_CHECK_LAUNCH("otvm_trimap_encode");
+    return 0;
+}

@@ -1,0 +1,275 @@
+// Per-frame glue of EvalModel.forward (reference models/alpha/model.py:380-512): compositing and
+// normalisation, trimap padding, the FBA/refinement heads with fba_fusion, output cropping, and the
+// first-frame trimap from a GT alpha.  All elementwise / HBM-bound.  Compiled with
+// -ffp-contract=off so the elementwise arithmetic follows the reference's operation order exactly.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__global__ void preprocess_kernel(const otvm_preprocess_params p) {
+    const int64_t P = (int64_t)p.Hp * p.Wp;
+    const float s = 1.f / 255.f;                              // IMG_SCALE, alpha/model.py:27
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const int yp = (int)(i / p.Wp), xp = (int)(i - (int64_t)yp * p.Wp);
+        const int y = yp - p.lh, x = xp - p.lw;
+        float img[3] = {0.f, 0.f, 0.f};
+        if ((unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W) {
+            const int64_t o = (int64_t)y * p.W + x, plane = (int64_t)p.H * p.W;
+            const float a = p.a[o];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {                     // BGR -> RGB flip (alpha/model.py:384-385)
+                const float sf = p.fg[(2 - c) * plane + o] * s;
+                const float sb = p.bg[(2 - c) * plane + o] * s;
+                img[c] = sf * a + sb * (1.f - a);             // alpha/model.py:386
+                p.scaled_imgs[c * plane + o] = img[c];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float n = (img[c] - p.mean[c]) / p.std[c];  // alpha/model.py:414
+            p.x11[i * p.x11_ld + c] = n;
+            p.d80[i * p.d80_ld + 64 + c] = n;                 // conv_out[-6][:, :3] (FBA/models.py:377)
+            p.d80[i * p.d80_ld + 67 + c] = img[c];            // img (FBA/models.py:377)
+            p.sq[i * p.sq_ld + c] = (img[c] - p.mean_q[c]) / p.std_q[c];   // STM.py:90
+            p.sm[i * p.sm_ld + c] = (img[c] - p.mean_m[c]) / p.std_m[c];   // STM.py:54
+        }
+    }
+}
+
+__global__ void pad_trimap_kernel(const float* __restrict__ tri, int H, int W, float* __restrict__ out, int Hp, int Wp,
+                                  int lh, int lw) {
+    const int64_t P = (int64_t)Hp * Wp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const int yp = (int)(i / Wp), xp = (int)(i - (int64_t)yp * Wp);
+        const int y = yp - lh, x = xp - lw;
+        const bool in = (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W;
+        const int64_t o = (int64_t)y * W + x, plane = (int64_t)H * W;
+        out[i] = in ? tri[o] : 1.f;                           // bg padded with 1 (alpha/model.py:410)
+        out[P + i] = in ? tri[plane + o] : 0.f;
+        out[2 * P + i] = in ? tri[2 * plane + o] : 0.f;
+    }
+}
+
+__global__ void upsample4_softmax3_kernel(const float* __restrict__ lg, int h4, int w4, int ld, float* __restrict__ probs) {
+    const int Hp = h4 * 4, Wp = w4 * 4;
+    const int64_t P = (int64_t)Hp * Wp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const int oy = (int)(i / Wp), ox = (int)(i - (int64_t)oy * Wp);
+        float fy = ((float)oy + 0.5f) * 0.25f - 0.5f, fx = ((float)ox + 0.5f) * 0.25f - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < h4 - 1 ? 1 : 0), x1 = x0 + (x0 < w4 - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        float l[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v00 = lg[((int64_t)y0 * w4 + x0) * ld + c], v01 = lg[((int64_t)y0 * w4 + x1) * ld + c];
+            const float v10 = lg[((int64_t)y1 * w4 + x0) * ld + c], v11 = lg[((int64_t)y1 * w4 + x1) * ld + c];
+            l[c] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+        }
+        const float m = fmaxf(l[0], fmaxf(l[1], l[2]));
+        const float e0 = expf(l[0] - m), e1 = expf(l[1] - m), e2 = expf(l[2] - m);
+        const float inv = 1.f / (e0 + e1 + e2);
+        probs[i] = e0 * inv;
+        probs[P + i] = e1 * inv;
+        probs[2 * P + i] = e2 * inv;
+    }
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+
+// 1x1 conv 16 -> n_out, clamp / sigmoid, fba_fusion (FBA/models.py:279-288; the B update reads the
+// already-updated F), softmax of the 3 trimap-refinement logits.
+__global__ __launch_bounds__(256) void fba_head_kernel(const float* __restrict__ hid, int hid_ld,
+                                                       const float* __restrict__ w, const float* __restrict__ b, int n_out,
+                                                       const float* __restrict__ img, int img_ld, int64_t P,
+                                                       float* __restrict__ alpha_out, int alpha_stride,
+                                                       float* __restrict__ tri_out, float* __restrict__ sm, int sm_ld) {
+    __shared__ float sw[10 * 16 + 10];
+    for (int i = threadIdx.x; i < n_out * 16; i += blockDim.x) sw[i] = w[i];
+    for (int i = threadIdx.x; i < n_out; i += blockDim.x) sw[160 + i] = b[i];
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        float h[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(hid + i * hid_ld + 4 * k);
+            h[4 * k] = v.x; h[4 * k + 1] = v.y; h[4 * k + 2] = v.z; h[4 * k + 3] = v.w;
+        }
+        float o[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+            if (j < n_out) {
+                float acc = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc += sw[j * 16 + k] * h[k];
+                o[j] = acc + sw[160 + j];
+            } else {
+                o[j] = 0.f;
+            }
+        }
+        float al = clamp01(o[0]);
+        float im[3], F[3], B[3];
+        float num = 0.f, den = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            im[c] = img[i * img_ld + c];
+            const float f0 = sigmoidf(o[1 + c]), b0 = sigmoidf(o[4 + c]);
+            float fn = al * im[c] + (1.f - al * al) * f0 - al * (1.f - al) * b0;
+            float bn = (1.f - al) * im[c] + (2.f * al - al * al) * b0 - al * (1.f - al) * fn;
+            F[c] = clamp01(fn);
+            B[c] = clamp01(bn);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            num += (im[c] - B[c]) * (F[c] - B[c]);
+            den += (F[c] - B[c]) * (F[c] - B[c]);
+        }
+        al = clamp01((al * 0.1f + num) / (den + 0.1f));
+        alpha_out[i * alpha_stride] = al;
+        if (n_out == 10) {
+            const float m = fmaxf(o[7], fmaxf(o[8], o[9]));
+            const float e0 = expf(o[7] - m), e1 = expf(o[8] - m), e2 = expf(o[9] - m);
+            const float inv = 1.f / (e0 + e1 + e2);
+            tri_out[i] = e0 * inv;
+            tri_out[P + i] = e1 * inv;
+            tri_out[2 * P + i] = e2 * inv;
+            if (sm) {                                           // Es = cat[tri, alpha, hid] (trimap/model.py:231)
+                sm[i * sm_ld + 3] = e1 * inv;                   // unknown prob  -> conv1_m (STM.py:58)
+                sm[i * sm_ld + 4] = e2 * inv;                   // fg prob       -> conv1_o
+                sm[i * sm_ld + 5] = al;                         // alpha         -> conv1_a
+            }
+        }
+    }
+}
+
+__global__ void crop_outputs_kernel(const float* __restrict__ alpha_p, const float* __restrict__ tri_p, int Hp, int Wp, int H,
+                                    int W, int lh, int lw, float* __restrict__ alpha, uint8_t* __restrict__ alpha_u8,
+                                    float* __restrict__ tri) {
+    const int64_t N = (int64_t)H * W, P = (int64_t)Hp * Wp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        const int64_t ip = (int64_t)(y + lh) * Wp + (x + lw);
+        const float a = alpha_p[ip];
+        alpha[i] = a;
+        if (alpha_u8) alpha_u8[i] = (uint8_t)(a * 255.f);       // (alphas*255).byte() truncates (eval.py:209)
+        if (tri) {
+            tri[i] = tri_p[ip];
+            tri[N + i] = tri_p[P + ip];
+            tri[2 * N + i] = tri_p[2 * P + ip];
+        }
+    }
+}
+
+__global__ void unknown_rowmax_kernel(const float* __restrict__ a, int H, int W, int r, uint8_t* __restrict__ tmp) {
+    const int64_t N = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        int any = 0;
+        const int lo = x - r < 0 ? 0 : x - r, hi = x + r >= W ? W - 1 : x + r;
+        for (int xx = lo; xx <= hi; ++xx) {
+            const float v = a[(int64_t)y * W + xx];
+            any |= (v > 0.f && v < 1.f);
+        }
+        tmp[i] = (uint8_t)any;
+    }
+}
+
+__global__ void trimap_from_alpha_kernel(const float* __restrict__ a, const uint8_t* __restrict__ tmp, int H, int W, int r,
+                                         float* __restrict__ out) {
+    const int64_t N = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (int64_t)y * W);
+        int any = 0;
+        const int lo = y - r < 0 ? 0 : y - r, hi = y + r >= H ? H - 1 : y + r;
+        for (int yy = lo; yy <= hi; ++yy) any |= tmp[(int64_t)yy * W + x];
+        // trimap1 = where(dilated, 1, 2*alpha).long() -> one_hot (alpha/model.py:361-362)
+        int cls = any ? 1 : (int)(2.f * a[i]);
+        cls = cls < 0 ? 0 : (cls > 2 ? 2 : cls);
+        out[i] = cls == 0 ? 1.f : 0.f;
+        out[N + i] = cls == 1 ? 1.f : 0.f;
+        out[2 * N + i] = cls == 2 ? 1.f : 0.f;
+    }
+}
+
+__global__ void onehot_argmax3_kernel(const float* __restrict__ tri, int64_t P, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v0 = tri[i], v1 = tri[P + i], v2 = tri[2 * P + i];
+        int cls = 0;
+        float m = v0;
+        if (v1 > m) { m = v1; cls = 1; }
+        if (v2 > m) { cls = 2; }
+        out[i] = cls == 0 ? 1.f : 0.f;
+        out[P + i] = cls == 1 ? 1.f : 0.f;
+        out[2 * P + i] = cls == 2 ? 1.f : 0.f;
+    }
+}
+
+int grid_for(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int otvm_preprocess(const otvm_preprocess_params* p, void* stream) {
+    OTVM_REQUIRE(p && p->fg && p->bg && p->a && p->x11 && p->sq && p->sm && p->d80 && p->scaled_imgs,
+                 "otvm_preprocess: null pointer");
+    hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for((int64_t)p->Hp * p->Wp)), dim3(256), 0, (hipStream_t)stream, *p);
+    OTVM_CHECK_LAUNCH("otvm_preprocess");
+    return 0;
+}
+
+extern "C" int otvm_pad_trimap(const float* tri, int H, int W, float* out, int Hp, int Wp, int lh, int lw, void* stream) {
+    hipLaunchKernelGGL(pad_trimap_kernel, dim3(grid_for((int64_t)Hp * Wp)), dim3(256), 0, (hipStream_t)stream, tri, H, W, out,
+                       Hp, Wp, lh, lw);
+    OTVM_CHECK_LAUNCH("otvm_pad_trimap");
+    return 0;
+}
+
+extern "C" int otvm_upsample4_softmax3(const float* logits, int h4, int w4, int ld, float* probs, void* stream) {
+    hipLaunchKernelGGL(upsample4_softmax3_kernel, dim3(grid_for((int64_t)h4 * w4 * 16)), dim3(256), 0, (hipStream_t)stream,
+                       logits, h4, w4, ld, probs);
+    OTVM_CHECK_LAUNCH("otvm_upsample4_softmax3");
+    return 0;
+}
+
+extern "C" int otvm_fba_head(const float* hid, int hid_ld, const float* w, const float* b, int n_out, const float* img,
+                             int img_ld, int64_t P, float* alpha_out, int alpha_stride, float* tri_out, float* sm,
+                             int sm_ld, void* stream) {
+    OTVM_REQUIRE(n_out == 7 || n_out == 10, "otvm_fba_head: n_out must be 7 or 10 (got %d)", n_out);
+    OTVM_REQUIRE(n_out == 7 || tri_out, "otvm_fba_head: tri_out required when n_out == 10");
+    OTVM_REQUIRE(hid_ld % 4 == 0 && ((uintptr_t)hid & 15) == 0, "otvm_fba_head: hid view must be 16-byte aligned");
+    hipLaunchKernelGGL(fba_head_kernel, dim3(grid_for(P)), dim3(256), 0, (hipStream_t)stream, hid, hid_ld, w, b, n_out, img,
+                       img_ld, P, alpha_out, alpha_stride, tri_out, sm, sm_ld);
+    OTVM_CHECK_LAUNCH("otvm_fba_head");
+    return 0;
+}
+
+extern "C" int otvm_crop_outputs(const float* alpha_p, const float* tri_p, int Hp, int Wp, int H, int W, int lh, int lw,
+                                 float* alpha, uint8_t* alpha_u8, float* tri, void* stream) {
+    hipLaunchKernelGGL(crop_outputs_kernel, dim3(grid_for((int64_t)H * W)), dim3(256), 0, (hipStream_t)stream, alpha_p, tri_p,
+                       Hp, Wp, H, W, lh, lw, alpha, alpha_u8, tri);
+    OTVM_CHECK_LAUNCH("otvm_crop_outputs");
+    return 0;
+}
+
+extern "C" int otvm_trimap_from_alpha(const float* a, int H, int W, int r, float* out, void* ws, void* stream) {
+    OTVM_REQUIRE(r >= 0 && ws, "otvm_trimap_from_alpha: bad arguments");
+    const int g = grid_for((int64_t)H * W);
+    hipLaunchKernelGGL(unknown_rowmax_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, a, H, W, r, (uint8_t*)ws);
+    hipLaunchKernelGGL(trimap_from_alpha_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, a, (const uint8_t*)ws, H, W, r,
+                       out);
+    OTVM_CHECK_LAUNCH("otvm_trimap_from_alpha");
+    return 0;
+}
+
+extern "C" int otvm_onehot_argmax3(const float* tri, int64_t P, float* out, void* stream) {
+    hipLaunchKernelGGL(onehot_argmax3_kernel, dim3(grid_for(P)), dim3(256), 0, (hipStream_t)stream, tri, P, out);
+    OTVM_CHECK_LAUNCH("otvm_onehot_argmax3");
+    return 0;
+}

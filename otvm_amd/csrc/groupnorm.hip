@@ -1,0 +1,107 @@
+// GroupNorm(32 groups, eps 1e-5, affine) on NHWC fp32 activations -- HBM-bound streaming kernels.
+//   stats : one pass, 16-byte loads, per-thread fp32 partials over a short pixel run, promoted to
+//           fp64 for the block (LDS) and device (global atomic) reductions, so the result does not
+//           depend on the reduction order beyond fp64 rounding.
+//   apply : y = act((x - mean)*rstd*gamma + beta [+ residual]); per-channel scale/shift are built
+//           once per block in LDS from the fp64 sums.
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int G = 32;
+
+__global__ void gn_stats_kernel(const float* __restrict__ x, int64_t P, int C, int ld, double* __restrict__ stats) {
+    __shared__ double red[G * 2];
+    const int Q = C >> 2;                         // float4 columns per pixel
+    const int rows = blockDim.x / Q;              // pixels covered per block iteration
+    const int q = threadIdx.x % Q, r = threadIdx.x / Q;
+    if (threadIdx.x < G * 2) red[threadIdx.x] = 0.0;
+    __syncthreads();
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+    if (r < rows) {
+        for (int64_t pix = (int64_t)blockIdx.x * rows + r; pix < P; pix += (int64_t)gridDim.x * rows) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * ld + q * 4);
+            s += v;
+            ss += v * v;
+        }
+    }
+    const int cg = C / G;                         // channels per group (>= 2)
+    if (cg >= 4) {
+        const int g = (q * 4) / cg;
+        atomicAdd(&red[g * 2], (double)s.x + (double)s.y + (double)s.z + (double)s.w);
+        atomicAdd(&red[g * 2 + 1], (double)ss.x + (double)ss.y + (double)ss.z + (double)ss.w);
+    } else {                                      // cg == 2: a float4 straddles two groups
+        const int g = (q * 4) / 2;
+        atomicAdd(&red[g * 2], (double)s.x + (double)s.y);
+        atomicAdd(&red[g * 2 + 1], (double)ss.x + (double)ss.y);
+        atomicAdd(&red[g * 2 + 2], (double)s.z + (double)s.w);
+        atomicAdd(&red[g * 2 + 3], (double)ss.z + (double)ss.w);
+    }
+    __syncthreads();
+    if (threadIdx.x < G * 2) atomicAdd(&stats[threadIdx.x], red[threadIdx.x]);
+}
+
+__global__ void gn_apply_kernel(const float* __restrict__ x, int64_t P, int C, int ld, const double* __restrict__ stats,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ residual, int res_ld, int act, float* __restrict__ out,
+                                int out_ld) {
+    extern __shared__ __attribute__((aligned(16))) float sc[];   // [C] scale, [C] shift
+    float* sh = sc + C;
+    const int cg = C / G;
+    const double cnt = (double)P * cg;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cg;
+        const double mean = stats[g * 2] / cnt;
+        double var = stats[g * 2 + 1] / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+        const float a = rstd * gamma[c];
+        sc[c] = a;
+        sh[c] = beta[c] - (float)mean * a;
+    }
+    __syncthreads();
+    const int Q = C >> 2;
+    const int64_t total = P * Q;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / Q;
+        const int c = (int)(i - pix * Q) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * ld + c);
+        const f32x4 a = *reinterpret_cast<const f32x4*>(sc + c);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(sh + c);
+        v = v * a + b;
+        if (residual) v += *reinterpret_cast<const f32x4*>(residual + pix * res_ld + c);
+        v.x = otvm_act(v.x, act); v.y = otvm_act(v.y, act); v.z = otvm_act(v.z, act); v.w = otvm_act(v.w, act);
+        *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int otvm_gn_stats(const float* x, int64_t P, int C, int ld, double* stats, void* stream) {
+    OTVM_REQUIRE(C % 64 == 0 && C <= 2048, "otvm_gn_stats: C=%d unsupported (need multiple of 64, <= 2048)", C);
+    OTVM_REQUIRE(ld % 4 == 0 && ((uintptr_t)x & 15) == 0, "otvm_gn_stats: unaligned view");
+    const int Q = C / 4;
+    const int threads = Q <= 256 ? 256 : 512;
+    const int rows = threads / Q;
+    int64_t blocks = (P + rows - 1) / rows;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(gn_stats_kernel, dim3((int)blocks), dim3(threads), 0, (hipStream_t)stream, x, P, C, ld, stats);
+    OTVM_CHECK_LAUNCH("otvm_gn_stats");
+    return 0;
+}
+
+extern "C" int otvm_gn_apply(const float* x, int64_t P, int C, int ld, const double* stats, const float* gamma,
+                             const float* beta, const float* residual, int res_ld, int act, float* out, int out_ld,
+                             void* stream) {
+    OTVM_REQUIRE(C % 64 == 0 && C <= 2048, "otvm_gn_apply: C=%d unsupported", C);
+    OTVM_REQUIRE(ld % 4 == 0 && out_ld % 4 == 0 && (!residual || res_ld % 4 == 0), "otvm_gn_apply: unaligned view");
+    const int64_t total = P * (C / 4);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((int)blocks), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, x, P, C,
+                       ld, stats, gamma, beta, residual, res_ld, act, out, out_ld);
+    OTVM_CHECK_LAUNCH("otvm_gn_apply");
+    return 0;
+}

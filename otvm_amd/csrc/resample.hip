@@ -1,0 +1,133 @@
+// Pooling / resampling kernels on NHWC fp32 (HBM-bound, 16-byte accesses along channels).
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+__device__ __forceinline__ f32x4 vmax(f32x4 a, f32x4 b) {
+    f32x4 r = {fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
+    return r;
+}
+
+// F.max_pool2d(kernel 3, stride 2, padding 1): padding acts as -inf
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ in, int H, int W, int C, int ld, float* __restrict__ out,
+                                    int Ho, int Wo, int out_ld) {
+    const int Q = C >> 2;
+    const int64_t total = (int64_t)Ho * Wo * Q;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / Q;
+        const int c = (int)(i - pix * Q) * 4;
+        const int oy = (int)(pix / Wo), ox = (int)(pix - (int64_t)oy * Wo);
+        const float ninf = -__builtin_huge_valf();
+        f32x4 m = {ninf, ninf, ninf, ninf};
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int iy = oy * 2 + dy;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int ix = ox * 2 + dx;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                m = vmax(m, *reinterpret_cast<const f32x4*>(in + ((int64_t)iy * W + ix) * ld + c));
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = m;
+    }
+}
+
+// F.interpolate(bilinear, align_corners=False): src = (dst + 0.5) * (in/out) - 0.5, clamped at 0;
+// the upper neighbour index is clamped to the last row/col (PyTorch area_pixel_compute_source_index).
+__global__ void upsample_bilinear_kernel(const float* __restrict__ in, int Hi, int Wi, int C, int in_ld,
+                                         const float* __restrict__ add, int add_ld, float* __restrict__ out, int Ho,
+                                         int Wo, int out_ld, float sy, float sx) {
+    const int Q = C >> 2;
+    const int64_t total = (int64_t)Ho * Wo * Q;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pix = i / Q;
+        const int c = (int)(i - pix * Q) * 4;
+        const int oy = (int)(pix / Wo), ox = (int)(pix - (int64_t)oy * Wo);
+        float fy = ((float)oy + 0.5f) * sy - 0.5f;
+        float fx = ((float)ox + 0.5f) * sx - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(in + ((int64_t)y0 * Wi + x0) * in_ld + c);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(in + ((int64_t)y0 * Wi + x1) * in_ld + c);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(in + ((int64_t)y1 * Wi + x0) * in_ld + c);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(in + ((int64_t)y1 * Wi + x1) * in_ld + c);
+        f32x4 v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+        if (add) v += *reinterpret_cast<const f32x4*>(add + pix * add_ld + c);
+        *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = v;
+    }
+}
+
+// AdaptiveAvgPool2d(s), s in {1,2,3,6}: bin i covers [floor(i*N/s), ceil((i+1)*N/s)).
+// grid = (50 bins, C/256 channel slabs); 256 threads = 64 float4 columns x 4 pixel lanes.
+__global__ __launch_bounds__(256) void ppm_pool_kernel(const float* __restrict__ in, int H, int W, int C, int ld,
+                                                       float* __restrict__ out) {
+    int bin = blockIdx.x, s, base;
+    if (bin < 1) { s = 1; base = 0; }
+    else if (bin < 5) { s = 2; base = 1; }
+    else if (bin < 14) { s = 3; base = 5; }
+    else { s = 6; base = 14; }
+    const int b = bin - base, by = b / s, bx = b - by * s;
+    const int y0 = (by * H) / s, y1 = ((by + 1) * H + s - 1) / s;
+    const int x0 = (bx * W) / s, x1 = ((bx + 1) * W + s - 1) / s;
+    const int q = threadIdx.x & 63, lanep = threadIdx.x >> 6;
+    const int c = blockIdx.y * 256 + q * 4;
+    const int rw = x1 - x0, n = (y1 - y0) * rw;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        for (int i = lanep; i < n; i += 4) {
+            const int yy = y0 + i / rw, xx = x0 + i % rw;
+            acc += *reinterpret_cast<const f32x4*>(in + ((int64_t)yy * W + xx) * ld + c);
+        }
+    }
+    __shared__ f32x4 red[256];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (lanep == 0 && c < C) {
+        f32x4 t = red[q] + red[q + 64] + red[q + 128] + red[q + 192];
+        const float inv = 1.f / (float)n;
+        *reinterpret_cast<f32x4*>(out + (int64_t)bin * C + c) = t * inv;
+    }
+}
+
+}  // namespace
+
+static int grid_for(int64_t total) {
+    int64_t b = (total + 255) / 256;
+    return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+extern "C" int otvm_maxpool3x3s2(const float* in, int H, int W, int C, int ld, float* out, int out_ld, void* stream) {
+    OTVM_REQUIRE(C % 4 == 0 && ld % 4 == 0 && out_ld % 4 == 0, "otvm_maxpool3x3s2: channels must be multiples of 4");
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for((int64_t)Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream,
+                       in, H, W, C, ld, out, Ho, Wo, out_ld);
+    OTVM_CHECK_LAUNCH("otvm_maxpool3x3s2");
+    return 0;
+}
+
+extern "C" int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, int in_ld, const float* add, int add_ld,
+                                      float* out, int Ho, int Wo, int out_ld, void* stream) {
+    OTVM_REQUIRE(C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0 && (!add || add_ld % 4 == 0),
+                 "otvm_upsample_bilinear: channels must be multiples of 4");
+    const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
+    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(grid_for((int64_t)Ho * Wo * (C / 4))), dim3(256), 0,
+                       (hipStream_t)stream, in, Hi, Wi, C, in_ld, add, add_ld, out, Ho, Wo, out_ld, sy, sx);
+    OTVM_CHECK_LAUNCH("otvm_upsample_bilinear");
+    return 0;
+}
+
+extern "C" int otvm_ppm_pool(const float* in, int H, int W, int C, int ld, float* out, void* stream) {
+    OTVM_REQUIRE(C % 4 == 0 && ld % 4 == 0, "otvm_ppm_pool: channels must be multiples of 4");
+    hipLaunchKernelGGL(ppm_pool_kernel, dim3(50, otvm_ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, in, H, W, C, ld,
+                       out);
+    OTVM_CHECK_LAUNCH("otvm_ppm_pool");
+    return 0;
+}

@@ -1,0 +1,572 @@
+"""Host-side launch plan for the OTVM frame path on MI355X.
+
+The reference executes ``EvalModel.forward`` (models/alpha/model.py:391-512) as ~600 ATen calls per
+frame.  Here the same function is compiled once per input resolution into a static list of HIP kernel
+launches over pre-allocated NHWC buffers (``FramePlan``); running a frame is a tight loop of ctypes calls
+into ``libotvm_hip.so`` on torch's current HIP stream.  PyTorch is used for device memory only.
+
+What is decided at plan time (load time for weights):
+  * weight standardisation of the 66 WS convs is applied once (``otvm_pack_conv_weight(ws=1)``),
+    instead of per forward as ``layers_WS.py:15-21`` does;
+  * the 86 eval-mode BatchNorms of the STM encoders are folded into their convolutions;
+  * the five stem convolutions of ``Encoder_M`` (STM.py:56-66) become one 24-channel convolution;
+  * every ``torch.cat`` is replaced by producers writing channel slices of the consumer's buffer;
+  * the memory bank is a set of per-slot key/value buffers (``alpha/model.py:472-493`` policy kept).
+"""
+import ctypes as C
+
+import torch
+
+from . import lib as L
+
+NONE, RELU, LEAKY = 0, 1, 2
+
+
+def _rup(x, m):
+    return (x + m - 1) // m * m
+
+
+class Act:
+    """A [H, W, C] fp32 NHWC view with pixel stride ``ld`` inside a flat device buffer."""
+    __slots__ = ("t", "H", "W", "C", "ld", "off")
+
+    def __init__(self, t, H, W, C, ld=None, off=0):
+        self.t, self.H, self.W, self.C = t, H, W, C
+        self.ld = C if ld is None else ld
+        self.off = off
+
+    @property
+    def ptr(self):
+        return self.t.data_ptr() + 4 * self.off
+
+    @property
+    def P(self):
+        return self.H * self.W
+
+    def ch(self, c0, c):
+        return Act(self.t, self.H, self.W, c, self.ld, self.off + c0)
+
+    def torch(self):
+        """[H, W, C] strided torch view (tests / debugging only)."""
+        return torch.as_strided(self.t, (self.H, self.W, self.C), (self.W * self.ld, self.ld, 1), self.off)
+
+
+class ConvW:
+    __slots__ = ("w", "K_pad", "O", "I_pad", "kh", "kw", "bias")
+
+
+def pad_amounts(h, w, d):
+    """(lw, uw, lh, uh): reference models/alpha/common.py:6-27."""
+    nh = h + (d - h % d) % d
+    nw = w + (d - w % d) % d
+    lh, lw = int((nh - h) / 2), int((nw - w) / 2)
+    return lw, nw - w - lw, lh, nh - h - lh
+
+
+def bank_update(bank, new, first_frame, memorize, max_memory_num):
+    """Slot policy of reference models/alpha/model.py:472-493.  Returns (bank, released_slots)."""
+    old = list(bank)
+    if max_memory_num == 0:
+        nb = [new] if first_frame else bank
+    elif max_memory_num == 1:
+        nb = [new]
+    else:
+        if first_frame:
+            nb = [new]
+        elif memorize or len(bank) == 1:
+            nb = bank + [new]
+        else:
+            nb = bank[:-1] + [new]
+        if len(nb) > max_memory_num:
+            nb = nb[:1] + nb[2:]
+    released = [s for s in old + [new] if not any(s is k for k in nb)]
+    return nb, released
+
+
+class HipEngine:
+    def __init__(self, state_dict, device):
+        self.lib = L.load()
+        self.dev = torch.device(device)
+        if self.dev.type != "cuda":
+            raise RuntimeError("otvm_amd: the HIP path needs a GPU device (got %s); there is no CPU fallback" % device)
+        self.sd = {k: v.detach().to(self.dev, torch.float32).contiguous() for k, v in state_dict.items()
+                   if v.is_floating_point()}
+        self.W = {}
+        self._keep = []
+        self.plans = {}
+        self.bank = []
+        self.free_slots = []
+        self.stream = 0
+        self._pack_all()
+
+    # ------------------------------------------------------------------ weights
+    def _stream(self):
+        return torch.cuda.current_stream(self.dev).cuda_stream
+
+    def _pack(self, name, w, ws=False, scale=None, bias=None, i_pad=None):
+        O, I, kh, kw = w.shape
+        cw = ConvW()
+        cw.O, cw.kh, cw.kw = O, kh, kw
+        cw.I_pad = _rup(I, 4) if i_pad is None else i_pad
+        cw.K_pad = _rup(kh * kw * cw.I_pad, 32)
+        O_pad = _rup(O, 128)
+        cw.w = torch.empty(O_pad * cw.K_pad, dtype=torch.float32, device=self.dev)
+        cw.bias = bias
+        w = w.contiguous()
+        L.check(self.lib.otvm_pack_conv_weight(w.data_ptr(), O, I, kh, kw, 1 if ws else 0,
+                                               0 if scale is None else scale.data_ptr(), cw.w.data_ptr(), O_pad,
+                                               cw.I_pad, cw.K_pad, self._stream()), "pack " + name)
+        self._keep.append((w, scale))
+        self.W[name] = cw
+
+    def _fold_bn(self, bn):
+        sd = self.sd
+        n = sd[bn + ".weight"].numel()
+        scale = torch.empty(n, dtype=torch.float32, device=self.dev)
+        bias = torch.empty(n, dtype=torch.float32, device=self.dev)
+        L.check(self.lib.otvm_fold_bn(sd[bn + ".weight"].data_ptr(), sd[bn + ".bias"].data_ptr(),
+                                      sd[bn + ".running_mean"].data_ptr(), sd[bn + ".running_var"].data_ptr(), 1e-5, n,
+                                      scale.data_ptr(), bias.data_ptr(), self._stream()), "fold_bn " + bn)
+        return scale, bias
+
+    def _pack_all(self):
+        sd = self.sd
+        for k, v in sd.items():
+            if not (k.endswith(".weight") and v.dim() == 4):
+                continue
+            name = k[:-7]
+            if k.startswith("NET."):
+                ws = not ("conv_up4" in k or ".pred." in k)               # layers_WS.Conv2d vs nn.Conv2d
+                if name in ("NET.decoder.conv_up4.4", "NET.refine.pred.4"):
+                    continue                                             # 1x1 heads run inside otvm_fba_head
+                self._pack(name, v, ws=ws, bias=sd.get(name + ".bias"))
+            elif ".Encoder_" in k:
+                if ".conv1_" in k or name.endswith("Encoder_M.conv1"):
+                    continue                                             # merged stem, below
+                bn = name.replace(".conv", ".bn").replace("downsample.0", "downsample.1")
+                scale, bias = self._fold_bn(bn)
+                self._pack(name, v, scale=scale, bias=bias)
+            else:                                                        # KV heads, STM decoder: plain conv + bias
+                self._pack(name, v, bias=sd.get(name + ".bias"))
+        # Encoder_M stem: conv1_h(hid16) + conv1(rgb) + conv1_m(p_un) + conv1_o(p_fg) + conv1_a(alpha) (STM.py:63-66)
+        e = "trimap.model.Encoder_M."
+        wcat = torch.cat([sd[e + "conv1_h.weight"], sd[e + "conv1.weight"], sd[e + "conv1_m.weight"],
+                          sd[e + "conv1_o.weight"], sd[e + "conv1_a.weight"]], dim=1)
+        scale, bias = self._fold_bn(e + "bn1")
+        self._pack(e + "stem", wcat, scale=scale, bias=bias, i_pad=24)
+        torch.cuda.synchronize(self.dev)
+
+    # ------------------------------------------------------------------ plans
+    def plan(self, H, W):
+        key = (H, W)
+        if key not in self.plans:
+            self.plans[key] = FramePlan(self, H, W)
+        return self.plans[key]
+
+    def reset(self):
+        self.free_slots.extend(self.bank)
+        self.bank = []
+
+    def _vec3(self, key):
+        return [float(x) for x in self.sd[key].flatten().tolist()]
+
+    def frame(self, a, fg, bg, tri_gt=None, first_frame=False, last_frame=False, memorize=False, max_memory_num=2,
+              dilate_kernel=None, frame_id=0, cls_override=None):
+        """One call of EvalModel.forward (reference models/alpha/model.py:391-512) on the HIP path.
+
+        a [1,1,1,H,W] in [0,1]; fg, bg [1,1,3,H,W] BGR 0..255; tri_gt [1,1,3,H,W] or None.
+        Returns the reference's 5-tuple (scaled_imgs, preds_trimap, tri_gt, preds_alpha, scaled_gts)."""
+        dev, lib = self.dev, self.lib
+        f32 = torch.float32
+        a = a.to(dev, f32).contiguous()
+        fg = fg.to(dev, f32).contiguous()
+        bg = bg.to(dev, f32).contiguous()
+        if a.dim() != 5 or a.shape[0] != 1 or a.shape[1] != 1:
+            raise ValueError("otvm_amd: inputs must be [1,1,C,H,W] (batch 1, one frame), got %s" % (tuple(a.shape),))
+        H, W = int(fg.shape[-2]), int(fg.shape[-1])
+        pl = self.plan(H, W)
+        stream = self._stream()
+        scaled_imgs = torch.empty((1, 1, 3, H, W), dtype=f32, device=dev)
+        alpha = torch.empty((1, 1, 1, H, W), dtype=f32, device=dev)
+        alpha_u8 = torch.empty((H, W), dtype=torch.uint8, device=dev)
+        tri_out = torch.empty((1, 1, 3, H, W), dtype=f32, device=dev)
+        tri_gt_out = torch.empty((1, 1, 3, H, W), dtype=f32, device=dev)
+        pl.stats.zero_()
+        pp = L.PreprocessParams()
+        pp.fg, pp.bg, pp.a = fg.data_ptr(), bg.data_ptr(), a.data_ptr()
+        pp.H, pp.W, pp.Hp, pp.Wp, pp.lh, pp.lw = H, W, pl.Hp, pl.Wp, pl.lh, pl.lw
+        for name, key in (("mean", "IMG_MEAN"), ("std", "IMG_STD"), ("mean_q", "trimap.model.Encoder_Q.mean"),
+                          ("std_q", "trimap.model.Encoder_Q.std"), ("mean_m", "trimap.model.Encoder_M.mean"),
+                          ("std_m", "trimap.model.Encoder_M.std")):
+            setattr(pp, name, (C.c_float * 3)(*self._consts(key)))
+        pp.scaled_imgs = scaled_imgs.data_ptr()
+        pp.x11, pp.x11_ld = pl.X11.ptr, pl.X11.ld
+        pp.sq, pp.sq_ld = pl.SQ.ptr, pl.SQ.ld
+        smv = pl.SM.ch(16, 8)
+        pp.sm, pp.sm_ld = smv.ptr, smv.ld
+        pp.d80, pp.d80_ld = pl.D80.ptr, pl.D80.ld
+        L.check(lib.otvm_preprocess(C.byref(pp), stream), "preprocess")
+
+        if tri_gt is not None:
+            tri_src = tri_gt.to(dev, f32).contiguous()
+            L.check(lib.otvm_onehot_argmax3(tri_src.data_ptr(), H * W, tri_gt_out.data_ptr(), stream), "onehot")
+        else:
+            if dilate_kernel is None:
+                raise ValueError("otvm_amd: tri_gt=None needs a fixed dilate_kernel (reference eval always sets one)")
+            ws = pl.raw("tfa_ws", H * W, torch.uint8)
+            L.check(lib.otvm_trimap_from_alpha(a.data_ptr(), H, W, int(dilate_kernel), tri_gt_out.data_ptr(),
+                                               ws.data_ptr(), stream), "trimap_from_alpha")
+            tri_src = tri_gt_out
+
+        if first_frame:
+            self.reset()
+            L.check(lib.otvm_pad_trimap(tri_src.data_ptr(), H, W, pl.PROBS.data_ptr(), pl.Hp, pl.Wp, pl.lh, pl.lw, stream),
+                    "pad_trimap")
+        else:
+            if not self.bank:
+                raise RuntimeError("otvm_amd: non-first frame with an empty memory bank (call with first_frame=True first)")
+            pl.run("segment_a", stream)
+            pl.memory_read(self.bank, stream)
+            pl.run("segment_b", stream)
+        pl.encode(stream, cls_override)
+        pl.run("fba", stream)
+        if not last_frame:
+            slot = pl.new_slot()
+            slot["frame"] = frame_id
+            pl.run("memorize", stream)
+            pl.kv_into_slot(slot, stream)
+            self.bank, released = bank_update(self.bank, slot, first_frame, memorize, max_memory_num)
+            self.free_slots.extend(released)
+        L.check(lib.otvm_crop_outputs(pl.ALPHA_P.data_ptr(), pl.TRI_P.data_ptr(), pl.Hp, pl.Wp, H, W, pl.lh, pl.lw,
+                                      alpha.data_ptr(), alpha_u8.data_ptr(), tri_out.data_ptr(), stream), "crop")
+        self.last_alpha_u8 = alpha_u8
+        self.last_plan = pl
+        return scaled_imgs, tri_out, tri_gt_out, alpha, a
+
+    def _consts(self, key):
+        c = getattr(self, "_const_cache", None)
+        if c is None:
+            c = self._const_cache = {}
+        if key not in c:
+            c[key] = self._vec3(key)
+        return c[key]
+
+
+class FramePlan:
+    """Buffers + launch lists for one input resolution."""
+
+    def __init__(self, eng, H, W):
+        self.e = eng
+        self.lib = eng.lib
+        self.dev = eng.dev
+        self.H, self.W = H, W
+        self.lw, self.uw, self.lh, self.uh = pad_amounts(H, W, 32)
+        self.Hp, self.Wp = H + self.lh + self.uh, W + self.lw + self.uw
+        self.P = self.Hp * self.Wp
+        self._bufs = {}
+        self._keep = []
+        self.n_gn = 0
+        self.steps = {}
+        self._build()
+        self.stats = torch.zeros(max(self.n_gn, 1) * 64, dtype=torch.float64, device=self.dev)
+        self._bind_stats()
+
+    # ---- buffers
+    def buf(self, name, H, W, C):
+        key = (name, H, W, C)
+        if key not in self._bufs:
+            self._bufs[key] = Act(torch.zeros(H * W * C, dtype=torch.float32, device=self.dev), H, W, C)
+        return self._bufs[key]
+
+    def raw(self, name, n, dtype=torch.float32):
+        key = ("raw", name, n, dtype)
+        if key not in self._bufs:
+            self._bufs[key] = torch.zeros(n, dtype=dtype, device=self.dev)
+        return self._bufs[key]
+
+    # ---- step builders (S = list being filled)
+    def conv(self, S, x, wname, out, stride=1, pad=0, dil=1, act=NONE, in_relu=0, residual=None):
+        w = self.e.W[wname]
+        assert x.C == w.I_pad, (wname, x.C, w.I_pad)
+        Ho = (x.H + 2 * pad - dil * (w.kh - 1) - 1) // stride + 1
+        Wo = (x.W + 2 * pad - dil * (w.kw - 1) - 1) // stride + 1
+        assert (out.H, out.W) == (Ho, Wo) and out.C >= w.O, (wname, out.H, out.W, Ho, Wo, out.C, w.O)
+        p = L.ConvParams(x.ptr, x.H, x.W, x.C, x.ld, w.w.data_ptr(), w.K_pad,
+                         0 if w.bias is None else w.bias.data_ptr(),
+                         0 if residual is None else residual.ptr, 0 if residual is None else residual.ld,
+                         out.ptr, Ho, Wo, w.O, out.ld, w.kh, w.kw, stride, pad, dil, in_relu, act)
+        self._keep.append(p)
+        S.append((self.lib.otvm_conv2d, (C.byref(p),), "conv " + wname))
+
+    def gn(self, S, x, name, act, out=None, residual=None):
+        out = x if out is None else out
+        sd = self.e.sd
+        idx = self.n_gn
+        self.n_gn += 1
+        S.append(("gn_stats", (x.ptr, x.P, x.C, x.ld), idx, "gn_stats " + name))
+        S.append(("gn_apply", (x.ptr, x.P, x.C, x.ld), idx,
+                  (sd[name + ".weight"].data_ptr(), sd[name + ".bias"].data_ptr(),
+                   0 if residual is None else residual.ptr, 0 if residual is None else residual.ld, act,
+                   out.ptr, out.ld), "gn_apply " + name))
+
+    def _bind_stats(self):
+        base = self.stats.data_ptr()
+        for key, S in self.steps.items():
+            for i, st in enumerate(S):
+                if st[0] == "gn_stats":
+                    _, a, idx, label = st
+                    S[i] = (self.lib.otvm_gn_stats, a + (base + idx * 512,), label)
+                elif st[0] == "gn_apply":
+                    _, a, idx, b, label = st
+                    S[i] = (self.lib.otvm_gn_apply, a + (base + idx * 512,) + b, label)
+
+    def upsample(self, S, x, out, add=None):
+        S.append((self.lib.otvm_upsample_bilinear,
+                  (x.ptr, x.H, x.W, x.C, x.ld, 0 if add is None else add.ptr, 0 if add is None else add.ld,
+                   out.ptr, out.H, out.W, out.ld), "upsample"))
+
+    def maxpool(self, S, x, out):
+        S.append((self.lib.otvm_maxpool3x3s2, (x.ptr, x.H, x.W, x.C, x.ld, out.ptr, out.ld), "maxpool"))
+
+    # ---- network pieces
+    def gn_bottleneck(self, S, x, p, planes, stride, dil, has_ds, out):
+        Ho, Wo = x.H // stride, x.W // stride
+        t1 = self.buf("bt1", x.H, x.W, planes)
+        self.conv(S, x, p + ".conv1", t1)
+        self.gn(S, t1, p + ".bn1", RELU)
+        t2 = self.buf("bt2", Ho, Wo, planes)
+        self.conv(S, t1, p + ".conv2", t2, stride=stride, pad=dil, dil=dil)
+        self.gn(S, t2, p + ".bn2", RELU)
+        t3 = self.buf("bt3", Ho, Wo, planes * 4)
+        self.conv(S, t2, p + ".conv3", t3)
+        if has_ds:
+            idt = self.buf("btd", Ho, Wo, planes * 4)
+            self.conv(S, x, p + ".downsample.0", idt, stride=stride)
+            self.gn(S, idt, p + ".downsample.1", NONE)
+        else:
+            idt = x
+        self.gn(S, t3, p + ".bn3", RELU, out=out, residual=idt)
+
+    def bn_bottleneck(self, S, x, p, planes, stride, has_ds, out, tag):
+        Ho, Wo = x.H // stride, x.W // stride
+        t1 = self.buf(tag + "t1", x.H, x.W, planes)
+        self.conv(S, x, p + ".conv1", t1, act=RELU)
+        t2 = self.buf(tag + "t2", Ho, Wo, planes)
+        self.conv(S, t1, p + ".conv2", t2, stride=stride, pad=1, act=RELU)
+        if has_ds:
+            idt = self.buf(tag + "td", Ho, Wo, planes * 4)
+            self.conv(S, x, p + ".downsample.0", idt, stride=stride)
+        else:
+            idt = x
+        self.conv(S, t2, p + ".conv3", out, residual=idt, act=RELU)
+
+    def stm_trunk(self, S, stem_out, e, tag):
+        """maxpool + res2/res3/res4 (BN folded) of an STM encoder.  Returns r4, r3, r2."""
+        H4, W4 = self.Hp // 4, self.Wp // 4
+        x = self.buf(tag + "pool", H4, W4, 64)
+        self.maxpool(S, stem_out, x)
+        outs = {}
+        for lname, n, planes, s0 in (("res2", 3, 64, 1), ("res3", 4, 128, 2), ("res4", 6, 256, 2)):
+            for b in range(n):
+                st = s0 if b == 0 else 1
+                o = self.buf(tag + lname + ("a" if b % 2 == 0 else "b"), x.H // st, x.W // st, planes * 4)
+                self.bn_bottleneck(S, x, e + "%s.%d" % (lname, b), planes, st, b == 0, o, tag)
+                x = o
+            outs[lname] = x
+        return outs["res4"], outs["res3"], outs["res2"]
+
+    def resblock(self, S, x, p, out, tag):
+        """STM.py:9-30 (no downsample case): out = x + conv2(relu(conv1(relu(x))))."""
+        r = self.buf(tag + "r", x.H, x.W, 256)
+        self.conv(S, x, p + ".conv1", r, pad=1, in_relu=1)
+        self.conv(S, r, p + ".conv2", out, pad=1, in_relu=1, residual=x)
+
+    def _build(self):
+        e, lib = self.e, self.lib
+        Hp, Wp, P = self.Hp, self.Wp, self.P
+        H2, W2, H4, W4, H8, W8, H16, W16 = Hp // 2, Wp // 2, Hp // 4, Wp // 4, Hp // 8, Wp // 8, Hp // 16, Wp // 16
+        self.hw = H16 * W16
+
+        # ---------------- frame-level buffers
+        self.X11 = self.buf("X11", Hp, Wp, 12)          # 0-2 normalised RGB, 3-8 distance encoding, 9-10 soft, 11 zero
+        self.SQ = self.buf("SQ", Hp, Wp, 4)             # Encoder_Q input (normalised RGB)
+        self.SM = self.buf("SM", Hp, Wp, 24)            # Encoder_M input: hid16 | rgb | p_un p_fg alpha | pad
+        self.D80 = self.buf("D80", Hp, Wp, 80)          # conv_up3 out 0-63 | rgb_n 64-66 | rgb 67-69 | tri2 70-71 | alpha 72
+        self.PROBS = self.raw("probs", 3 * P)           # planar trimap probabilities fed to the encoding
+        self.CLS = self.raw("cls", P, torch.uint8)
+        self.ALPHA_P = self.raw("alpha_p", P)
+        self.TRI_P = self.raw("tri_p", 3 * P)
+        self.enc_ws = self.raw("enc_ws", int(lib.otvm_trimap_encode_ws_bytes(Hp, Wp)), torch.uint8)
+
+        # ---------------- STM segment (STM.py:239-257)
+        S = []
+        sd = e.sd
+        q = "trimap.model.Encoder_Q."
+        stem = self.buf("q_stem", H2, W2, 64)
+        self.conv(S, self.SQ, q + "conv1", stem, stride=2, pad=3, act=RELU)
+        r4, r3, r2 = self.stm_trunk(S, stem, q, "q_")
+        self.QK = self.buf("QK", H16, W16, 128)
+        self.M4 = self.buf("M4", H16, W16, 1024)
+        self.conv(S, r4, "trimap.model.KV_Q_r4.Key", self.QK, pad=1)
+        self.conv(S, r4, "trimap.model.KV_Q_r4.Value", self.M4.ch(512, 512), pad=1)
+        self.steps["segment_a"] = S
+        S = []
+        d = "trimap.model.Decoder."
+        m = self.buf("d_m4a", H16, W16, 256)
+        self.conv(S, self.M4, d + "convFM", m, pad=1)
+        m4 = self.buf("d_m4b", H16, W16, 256)
+        self.resblock(S, m, d + "ResMM", m4, "d16")
+        pm = m4
+        for rf, feat, (h, w) in (("RF3", r3, (H8, W8)), ("RF2", r2, (H4, W4))):
+            s0 = self.buf("d_s0", h, w, 256)
+            self.conv(S, feat, d + rf + ".convFS", s0, pad=1)
+            s1 = self.buf("d_s1", h, w, 256)
+            self.resblock(S, s0, d + rf + ".ResFS", s1, "d%d" % h)
+            mm = self.buf("d_mm", h, w, 256)
+            self.upsample(S, pm, mm, add=s1)                        # m = s + up2(pm)  (STM.py:115)
+            mo = self.buf("d_mo", h, w, 256)
+            self.resblock(S, mm, d + rf + ".ResMM", mo, "d%d" % h)
+            pm = mo
+        self.L4 = self.buf("L4", H4, W4, 4)
+        self.conv(S, pm, d + "pred", self.L4, pad=1, in_relu=1)
+        S.append((lib.otvm_upsample4_softmax3, (self.L4.ptr, H4, W4, self.L4.ld, self.PROBS.data_ptr()), "up4softmax"))
+        self.steps["segment_b"] = S
+
+        # ---------------- FBA encoder (FBA/models.py:251-269)
+        S = []
+        en = "NET.encoder."
+        self.U3 = self.buf("U3", H2, W2, 320)            # [up(conv_up2) 256 | c1 64]
+        self.U2 = self.buf("U2", H4, W4, 512)            # [up(conv_up1) 256 | l1 256]
+        self.PPMCAT = self.buf("PPMCAT", H8, W8, 3072)   # [l4 2048 | ppm 4x256]
+        c1raw = self.buf("c1raw", H2, W2, 64)
+        self.conv(S, self.X11, en + "conv1", c1raw, stride=2, pad=3)
+        c1 = self.U3.ch(256, 64)
+        self.gn(S, c1raw, en + "bn1", RELU, out=c1)
+        x = self.buf("e_pool", H4, W4, 64)
+        self.maxpool(S, c1, x)
+        cfg = {"layer1": (64, 3, 1, 1, 1), "layer2": (128, 4, 2, 1, 1), "layer3": (256, 6, 1, 1, 2),
+               "layer4": (512, 3, 1, 2, 4)}
+        for lname in ("layer1", "layer2", "layer3", "layer4"):
+            planes, n, s0, d0, dn = cfg[lname]
+            for b in range(n):
+                st = s0 if b == 0 else 1
+                last = b == n - 1
+                if last and lname == "layer1":
+                    o = self.U2.ch(256, 256)
+                elif last and lname == "layer4":
+                    o = self.PPMCAT.ch(0, 2048)
+                else:
+                    o = self.buf("e_" + lname + ("a" if b % 2 == 0 else "b"), x.H // st, x.W // st, planes * 4)
+                self.gn_bottleneck(S, x, en + "%s.%d" % (lname, b), planes, st, d0 if b == 0 else dn, b == 0, o)
+                x = o
+        # ---------------- FBA decoder (FBA/models.py:351-392)
+        de = "NET.decoder."
+        conv5 = self.PPMCAT.ch(0, 2048)
+        self.POOL = self.raw("ppm_pool", 50 * 2048)
+        S.append((lib.otvm_ppm_pool, (conv5.ptr, H8, W8, 2048, conv5.ld, self.POOL.data_ptr()), "ppm_pool"))
+        base = 0
+        for i, s in enumerate((1, 2, 3, 6)):
+            pin = Act(self.POOL, s, s, 2048, 2048, base * 2048)
+            y = self.buf("ppm_y%d" % i, s, s, 256)
+            self.conv(S, pin, de + "ppm.%d.1" % i, y)
+            self.gn(S, y, de + "ppm.%d.2" % i, LEAKY)
+            self.upsample(S, y, self.PPMCAT.ch(2048 + 256 * i, 256))
+            base += s * s
+        u1 = self.buf("u1a", H8, W8, 256)
+        self.conv(S, self.PPMCAT, de + "conv_up1.0", u1, pad=1)
+        self.gn(S, u1, de + "conv_up1.1", LEAKY)
+        u1b = self.buf("u1b", H8, W8, 256)
+        self.conv(S, u1, de + "conv_up1.3", u1b, pad=1)
+        self.gn(S, u1b, de + "conv_up1.4", LEAKY)
+        self.upsample(S, u1b, self.U2.ch(0, 256))
+        u2 = self.buf("u2", H4, W4, 256)
+        self.conv(S, self.U2, de + "conv_up2.0", u2, pad=1)
+        self.gn(S, u2, de + "conv_up2.1", LEAKY)
+        self.upsample(S, u2, self.U3.ch(0, 256))
+        u3 = self.buf("u3", H2, W2, 64)
+        self.conv(S, self.U3, de + "conv_up3.0", u3, pad=1)
+        self.gn(S, u3, de + "conv_up3.1", LEAKY)
+        self.upsample(S, u3, self.D80.ch(0, 64))
+        h32 = self.buf("h32", Hp, Wp, 32)
+        self.conv(S, self.D80.ch(0, 72), de + "conv_up4.0", h32, pad=1, act=LEAKY)
+        hid_d = self.buf("hid_d", Hp, Wp, 16)
+        self.conv(S, h32, de + "conv_up4.2", hid_d, pad=1, act=LEAKY)
+        img = self.D80.ch(67, 3)
+        S.append((lib.otvm_fba_head,
+                  (hid_d.ptr, hid_d.ld, sd[de + "conv_up4.4.weight"].data_ptr(), sd[de + "conv_up4.4.bias"].data_ptr(), 7,
+                   img.ptr, img.ld, P, self.D80.ch(72, 1).ptr, self.D80.ld, 0, 0, 0), "fba_head7"))
+        # ---------------- refinement (FBA/models.py:417-435)
+        rf = "NET.refine."
+        r0 = self.buf("r0", Hp, Wp, 64)
+        self.conv(S, self.D80.ch(0, 76), rf + "conv1.0", r0, pad=1)
+        self.gn(S, r0, rf + "conv1.1", LEAKY)
+        x = r0
+        for l in ("layer1", "layer2"):
+            t1 = self.buf("rt1", Hp, Wp, 64)
+            self.conv(S, x, rf + l + ".conv1", t1, pad=1)
+            self.gn(S, t1, rf + l + ".bn1", RELU)
+            t2 = self.buf("rt2", Hp, Wp, 64)
+            self.conv(S, t1, rf + l + ".conv2", t2, pad=1)
+            o = self.buf("r_" + l, Hp, Wp, 64)
+            self.gn(S, t2, rf + l + ".bn2", RELU, out=o, residual=x)
+            x = o
+        self.conv(S, x, rf + "pred.0", h32, pad=1, act=LEAKY)
+        hid = self.SM.ch(0, 16)
+        self.conv(S, h32, rf + "pred.2", hid, pad=1, act=LEAKY)
+        S.append((lib.otvm_fba_head,
+                  (hid.ptr, hid.ld, sd[rf + "pred.4.weight"].data_ptr(), sd[rf + "pred.4.bias"].data_ptr(), 10,
+                   img.ptr, img.ld, P, self.ALPHA_P.data_ptr(), 1, self.TRI_P.data_ptr(),
+                   self.SM.ch(16, 8).ptr, self.SM.ld), "fba_head10"))
+        self.steps["fba"] = S
+
+        # ---------------- STM memorize (STM.py:201-228); key/value convs are bound to a slot at run time
+        S = []
+        m_ = "trimap.model.Encoder_M."
+        stem = self.buf("m_stem", H2, W2, 64)
+        self.conv(S, self.SM, m_ + "stem", stem, stride=2, pad=3, act=RELU)
+        self.r4m, _, _ = self.stm_trunk(S, stem, m_, "m_")
+        self.steps["memorize"] = S
+        self.mem_ws = None
+
+    # ------------------------------------------------------------------ run
+    def run(self, key, stream):
+        for st in self.steps[key]:
+            rc = st[0](*st[1], stream)
+            if rc != 0:
+                L.check(rc, st[2])
+
+    def new_slot(self):
+        e = self.e
+        for i, s in enumerate(e.free_slots):
+            if s["hw"] == self.hw:
+                return e.free_slots.pop(i)
+        H16, W16 = self.Hp // 16, self.Wp // 16
+        return dict(hw=self.hw, k=Act(torch.zeros(self.hw * 128, dtype=torch.float32, device=self.dev), H16, W16, 128),
+                    v=Act(torch.zeros(self.hw * 512, dtype=torch.float32, device=self.dev), H16, W16, 512), frame=-1)
+
+    def memory_read(self, bank, stream):
+        T = len(bank)
+        need = int(self.lib.otvm_memory_read_ws_bytes(self.hw, T))
+        if self.mem_ws is None or self.mem_ws.numel() < need:
+            self.mem_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        keys = (C.c_void_p * T)(*[s["k"].ptr for s in bank])
+        vals = (C.c_void_p * T)(*[s["v"].ptr for s in bank])
+        out = self.M4.ch(0, 512)
+        L.check(self.lib.otvm_memory_read(self.QK.ptr, self.QK.ld, keys, vals, T, self.hw, out.ptr, out.ld,
+                                          self.mem_ws.data_ptr(), stream), "memory_read")
+
+    def kv_into_slot(self, slot, stream):
+        if "kv_steps" not in slot:
+            S = []
+            self.conv(S, self.r4m, "trimap.model.KV_M_r4.Key", slot["k"], pad=1)
+            self.conv(S, self.r4m, "trimap.model.KV_M_r4.Value", slot["v"], pad=1)
+            slot["kv_steps"] = S
+        for st in slot["kv_steps"]:
+            L.check(st[0](*st[1], stream), st[2])
+
+    def encode(self, stream, cls_override=None):
+        """8-channel trimap encoding of PROBS into X11[3:11] / D80[70:72] (alpha/model.py:40-53)."""
+        L.check(self.lib.otvm_trimap_encode(self.PROBS.data_ptr(), self.Hp, self.Wp,
+                                            0 if cls_override is None else cls_override.data_ptr(), self.CLS.data_ptr(),
+                                            self.X11.ptr, self.X11.ld, self.D80.ptr, self.D80.ld, self.enc_ws.data_ptr(),
+                                            stream), "trimap_encode")

@@ -1,0 +1,86 @@
+"""ctypes binding of libotvm_hip.so (C ABI: include/otvm_hip.h).
+
+There is NO fallback: if the library is missing or a call fails, a RuntimeError is raised.  The
+product path never routes through PyTorch ops or the CPU oracle for its device compute.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libotvm_hip.so")
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class ConvParams(C.Structure):
+    _fields_ = [("inp", vp), ("H", i32), ("W", i32), ("Cin", i32), ("in_ld", i32),
+                ("w", vp), ("K_pad", i32),
+                ("bias", vp),
+                ("residual", vp), ("res_ld", i32),
+                ("out", vp), ("Ho", i32), ("Wo", i32), ("Cout", i32), ("out_ld", i32),
+                ("kh", i32), ("kw", i32), ("stride", i32), ("pad", i32), ("dil", i32),
+                ("in_relu", i32), ("act", i32)]
+
+
+class PreprocessParams(C.Structure):
+    _fields_ = [("fg", vp), ("bg", vp), ("a", vp),
+                ("H", i32), ("W", i32), ("Hp", i32), ("Wp", i32), ("lh", i32), ("lw", i32),
+                ("mean", f32 * 3), ("std", f32 * 3), ("mean_q", f32 * 3), ("std_q", f32 * 3),
+                ("mean_m", f32 * 3), ("std_m", f32 * 3),
+                ("scaled_imgs", vp),
+                ("x11", vp), ("x11_ld", i32), ("sq", vp), ("sq_ld", i32), ("sm", vp), ("sm_ld", i32),
+                ("d80", vp), ("d80_ld", i32)]
+
+
+_PROTOS = {
+    "otvm_abi_version": (i32, []),
+    "otvm_fold_bn": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp]),
+    "otvm_pack_conv_weight": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp]),
+    "otvm_conv2d": (i32, [C.POINTER(ConvParams), vp]),
+    "otvm_gn_stats": (i32, [vp, i64, i32, i32, vp, vp]),
+    "otvm_gn_apply": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i32, i32, vp, i32, vp]),
+    "otvm_maxpool3x3s2": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
+    "otvm_upsample_bilinear": (i32, [vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, i32, vp]),
+    "otvm_ppm_pool": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+    "otvm_memory_read_ws_bytes": (i64, [i32, i32]),
+    "otvm_memory_read": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp), i32, i32, vp, i32, vp, vp]),
+    "otvm_preprocess": (i32, [C.POINTER(PreprocessParams), vp]),
+    "otvm_pad_trimap": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, vp]),
+    "otvm_upsample4_softmax3": (i32, [vp, i32, i32, i32, vp, vp]),
+    "otvm_trimap_encode_ws_bytes": (i64, [i32, i32]),
+    "otvm_trimap_encode": (i32, [vp, i32, i32, vp, vp, vp, i32, vp, i32, vp, vp]),
+    "otvm_fba_head": (i32, [vp, i32, vp, vp, i32, vp, i32, i64, vp, i32, vp, vp, i32, vp]),
+    "otvm_crop_outputs": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "otvm_trimap_from_alpha": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    "otvm_onehot_argmax3": (i32, [vp, i64, vp, vp]),
+}
+
+EXPORTED = sorted(list(_PROTOS) + ["otvm_last_error"])
+
+_lib = None
+
+
+def load():
+    """Load the HIP library (after torch, so both share one libamdhip64 runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "otvm_amd: %s is missing -- build it with `python otvm_amd/csrc/build.py` "
+            "(or __graft_entry__.build()).  There is no CPU/PyTorch fallback." % LIB_PATH)
+    import torch  # noqa: F401  (loads torch's bundled libamdhip64.so.7 first; same SONAME)
+    lib = C.CDLL(LIB_PATH)
+    lib.otvm_last_error.restype = C.c_char_p
+    lib.otvm_last_error.argtypes = []
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("otvm_hip %s failed (%d): %s" % (what, rc, load().otvm_last_error().decode()))

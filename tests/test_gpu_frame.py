@@ -1,0 +1,149 @@
+"""GPU (-m gpu): the whole frame path through the reference-shaped boundary (EvalModel.forward) against
+the CPU oracle and the reference-generated golden fixtures.
+
+Parity statement checked here ("parity"):
+  * alpha max-abs <= 1e-3 vs the oracle on every frame (fp32 contract of BASELINE.json);
+  * the only discontinuity of the path is the 3-class argmax that feeds the distance transform
+    (alpha/model.py:42).  If the HIP class map differs from the oracle's, every differing pixel must be
+    a numerical near-tie in the oracle (top-2 probability gap < 1e-3); the oracle frame is then re-run
+    with the HIP tie-breaks (``class_override``) and the 1e-3 bound must hold.  The number of such
+    tie-breaks is reported; on the committed sequences it is expected to be 0 or a handful.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.common import clip_inputs, frame_flags, load_golden, load_sequences_meta
+
+pytestmark = pytest.mark.gpu
+META = load_sequences_meta()
+ALPHA_TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def model(synth_sd):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from otvm_amd import helpers
+    cfg = helpers.default_cfg()
+    cache = {}
+
+    def make(dk):
+        if dk not in cache:
+            m = helpers.get_model_alpha(cfg, helpers.get_model_trimap(cfg, "Test", dk), "Test", dk)
+            m.load_state_dict(synth_sd, strict=True)
+            cache[dk] = torch.nn.DataParallel(m.cuda()).eval()        # exactly as eval.py:77-80
+        return cache[dk]
+    return make
+
+
+def nchw(act, Cc=None):
+    from tests.gpu_util import from_act
+    return from_act(act, Cc)
+
+
+def stage_report(pl, cap, first_frame):
+    """max-abs differences of intermediate tensors (HIP buffers vs oracle capture), for diagnosis."""
+    rep = {}
+    Hp, Wp, P = pl.Hp, pl.Wp, pl.P
+
+    def d(name, got, ref):
+        rep[name] = (float((got - ref).abs().max()), float(ref.abs().max()))
+    d("x11", nchw(pl.X11, 11), cap["x11"])
+    feats = cap["feats"]
+    d("c1", nchw(pl.U3.ch(256, 64)), feats[1])
+    d("l1", nchw(pl.U2.ch(256, 256)), feats[2])
+    d("l4", nchw(pl.PPMCAT.ch(0, 2048)), feats[5])
+    d("x_dec", nchw(pl.D80.ch(0, 70)), cap["x_dec"])
+    d("dec_alpha", nchw(pl.D80.ch(72, 1)), cap["dec_out"][:, :1])
+    d("hid", nchw(pl.SM.ch(0, 16)), cap["hid"])
+    d("alpha_p", pl.ALPHA_P.reshape(1, 1, Hp, Wp).cpu(), cap["alpha_p"])
+    d("tri_out_p", pl.TRI_P.reshape(1, 3, Hp, Wp).cpu(), cap["tri_out_p"])
+    if not first_frame:
+        d("k4", nchw(pl.QK), cap["k4"])
+        d("m4", nchw(pl.M4), cap["m4"])
+        d("tri_in", pl.PROBS.reshape(1, 3, Hp, Wp).cpu(), cap["tri_in"])
+    return rep
+
+
+def run_sequence(model, synth_sd, meta, max_frames=None):
+    from oracle.otvm_oracle import OtvmOracle
+    m = model(meta["dilate_kernel"])
+    eng_model = m.module
+    orc = OtvmOracle(synth_sd, dilate_kernel=meta["dilate_kernel"])
+    results = []
+    for t, (a, fg, bg, tri_gt) in enumerate(clip_inputs(meta)):
+        if max_frames is not None and t >= max_frames:
+            break
+        flags = frame_flags(meta, t)
+        out = m(a, fg, bg, tri=None, tri_gt=tri_gt, large_input=False, _frame_id=t, **flags)
+        torch.cuda.synchronize()
+        pl = eng_model._engine.last_plan
+        cls_h = pl.CLS.reshape(pl.Hp, pl.Wp).cpu().long()
+        bank_before = list(orc.bank)
+        cap = {}
+        ref = orc.frame(a, fg, bg, tri_gt=tri_gt, frame_id=t, capture=cap, **flags)
+        ties = 0
+        if not torch.equal(cls_h, cap["cls"]):
+            diff = cls_h != cap["cls"]
+            ties = int(diff.sum())
+            top2 = torch.sort(cap["tri_in"][0], dim=0, descending=True)[0]
+            gap = (top2[0] - top2[1])[diff]
+            assert float(gap.max()) < 1e-3, "class map differs at a pixel that is not a near-tie (gap %g)" % float(gap.max())
+            orc.bank = bank_before
+            cap = {}
+            ref = orc.frame(a, fg, bg, tri_gt=tri_gt, frame_id=t, capture=cap, class_override=cls_h, **flags)
+        rep = stage_report(pl, cap, flags["first_frame"])
+        da = float((out[3].cpu() - ref[3]).abs().max())
+        dt = float((out[1].cpu() - ref[1]).abs().max())
+        results.append(dict(t=t, alpha=da, tri=dt, ties=ties, rep=rep, out=out, ref=ref,
+                            bank=[s["frame"] for s in eng_model._engine.bank], obank=[b[2] for b in orc.bank]))
+    return results
+
+
+def fmt(rep):
+    return " ".join("%s=%.1e/%.1e" % (k, v[0], v[1]) for k, v in rep.items())
+
+
+@pytest.mark.parametrize("name", sorted(META.keys()))
+def test_sequence_vs_oracle_and_golden(name, model, synth_sd):
+    meta = META[name]
+    gold = load_golden(name)
+    res = run_sequence(model, synth_sd, meta)
+    total_ties = 0
+    for r in res:
+        t = r["t"]
+        print("%s t=%d alpha=%.2e tri=%.2e ties=%d bank=%s | %s" % (name, t, r["alpha"], r["tri"], r["ties"], r["bank"], fmt(r["rep"])))
+        assert r["bank"] == r["obank"], (t, r["bank"], r["obank"])
+        assert len(r["bank"]) == gold["bank"][t]
+        assert r["alpha"] <= ALPHA_TOL, "frame %d alpha max-abs %.3e (stages: %s)" % (t, r["alpha"], fmt(r["rep"]))
+        assert r["tri"] <= 5e-3, "frame %d trimap max-abs %.3e" % (t, r["tri"])
+        total_ties += r["ties"]
+        out, ref = r["out"], r["ref"]
+        assert torch.equal(out[2].cpu(), ref[2]) and torch.equal(out[4].cpu(), ref[4])
+        assert float((out[0].cpu() - ref[0]).abs().max()) <= 1e-6
+        if r["ties"] == 0 and total_ties == 0:
+            # no tie-break so far: the reference-generated fixture is directly comparable
+            assert float(np.abs(out[3][0, 0, 0].cpu().numpy() - gold["alpha"][t]).max()) <= 2e-3
+    # returned tri_gt equals the reference's
+    np.testing.assert_array_equal(res[-1]["out"][2][0, 0].cpu().numpy(), gold["tri_gt"])
+    print("%s: total tie-breaks %d" % (name, total_ties))
+
+
+def test_alpha_u8_truncates(model, synth_sd):
+    meta = META["demo_70x90_single"]
+    m = model(meta["dilate_kernel"])
+    a, fg, bg, tri_gt = clip_inputs(meta)[0]
+    out = m(a, fg, bg, tri=None, tri_gt=tri_gt, **frame_flags(meta, 0))
+    u8 = m.module._engine.last_alpha_u8.cpu()
+    assert torch.equal(u8, (out[3][0, 0, 0].cpu() * 255).byte())          # eval.py:209
+
+
+def test_cpu_module_fails_loudly(synth_sd):
+    from otvm_amd import helpers
+    cfg = helpers.default_cfg()
+    m = helpers.get_model_alpha(cfg, helpers.get_model_trimap(cfg, "Test", 12), "Test", 12)
+    m.load_state_dict(synth_sd, strict=True)
+    with pytest.raises(RuntimeError):
+        m(torch.ones(1, 1, 1, 32, 32), torch.zeros(1, 1, 3, 32, 32), torch.zeros(1, 1, 3, 32, 32),
+          tri_gt=torch.zeros(1, 1, 3, 32, 32), first_frame=True)

@@ -1,0 +1,308 @@
+"""GPU (-m gpu): every HIP kernel of libotvm_hip.so against the same op evaluated on the CPU
+(torch fp32 ops / the oracle's functions), through the C ABI."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def G():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from tests import gpu_util
+    from otvm_amd import lib
+    lib.load()
+    return gpu_util
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+CONV_CASES = [
+    # Cin, Cout, k, stride, pad, dil, H, W, bias, act, in_relu, residual
+    (64, 64, 1, 1, 0, 1, 24, 40, False, 0, 0, False),
+    (64, 256, 1, 1, 0, 1, 24, 40, True, 1, 0, True),
+    (256, 512, 1, 2, 0, 1, 24, 40, False, 0, 0, False),
+    (128, 128, 3, 2, 1, 1, 24, 40, False, 0, 0, False),
+    (256, 256, 3, 1, 2, 2, 17, 30, False, 0, 0, False),
+    (512, 512, 3, 1, 4, 4, 17, 30, False, 0, 0, False),
+    (11, 64, 7, 2, 3, 1, 64, 96, False, 0, 0, False),
+    (22, 64, 7, 2, 3, 1, 32, 64, True, 1, 0, False),
+    (72, 32, 3, 1, 1, 1, 32, 48, True, 2, 0, False),
+    (32, 16, 3, 1, 1, 1, 32, 48, True, 2, 0, False),
+    (73, 64, 3, 1, 1, 1, 32, 48, True, 0, 0, False),
+    (256, 3, 3, 1, 1, 1, 16, 24, True, 0, 1, False),
+    (256, 256, 3, 1, 1, 1, 16, 24, True, 0, 1, True),
+    (1024, 128, 3, 1, 1, 1, 6, 8, True, 0, 0, False),
+    (320, 64, 3, 1, 1, 1, 40, 56, True, 0, 0, False),
+    (2048, 256, 1, 1, 0, 1, 6, 6, True, 0, 0, False),
+    (64, 64, 3, 1, 1, 1, 130, 258, False, 0, 0, False),     # > 256*128 pixels -> the 128x64 tile
+    (512, 2048, 1, 1, 0, 1, 40, 70, False, 0, 0, False),    # many tiles -> the 128x128 tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "c%d_%d_k%d_s%d_d%d_%dx%d" % (c[0], c[1], c[2], c[3], c[5], c[6], c[7]))
+def test_conv2d(G, case):
+    Cin, Cout, k, stride, pad, dil, H, W, use_bias, act, in_relu, use_res = case
+    x = rnd(1, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=1.0 / math.sqrt(Cin * k * k))
+    b = rnd(Cout, seed=3) if use_bias else None
+    xin = F.relu(x) if in_relu else x
+    ref = F.conv2d(xin, w, b, stride, pad, dil)
+    res = rnd(*ref.shape, seed=4) if use_res else None
+    if use_res:
+        ref = ref + res
+    ref = F.relu(ref) if act == 1 else (F.leaky_relu(ref, 0.01) if act == 2 else ref)
+    cw = G.pack_weight(w)
+    xa = G.to_act(x, ld=cw.I_pad + 4, off=4)                 # read a channel slice of a wider buffer
+    assert xa.C == cw.I_pad
+    out = G.empty_act(ref.shape[2], ref.shape[3], max(4, (Cout + 3) // 4 * 4), ld=Cout + 8 - Cout % 4, off=4)
+    ra = G.to_act(res) if use_res else None
+    G.conv2d(xa, cw, out, None if b is None else b.to(G.DEV), stride, pad, dil, act, in_relu, ra)
+    got = G.from_act(out, Cout)
+    assert torch.isfinite(got).all()
+    assert G.maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_weight_standardisation_and_bn_fold(G):
+    from oracle.otvm_oracle import standardise_weight
+    from otvm_amd import lib as L
+    w = rnd(64, 24, 3, 3, seed=5, scale=0.05) + 0.02
+    x = rnd(1, 24, 20, 28, seed=6)
+    cw = G.pack_weight(w, ws=True)
+    out = G.empty_act(20, 28, 64)
+    G.conv2d(G.to_act(x), cw, out, pad=1)
+    ref = F.conv2d(x, standardise_weight(w), None, 1, 1)
+    assert G.maxdiff(G.from_act(out), ref) <= 3e-5 * float(ref.abs().max())
+    # BatchNorm(eval) folded into the conv (scale into weights, shift into bias)
+    g_, b_, m_, v_ = rnd(64, seed=7).abs() + 0.5, rnd(64, seed=8), rnd(64, seed=9), rnd(64, seed=10).abs() + 0.5
+    dv = [t.to(G.DEV) for t in (g_, b_, m_, v_)]
+    scale = torch.empty(64, device=G.DEV)
+    bias = torch.empty(64, device=G.DEV)
+    L.check(L.load().otvm_fold_bn(dv[0].data_ptr(), dv[1].data_ptr(), dv[2].data_ptr(), dv[3].data_ptr(), 1e-5, 64,
+                                  scale.data_ptr(), bias.data_ptr(), G.stream()))
+    cw = G.pack_weight(w, scale=scale.cpu())
+    G.conv2d(G.to_act(x), cw, out, bias, pad=1, act=1)
+    ref = F.relu(F.batch_norm(F.conv2d(x, w, None, 1, 1), m_, v_, g_, b_, False, 0.0, 1e-5))
+    assert G.maxdiff(G.from_act(out), ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("Cc,H,W,act,use_res", [(64, 33, 47, 1, False), (128, 16, 20, 2, False), (256, 9, 11, 1, True),
+                                                (2048, 5, 7, 0, False), (1024, 6, 6, 1, True), (256, 1, 1, 2, False),
+                                                (256, 2, 2, 2, False), (64, 128, 160, 2, True)])
+def test_groupnorm(G, Cc, H, W, act, use_res):
+    from otvm_amd import lib as L
+    lib = L.load()
+    x = rnd(1, Cc, H, W, seed=11) * 3 + 1.5
+    gamma, beta = rnd(Cc, seed=12) + 1, rnd(Cc, seed=13)
+    res = rnd(1, Cc, H, W, seed=14) if use_res else None
+    ref = F.group_norm(x, 32, gamma, beta, 1e-5)
+    if use_res:
+        ref = ref + res
+    ref = F.relu(ref) if act == 1 else (F.leaky_relu(ref, 0.01) if act == 2 else ref)
+    xa = G.to_act(x, ld=Cc + 4, off=4)
+    out = G.empty_act(H, W, Cc)
+    stats = torch.zeros(64, dtype=torch.float64, device=G.DEV)
+    ra = G.to_act(res) if use_res else None
+    gd, bd = gamma.to(G.DEV), beta.to(G.DEV)
+    L.check(lib.otvm_gn_stats(xa.ptr, H * W, Cc, xa.ld, stats.data_ptr(), G.stream()))
+    L.check(lib.otvm_gn_apply(xa.ptr, H * W, Cc, xa.ld, stats.data_ptr(), gd.data_ptr(), bd.data_ptr(),
+                              0 if ra is None else ra.ptr, 0 if ra is None else ra.ld, act, out.ptr, out.ld, G.stream()))
+    torch.cuda.synchronize()
+    assert G.maxdiff(G.from_act(out), ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_maxpool_upsample_ppm(G):
+    from otvm_amd import lib as L
+    lib = L.load()
+    x = rnd(1, 64, 34, 50, seed=15)
+    out = G.empty_act(17, 25, 64)
+    xa = G.to_act(x)
+    L.check(lib.otvm_maxpool3x3s2(xa.ptr, 34, 50, 64, xa.ld, out.ptr, out.ld, G.stream()))
+    torch.cuda.synchronize()
+    assert G.maxdiff(G.from_act(out), F.max_pool2d(x, 3, 2, 1)) == 0
+    # x2 upsample with add, and arbitrary-size upsample (PPM 3x3 -> 17x30)
+    add = rnd(1, 64, 68, 100, seed=16)
+    out = G.empty_act(68, 100, 64, ld=80, off=8)
+    aa = G.to_act(add)
+    L.check(lib.otvm_upsample_bilinear(xa.ptr, 34, 50, 64, xa.ld, aa.ptr, aa.ld, out.ptr, 68, 100, out.ld, G.stream()))
+    torch.cuda.synchronize()
+    ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) + add
+    assert G.maxdiff(G.from_act(out), ref) <= 1e-5
+    for s in (1, 2, 3, 6):
+        y = rnd(1, 256, s, s, seed=17 + s)
+        ya = G.to_act(y)
+        out = G.empty_act(17, 30, 256)
+        L.check(lib.otvm_upsample_bilinear(ya.ptr, s, s, 256, ya.ld, 0, 0, out.ptr, 17, 30, out.ld, G.stream()))
+        torch.cuda.synchronize()
+        ref = F.interpolate(y, size=(17, 30), mode="bilinear", align_corners=False)
+        assert G.maxdiff(G.from_act(out), ref) <= 1e-5
+    # adaptive average pooling bins 1,2,3,6 on a 17x30 map
+    z = rnd(1, 512, 17, 30, seed=30)
+    za = G.to_act(z)
+    pool = torch.empty(50 * 512, device=G.DEV)
+    L.check(lib.otvm_ppm_pool(za.ptr, 17, 30, 512, za.ld, pool.data_ptr(), G.stream()))
+    torch.cuda.synchronize()
+    base = 0
+    for s in (1, 2, 3, 6):
+        ref = F.adaptive_avg_pool2d(z, s)[0].permute(1, 2, 0).reshape(s * s, 512)
+        got = pool[base * 512:(base + s * s) * 512].reshape(s * s, 512).cpu()
+        assert G.maxdiff(got, ref) <= 1e-5
+        base += s * s
+
+
+@pytest.mark.parametrize("T,h,w", [(1, 5, 7), (2, 8, 12), (5, 9, 13), (3, 16, 20)])
+def test_memory_read(G, T, h, w):
+    from oracle.otvm_oracle import memory_read
+    from otvm_amd import lib as L
+    lib = L.load()
+    hw = h * w
+    mk, mv = rnd(128, T, h, w, seed=40, scale=2.5), rnd(512, T, h, w, seed=41)
+    qk, qv = rnd(128, h, w, seed=42, scale=2.5), rnd(512, h, w, seed=43)
+    mk[:, 0, 0, 0] = qk[:, 1, 1] * 3            # a dominant match: forces large running-max jumps
+    ref = memory_read(mk, mv, qk, qv)[:512].reshape(512, hw).t()
+    keys = [mk[:, t].reshape(128, hw).t().contiguous().to(G.DEV) for t in range(T)]
+    vals = [mv[:, t].reshape(512, hw).t().contiguous().to(G.DEV) for t in range(T)]
+    q = qk.reshape(128, hw).t().contiguous().to(G.DEV)
+    out = torch.full((hw, 1024), float("nan"), device=G.DEV)
+    ws = torch.empty(int(lib.otvm_memory_read_ws_bytes(hw, T)), dtype=torch.uint8, device=G.DEV)
+    kp = (C.c_void_p * T)(*[k.data_ptr() for k in keys])
+    vp = (C.c_void_p * T)(*[v.data_ptr() for v in vals])
+    L.check(lib.otvm_memory_read(q.data_ptr(), 128, kp, vp, T, hw, out.data_ptr(), 1024, ws.data_ptr(), G.stream()))
+    torch.cuda.synchronize()
+    got = out[:, :512].cpu()
+    assert torch.isfinite(got).all()
+    assert G.maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def _encode(G, probs, override=None):
+    from otvm_amd import lib as L
+    lib = L.load()
+    _, Hp, Wp = probs.shape
+    P = Hp * Wp
+    pd = probs.contiguous().to(G.DEV)
+    x11 = torch.zeros(P * 12, device=G.DEV)
+    d80 = torch.zeros(P * 80, device=G.DEV)
+    cls = torch.empty(P, dtype=torch.uint8, device=G.DEV)
+    ws = torch.empty(int(lib.otvm_trimap_encode_ws_bytes(Hp, Wp)), dtype=torch.uint8, device=G.DEV)
+    ov = None if override is None else override.to(torch.uint8).contiguous().to(G.DEV)
+    L.check(lib.otvm_trimap_encode(pd.data_ptr(), Hp, Wp, 0 if ov is None else ov.data_ptr(), cls.data_ptr(),
+                                   x11.data_ptr(), 12, d80.data_ptr(), 80, ws.data_ptr(), G.stream()))
+    torch.cuda.synchronize()
+    x = x11.reshape(Hp, Wp, 12).cpu()
+    return x[..., 3:11].permute(2, 0, 1), cls.reshape(Hp, Wp).cpu(), d80.reshape(Hp, Wp, 80)[..., 70:72].cpu()
+
+
+def test_trimap_encode(G):
+    from oracle.otvm_oracle import make_trimap8, class_map
+    from otvm_amd.synth_data import disc_trimap
+    cases = []
+    H, W = 64, 96
+    cases.append(torch.from_numpy(disc_trimap(H, W)))
+    allbg = torch.zeros(3, H, W); allbg[0] = 1
+    cases.append(allbg)                                          # fg class empty -> zero triple
+    allfg = torch.zeros(3, H, W); allfg[2] = 1
+    cases.append(allfg)
+    single = allbg.clone(); single[0, 20, 30] = 0; single[2, 20, 30] = 1
+    cases.append(single)
+    g = torch.Generator().manual_seed(5)
+    cases.append(torch.softmax(torch.randn(3, H, W, generator=g) * 3, 0))        # noisy masks
+    smooth = F.interpolate(torch.randn(1, 3, 8, 12, generator=g) * 4, size=(H, W), mode="bilinear")[0]
+    cases.append(torch.softmax(smooth, 0))
+    cases.append(torch.softmax(F.interpolate(torch.randn(1, 3, 5, 7, generator=g) * 4, size=(160, 224), mode="bilinear")[0], 0))
+    for probs in cases:
+        got, cls, tri2 = _encode(G, probs)
+        ref = make_trimap8(probs)
+        assert torch.equal(cls.long(), class_map(probs))
+        assert G.maxdiff(got, ref) <= 2e-6, G.maxdiff(got, ref)
+        assert torch.equal(tri2[..., 0], probs[0]) and torch.equal(tri2[..., 1], probs[2])
+    # class-map override (tie-break synchronisation used by the sequence parity test)
+    probs = cases[-2]
+    ov = class_map(probs).clone()
+    ov[10:14, 10:14] = 2
+    got, cls, _ = _encode(G, probs, ov)
+    assert torch.equal(cls.long(), ov)
+    assert G.maxdiff(got, make_trimap8(probs, ov)) <= 2e-6
+
+
+def test_fba_head(G):
+    from oracle.otvm_oracle import fba_fusion
+    from otvm_amd import lib as L
+    lib = L.load()
+    P = 37 * 41
+    for n_out in (7, 10):
+        hid = rnd(1, 16, 37, 41, seed=50)
+        w, b = rnd(n_out, 16, 1, 1, seed=51, scale=0.4), rnd(n_out, seed=52, scale=0.3)
+        img = torch.rand(1, 3, 37, 41, generator=torch.Generator().manual_seed(53))
+        out = F.conv2d(hid, w, b)
+        al = torch.clamp(out[:, 0:1], 0, 1)
+        al, _, _ = fba_fusion(al, img, torch.sigmoid(out[:, 1:4]), torch.sigmoid(out[:, 4:7]))
+        ha = G.to_act(hid, c_pad=16, ld=24, off=0)
+        ia = G.to_act(img, c_pad=4, ld=8, off=0)
+        alpha = torch.full((P * 2,), float("nan"), device=G.DEV)
+        tri = torch.full((3 * P,), float("nan"), device=G.DEV)
+        sm = torch.zeros(P * 24, device=G.DEV)
+        wd, bd = w.reshape(n_out, 16).contiguous().to(G.DEV), b.to(G.DEV)
+        L.check(lib.otvm_fba_head(ha.ptr, ha.ld, wd.data_ptr(), bd.data_ptr(), n_out, ia.ptr, ia.ld, P, alpha.data_ptr(), 2,
+                                  tri.data_ptr() if n_out == 10 else 0, sm.data_ptr() + 64 if n_out == 10 else 0, 24,
+                                  G.stream()))
+        torch.cuda.synchronize()
+        assert G.maxdiff(alpha[::2].cpu(), al.flatten()) <= 2e-6
+        if n_out == 10:
+            p = torch.softmax(out[:, 7:10], 1)[0].reshape(3, P)
+            assert G.maxdiff(tri.reshape(3, P).cpu(), p) <= 2e-6
+            s = sm.reshape(P, 24).cpu()
+            assert G.maxdiff(s[:, 19], p[1]) <= 2e-6 and G.maxdiff(s[:, 20], p[2]) <= 2e-6
+            assert G.maxdiff(s[:, 21], al.flatten()) <= 2e-6
+
+
+def test_glue_kernels(G):
+    from otvm_amd import lib as L
+    from otvm_amd.synth_data import soft_alpha
+    lib = L.load()
+    H, W = 50, 70
+    # first-frame trimap from GT alpha, narrow / medium kernels (alpha/model.py:342-362)
+    a = torch.from_numpy(soft_alpha(H, W, 0))
+    for r in (5, 12):
+        trimask = ((a > 0) & (a < 1)).float()[None, None]
+        tm = F.max_pool2d(trimask, 2 * r + 1, 1, r)[0, 0]
+        t1 = torch.where(tm > 0.5, torch.ones_like(a), 2 * a).long()
+        ref = F.one_hot(t1, 3).permute(2, 0, 1).float()
+        out = torch.empty(3 * H * W, device=G.DEV)
+        ws = torch.empty(H * W, dtype=torch.uint8, device=G.DEV)
+        ad = a.contiguous().to(G.DEV)
+        L.check(lib.otvm_trimap_from_alpha(ad.data_ptr(), H, W, r, out.data_ptr(), ws.data_ptr(), G.stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(out.reshape(3, H, W).cpu(), ref)
+    # pad / crop round trip and u8 truncation
+    tri = torch.rand(3, H, W)
+    Hp, Wp, lh, lw = 64, 96, 7, 13
+    pd = torch.empty(3 * Hp * Wp, device=G.DEV)
+    td = tri.contiguous().to(G.DEV)
+    L.check(lib.otvm_pad_trimap(td.data_ptr(), H, W, pd.data_ptr(), Hp, Wp, lh, lw, G.stream()))
+    ref = torch.cat([F.pad(tri[:1], (lw, Wp - W - lw, lh, Hp - H - lh), value=1.0),
+                     F.pad(tri[1:], (lw, Wp - W - lw, lh, Hp - H - lh), value=0.0)])
+    torch.cuda.synchronize()
+    assert torch.equal(pd.reshape(3, Hp, Wp).cpu(), ref)
+    alpha_p = torch.rand(Hp * Wp, device=G.DEV)
+    al, au8, tr = torch.empty(H * W, device=G.DEV), torch.empty(H * W, dtype=torch.uint8, device=G.DEV), torch.empty(3 * H * W, device=G.DEV)
+    L.check(lib.otvm_crop_outputs(alpha_p.data_ptr(), pd.data_ptr(), Hp, Wp, H, W, lh, lw, al.data_ptr(), au8.data_ptr(),
+                                  tr.data_ptr(), G.stream()))
+    torch.cuda.synchronize()
+    ac = alpha_p.reshape(Hp, Wp)[lh:lh + H, lw:lw + W].cpu()
+    assert torch.equal(al.reshape(H, W).cpu(), ac)
+    assert torch.equal(au8.reshape(H, W).cpu(), (ac * 255).byte())
+    assert torch.equal(tr.reshape(3, H, W).cpu(), tri)
+    # one-hot of argmax
+    oh = torch.empty(3 * H * W, device=G.DEV)
+    L.check(lib.otvm_onehot_argmax3(td.data_ptr(), H * W, oh.data_ptr(), G.stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(oh.reshape(3, H, W).cpu(), F.one_hot(tri.max(0)[1], 3).permute(2, 0, 1).float())
