@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- OTVM per-frame inference throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step = one frame of the hot path (EvalModel.forward: trimap propagation + alpha prediction + memorize)
+on a synthetic 1920x1080 clip (BASELINE.json configs[2]: T=100, memory every 5 frames, max 5 slots).
+Frames are resident in HBM as fp32 BGR [1,1,3,H,W] tensors (the reference DataLoader's format) before
+the timed region starts.  One process per GPU; with N>1 every rank mattes its own sequence (sequences
+are independent, frames inside a sequence are strictly sequential -- SURVEY.md 8e), no data-path
+collective; ranks meet in one all-reduce for the timing/metric sums.  value = total frames / max time.
+
+Extra legs (rank 0, N=1): `roofline` (fp32-MFMA implicit-GEMM conv kernel: algorithmic FLOPs / HIP-event
+time per launch, instrumented replay of the timed frames on the same stream) and `cpu_baseline`
+(the CPU oracle timed on the host cores for one steady-state frame of the same clip).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def device_clip(H, W, T, seed, dev):
+    """Smooth random video generated on the device (synthetic-data plumbing, not the measured path):
+    bilinear-upsampled low-res noise with per-frame drift + a moving disc; uint8-quantised BGR as fp32."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    h, w = H // 8, W // 8
+    base = torch.rand(1, 3, h, w, generator=g).to(dev)
+    drift = (torch.rand(1, 3, h, w, generator=g) * 2 - 1).to(dev)
+    yy, xx = torch.meshgrid(torch.arange(H, device=dev, dtype=torch.float32),
+                            torch.arange(W, device=dev, dtype=torch.float32), indexing="ij")
+    frames = []
+    for t in range(T):
+        lo = (base + 0.02 * t * drift).clamp(0, 1)
+        img = torch.nn.functional.interpolate(lo, size=(H, W), mode="bilinear", align_corners=True)
+        disc = ((yy - (H / 2 + 0.5 * t)) ** 2 + (xx - (W / 2 + 1.0 * t)) ** 2) < (H / 4) ** 2
+        img = torch.where(disc[None, None], 0.35 + 0.65 * img, 0.75 * img)
+        frames.append(torch.floor(img * 255.0 + 0.5).clamp(0, 255)[None].contiguous())   # [1,1,3,H,W]
+    return frames
+
+
+def build_model(dev, dilate_kernel=12):
+    from otvm_amd import helpers
+    from otvm_amd.synth_weights import synthetic_state_dict
+    sd = synthetic_state_dict(0)
+    cfg = helpers.default_cfg()
+    m = helpers.get_model_alpha(cfg, helpers.get_model_trimap(cfg, "Test", dilate_kernel), "Test", dilate_kernel)
+    m.load_state_dict(sd, strict=True)
+    return m.to(dev).eval(), sd
+
+
+def frame_kwargs(t, T, skip, max_num):
+    return dict(first_frame=(t == 0), last_frame=(t == T - 1), memorize=(t % skip == 0) if skip > 2 else False,
+                max_memory_num=max_num)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=97)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--skip", type=int, default=5)
+    ap.add_argument("--max-num", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    H, W, K, Wm = args.height, args.width, args.steps, args.warmup
+    T = Wm + K                                              # frames of the clip: warm-up then timed
+    from otvm_amd.synth_data import disc_trimap
+    model, sd = build_model(dev)
+    frames = device_clip(H, W, T, seed=2000 + rank, dev=dev)
+    tri = torch.from_numpy(disc_trimap(H, W))[None, None].to(dev)
+    a = torch.ones(1, 1, 1, H, W, device=dev)
+
+    def run_frames(t0, t1, sink=None):
+        for t in range(t0, t1):
+            out = model(a, frames[t], frames[t], tri=None, tri_gt=tri, large_input=False,
+                        **frame_kwargs(t, T, args.skip, args.max_num))
+            if sink is not None:
+                sink.append(out[3])
+        return out
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    # ---- warm-up (first frame: plan build, allocations; then W-1 steady frames)
+    run_frames(0, Wm)
+    sync_all()
+    t_start = time.perf_counter()
+    out = run_frames(Wm, T)
+    sync_all()
+    elapsed = time.perf_counter() - t_start
+    alpha_last = out[3]
+
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt[0])
+        frames_total = torch.tensor([float(K)], dtype=torch.float64, device=dev)
+        dist.all_reduce(frames_total, op=dist.ReduceOp.SUM)
+        total_frames = float(frames_total[0])
+    else:
+        total_frames = float(K)
+
+    eng = model._engine
+    pl = eng.last_plan
+    Hp, Wp, hw = pl.Hp, pl.Wp, pl.hw
+    T_read = min(args.max_num, 5)
+    flops_frame = 2.6195e6 * Hp * Wp + 1280.0 * T_read * hw * hw         # SURVEY.md 8d, steady state
+    result = {
+        "metric": "frames_per_sec", "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world,
+        "steps": K, "warmup": Wm, "ms_per_step": 1000.0 * elapsed / K, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "synthetic %dx%d clip, T=%d frames (warmup %d + timed %d), memory every %d, max %d slots, "
+                               "trimap propagation + alpha + memorize per frame, one sequence per GPU" %
+                               (W, H, T, Wm, K, args.skip, args.max_num),
+                   "padded": [Hp, Wp], "weights": "synthetic (otvm_amd.synth_weights seed 0)",
+                   "parallelism": "sequence-per-gpu x%d" % world},
+        "algorithmic_tflop_per_frame": flops_frame / 1e12,
+        "achieved_tflops_whole_frame": flops_frame / 1e12 / (elapsed / K),
+        "alpha_checksum": float(alpha_last.double().mean()),
+    }
+
+    if rank == 0 and world == 1 and not args.no_roofline:
+        # instrumented replay of a window of steady-state frames: HIP events around each conv launch
+        nrep = min(K, 10)
+        eng.prof = []
+        run_frames(T - nrep, T)
+        torch.cuda.synchronize(dev)
+        prof, eng.prof = eng.prof, None
+        tot_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof)
+        tot_fl = float(sum(f for _, f, _, _ in prof))
+        n = len(prof)
+        per_layer = {}
+        for label, f, e0, e1 in prof:
+            d = per_layer.setdefault(label, [0.0, 0.0, 0])
+            d[0] += e0.elapsed_time(e1); d[1] += f; d[2] += 1
+        worst = sorted(per_layer.items(), key=lambda kv: -kv[1][0])[:8]
+        achieved = tot_fl / (tot_ms * 1e-3) / 1e12
+        result["roofline"] = {
+            "bound": "mfma", "kernel": "conv_igemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+            "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+            "traffic": None,
+            "launches_per_frame": n / nrep, "avg_launch_ms": tot_ms / n, "algorithmic_gflop_per_launch": tot_fl / n / 1e9,
+            "conv_ms_per_frame": tot_ms / nrep, "conv_share_of_frame": (tot_ms / nrep) / (1000.0 * elapsed / K),
+            "slowest_layers_ms_per_frame": {k: round(v[0] / nrep, 3) for k, v in worst},
+            "method": "torch.cuda.Event pairs on the launch stream around every otvm_conv2d launch, replay of the last "
+                      "%d timed frames; FLOPs = 2*Ho*Wo*Cout*kh*kw*Cin (un-padded)" % nrep,
+        }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # CPU baseline: the oracle (port of the reference algorithm) on the host cores, ONE steady-state frame of the
+        # same clip at full resolution; its bank is seeded from the device bank so no CPU warm-up frames are needed.
+        from oracle.otvm_oracle import OtvmOracle
+        orc = OtvmOracle(sd, dilate_kernel=12)
+        t_s = 2
+        # replay frames 0..t_s-1 on the device to obtain the bank state at frame t_s
+        run_frames(0, t_s)
+        torch.cuda.synchronize(dev)
+        orc.bank = [(s["k"].t.reshape(hw, 128).t().reshape(128, Hp // 16, Wp // 16).cpu().contiguous(),
+                     s["v"].t.reshape(hw, 512).t().reshape(512, Hp // 16, Wp // 16).cpu().contiguous(), s["frame"])
+                    for s in eng.bank]
+        fa, ff, ft = a.cpu(), frames[t_s].cpu(), tri.cpu()
+        c0 = time.perf_counter()
+        ref = orc.frame(fa, ff, ff.clone(), tri_gt=ft, frame_id=t_s, **frame_kwargs(t_s, T, args.skip, args.max_num))
+        cpu_s = time.perf_counter() - c0
+        hip = model(a, frames[t_s], frames[t_s], tri=None, tri_gt=tri, **frame_kwargs(t_s, T, args.skip, args.max_num))
+        torch.cuda.synchronize(dev)
+        result["cpu_baseline"] = {
+            "value": 1.0 / cpu_s, "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 steady-state frame (t=%d, segment + FBA + memorize, T_read=%d) of the same %dx%d clip; "
+                      "oracle/otvm_oracle.py (PyTorch-CPU fp32, oneDNN) on %d threads of %d host cpus"
+                      % (t_s, len(eng.bank), W, H, torch.get_num_threads(), os.cpu_count()),
+            "seconds_per_frame": cpu_s,
+            "alpha_maxabs_hip_vs_cpu_same_frame": float((hip[3].cpu() - ref[3]).abs().max()),
+        }
+
+    if rank == 0:
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

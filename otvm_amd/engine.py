@@ -52,7 +52,7 @@ class Act:
 
 
 class ConvW:
-    __slots__ = ("w", "K_pad", "O", "I_pad", "kh", "kw", "bias")
+    __slots__ = ("w", "K_pad", "O", "I", "I_pad", "kh", "kw", "bias")
 
 
 def pad_amounts(h, w, d):
@@ -97,6 +97,7 @@ class HipEngine:
         self.bank = []
         self.free_slots = []
         self.stream = 0
+        self.prof = None
         self._pack_all()
 
     # ------------------------------------------------------------------ weights
@@ -106,7 +107,7 @@ class HipEngine:
     def _pack(self, name, w, ws=False, scale=None, bias=None, i_pad=None):
         O, I, kh, kw = w.shape
         cw = ConvW()
-        cw.O, cw.kh, cw.kw = O, kh, kw
+        cw.O, cw.I, cw.kh, cw.kw = O, I, kh, kw
         cw.I_pad = _rup(I, 4) if i_pad is None else i_pad
         cw.K_pad = _rup(kh * kw * cw.I_pad, 32)
         O_pad = _rup(O, 128)
@@ -296,7 +297,8 @@ class FramePlan:
                          0 if residual is None else residual.ptr, 0 if residual is None else residual.ld,
                          out.ptr, Ho, Wo, w.O, out.ld, w.kh, w.kw, stride, pad, dil, in_relu, act)
         self._keep.append(p)
-        S.append((self.lib.otvm_conv2d, (C.byref(p),), "conv " + wname))
+        flops = 2 * Ho * Wo * w.O * w.kh * w.kw * w.I           # algorithmic (un-padded) 2*MAC
+        S.append((self.lib.otvm_conv2d, (C.byref(p),), "conv " + wname, flops))
 
     def gn(self, S, x, name, act, out=None, residual=None):
         out = x if out is None else out
@@ -530,8 +532,23 @@ class FramePlan:
 
     # ------------------------------------------------------------------ run
     def run(self, key, stream):
+        prof = self.e.prof
+        if prof is None:
+            for st in self.steps[key]:
+                rc = st[0](*st[1], stream)
+                if rc != 0:
+                    L.check(rc, st[2])
+            return
+        # instrumented pass (bench.py roofline leg): HIP events around every conv launch, on this stream
         for st in self.steps[key]:
-            rc = st[0](*st[1], stream)
+            if st[2].startswith("conv "):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = st[0](*st[1], stream)
+                e1.record()
+                prof.append((st[2], st[3], e0, e1))
+            else:
+                rc = st[0](*st[1], stream)
             if rc != 0:
                 L.check(rc, st[2])
 
@@ -561,8 +578,15 @@ class FramePlan:
             self.conv(S, self.r4m, "trimap.model.KV_M_r4.Key", slot["k"], pad=1)
             self.conv(S, self.r4m, "trimap.model.KV_M_r4.Value", slot["v"], pad=1)
             slot["kv_steps"] = S
+        prof = self.e.prof
         for st in slot["kv_steps"]:
+            if prof is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             L.check(st[0](*st[1], stream), st[2])
+            if prof is not None:
+                e1.record()
+                prof.append((st[2], st[3], e0, e1))
 
     def encode(self, stream, cls_override=None):
         """8-channel trimap encoding of PROBS into X11[3:11] / D80[70:72] (alpha/model.py:40-53)."""

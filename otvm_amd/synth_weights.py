@@ -91,7 +91,7 @@ def _conv_weight(key, shape, r):
     if "Encoder_M.conv1_" in key:
         return r.normal(0.0, gain * 0.5, shape)
     if ".Key." in key:
-        return r.normal(0.0, 2.5 * np.sqrt(1.0 / fan_in), shape)
+        return r.normal(0.0, 1.2 * np.sqrt(1.0 / fan_in), shape)   # attention logits std ~6 (peaky, not one-hot)
     if "Decoder.pred" in key:
         w = r.normal(0.0, 4.0 * np.sqrt(1.0 / fan_in), shape)
         return w - w.mean(axis=(1, 2, 3), keepdims=True)         # balanced classes on relu(m2) >= 0

@@ -1,0 +1,99 @@
+"""``run_video_matte``: the build-owned counterpart of the reference's per-sequence loop
+(reference eval.py:157-228) -- frame flags, memory schedule, large-input rule, u8 quantisation.
+
+BASELINE.json names a ``run_video_matte()`` call surface; the reference has no such function (its loop
+is inlined in eval.py), so this reproduces that loop around the reference-shaped ``EvalModel``.
+"""
+import numpy as np
+import torch
+
+
+def memory_schedule(i_seq, height, width, skip=10, max_num=5):
+    """(memorize, max_memory_num, large_input) for frame ``i_seq`` -- eval.py:180-190, config.py:22-23."""
+    large = min(height, width) > 1100
+    if large:
+        skip, max_num = int(skip * 2), int(max_num / 2)
+    memorize = (i_seq % skip) == 0 if skip > 2 else False
+    return memorize, max_num, large
+
+
+def trimap_file_to_onehot(tri):
+    """Grayscale / 3-channel trimap image -> one-hot float32 [3,H,W] (bg, unknown, fg): dataset.py:880-893."""
+    tri = np.asarray(tri)
+    if tri.ndim == 3:
+        t = tri > 1                                    # BGR order as read by cv2
+        out = np.zeros(t.shape, np.float32)
+        out[..., 0][np.logical_not(t[..., 1] + t[..., 2])] = 1
+        out[..., 1][t[..., 2]] = 1
+        out[..., 2][t[..., 1]] = 1
+    else:
+        t = tri.copy()
+        out = np.zeros(t.shape + (3,), np.float32)
+        out[..., 0][t == 0] = 1
+        out[..., 2][t == t.max()] = 1
+        t[t == t.max()] = 0
+        out[..., 1][t == t.max()] = 1                  # second-largest level = unknown (incl. the two-level quirk)
+    return np.ascontiguousarray(out.transpose(2, 0, 1))
+
+
+@torch.no_grad()
+def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, skip=10, max_num=5,
+                    frames_are_rgb=False, on_frame=None, device=None, keep_on_device=False):
+    """Matte one sequence.
+
+    model       : EvalModel (optionally wrapped in nn.DataParallel), on the GPU
+    frames      : iterable/array of uint8 or float [H,W,3] images, BGR (cv2 order) unless frames_are_rgb
+    trimap      : first-frame trimap, one-hot float [3,H,W] (demo flow, dataset.py:866-893) or None
+    alphas      : per-frame GT alpha [H,W] in [0,1] (VideoMatting108 flow: first-frame trimap derived
+                  from alpha with the model's dilate kernel) -- required when trimap is None
+    backgrounds : optional per-frame BG images (V108 composites fg*a + bg*(1-a)); default bg = fg
+    Returns dict(alpha=[T,H,W] float32, alpha_u8=[T,H,W] uint8 (truncated, eval.py:209), trimap=[T,3,H,W]).
+    """
+    frames = list(frames) if not hasattr(frames, "shape") else frames
+    T = len(frames)
+    dev = device or next(model.parameters()).device
+    out_a, out_u8, out_t = [], [], []
+    core = model.module if hasattr(model, "module") else model
+    for i in range(T):
+        fr = frames[i]
+        f = fr if torch.is_tensor(fr) else torch.from_numpy(np.ascontiguousarray(fr))
+        f = f.to(dev).float()
+        if frames_are_rgb:
+            f = f.flip(-1)
+        fg = f.permute(2, 0, 1)[None, None].contiguous()
+        H, W = fg.shape[-2:]
+        if backgrounds is not None:
+            b = backgrounds[i]
+            b = b if torch.is_tensor(b) else torch.from_numpy(np.ascontiguousarray(b))
+            bg = b.to(dev).float().permute(2, 0, 1)[None, None].contiguous()
+        else:
+            bg = fg
+        if trimap is not None:
+            a = torch.ones(1, 1, 1, H, W, device=dev)
+            t = trimap if torch.is_tensor(trimap) else torch.from_numpy(np.ascontiguousarray(trimap))
+            tri_gt = t.to(dev).float()[None, None]
+        else:
+            al = alphas[i]
+            al = al if torch.is_tensor(al) else torch.from_numpy(np.ascontiguousarray(al))
+            a = al.to(dev).float()[None, None, None]
+            tri_gt = None
+        memorize, max_memory_num, large = memory_schedule(i, H, W, skip, max_num)
+        out = model(a, fg, bg, tri=None, tri_gt=tri_gt, first_frame=(i == 0), last_frame=(i == T - 1),
+                    memorize=memorize, max_memory_num=max_memory_num, large_input=large)
+        alpha = out[3][0, 0, 0]
+        u8 = core._engine.last_alpha_u8
+        if on_frame is not None:
+            on_frame(i, alpha, u8, out)
+        if keep_on_device:
+            out_a.append(alpha), out_u8.append(u8), out_t.append(out[1][0, 0])
+        else:
+            out_a.append(alpha.cpu()), out_u8.append(u8.cpu()), out_t.append(out[1][0, 0].cpu())
+    return dict(alpha=torch.stack(out_a), alpha_u8=torch.stack(out_u8), trimap=torch.stack(out_t))
+
+
+def sad(pred, ref, mask=None):
+    """Sum of absolute differences / 1000 (reference utils/tmp/metric.py:177-182)."""
+    d = (pred.float() - ref.float()).abs()
+    if mask is not None:
+        d = d * mask
+    return float(d.sum()) / 1000.0

@@ -5,7 +5,8 @@ Parity statement checked here ("parity"):
   * alpha max-abs <= 1e-3 vs the oracle on every frame (fp32 contract of BASELINE.json);
   * the only discontinuity of the path is the 3-class argmax that feeds the distance transform
     (alpha/model.py:42).  If the HIP class map differs from the oracle's, every differing pixel must be
-    a numerical near-tie in the oracle (top-2 probability gap < 1e-3); the oracle frame is then re-run
+    a numerical near-tie in the oracle (top-2 probability gap < 2e-3, i.e. inside twice the 1e-3 bound
+    asserted on the probabilities themselves); the oracle frame is then re-run
     with the HIP tie-breaks (``class_override``) and the 1e-3 bound must hold.  The number of such
     tie-breaks is reported; on the committed sequences it is expected to be 0 or a handful.
 """
@@ -89,7 +90,7 @@ def run_sequence(model, synth_sd, meta, max_frames=None):
             ties = int(diff.sum())
             top2 = torch.sort(cap["tri_in"][0], dim=0, descending=True)[0]
             gap = (top2[0] - top2[1])[diff]
-            assert float(gap.max()) < 1e-3, "class map differs at a pixel that is not a near-tie (gap %g)" % float(gap.max())
+            assert float(gap.max()) < 2e-3, "class map differs at a pixel that is not a near-tie (gap %g)" % float(gap.max())
             orc.bank = bank_before
             cap = {}
             ref = orc.frame(a, fg, bg, tri_gt=tri_gt, frame_id=t, capture=cap, class_override=cls_h, **flags)
@@ -118,6 +119,8 @@ def test_sequence_vs_oracle_and_golden(name, model, synth_sd):
         assert len(r["bank"]) == gold["bank"][t]
         assert r["alpha"] <= ALPHA_TOL, "frame %d alpha max-abs %.3e (stages: %s)" % (t, r["alpha"], fmt(r["rep"]))
         assert r["tri"] <= 5e-3, "frame %d trimap max-abs %.3e" % (t, r["tri"])
+        if "tri_in" in r["rep"]:
+            assert r["rep"]["tri_in"][0] <= 1e-3, "frame %d propagated trimap probs max-abs %.3e" % (t, r["rep"]["tri_in"][0])
         total_ties += r["ties"]
         out, ref = r["out"], r["ref"]
         assert torch.equal(out[2].cpu(), ref[2]) and torch.equal(out[4].cpu(), ref[4])
