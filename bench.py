@@ -27,7 +27,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_FP32_MFMA_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+# MI355X_MICROARCH.md, dense peaks.  f16x3 issues three f16 MFMAs per fp32-equivalent product, so its
+# roofline for ALGORITHMIC (fp32-equivalent) FLOPs is the f16 peak / 3.
+PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0 / 3.0}
+KERNEL_NAME = {"f32": "conv_igemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+               "f16x3": "conv_igemm_f16x3_kernel (3x v_mfma_f32_32x32x16_f16 per fp32-equivalent MAC)"}
 
 
 def device_clip(H, W, T, seed, dev):
@@ -49,13 +53,14 @@ def device_clip(H, W, T, seed, dev):
     return frames
 
 
-def build_model(dev, dilate_kernel=12):
+def build_model(dev, dilate_kernel=12, precision=None):
     from otvm_amd import helpers
     from otvm_amd.synth_weights import synthetic_state_dict
     sd = synthetic_state_dict(0)
     cfg = helpers.default_cfg()
     m = helpers.get_model_alpha(cfg, helpers.get_model_trimap(cfg, "Test", dilate_kernel), "Test", dilate_kernel)
     m.load_state_dict(sd, strict=True)
+    m.precision = precision
     return m.to(dev).eval(), sd
 
 
@@ -73,6 +78,9 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--skip", type=int, default=5)
     ap.add_argument("--max-num", type=int, default=5)
+    ap.add_argument("--precision", default=None, choices=["f32", "f16x3"],
+                    help="conv arithmetic: f16x3 = split-fp16 MFMA with fp32-class accuracy (default), f32 = exact-fp32 MFMA")
+    ap.add_argument("--layer-report", default=None, help="write the per-layer conv timing table (JSON) to this path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -93,7 +101,7 @@ def main():
     H, W, K, Wm = args.height, args.width, args.steps, args.warmup
     T = Wm + K                                              # frames of the clip: warm-up then timed
     from otvm_amd.synth_data import disc_trimap
-    model, sd = build_model(dev)
+    model, sd = build_model(dev, precision=args.precision)
     frames = device_clip(H, W, T, seed=2000 + rank, dev=dev)
     tri = torch.from_numpy(disc_trimap(H, W))[None, None].to(dev)
     a = torch.ones(1, 1, 1, H, W, device=dev)
@@ -134,12 +142,14 @@ def main():
     eng = model._engine
     pl = eng.last_plan
     Hp, Wp, hw = pl.Hp, pl.Wp, pl.hw
+    peak = PEAK_TFLOPS[eng.precision_name]
     T_read = min(args.max_num, 5)
     flops_frame = 2.6195e6 * Hp * Wp + 1280.0 * T_read * hw * hw         # SURVEY.md 8d, steady state
     result = {
         "metric": "frames_per_sec", "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world,
         "steps": K, "warmup": Wm, "ms_per_step": 1000.0 * elapsed / K, "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32" if eng.precision_name == "f32" else "f16x3 (fp32 operands split into fp16 hi+lo, fp32 accumulate)",
+        "data": "synthetic",
         "config": {"workload": "synthetic %dx%d clip, T=%d frames (warmup %d + timed %d), memory every %d, max %d slots, "
                                "trimap propagation + alpha + memorize per frame, one sequence per GPU" %
                                (W, H, T, Wm, K, args.skip, args.max_num),
@@ -165,10 +175,14 @@ def main():
             d = per_layer.setdefault(label, [0.0, 0.0, 0])
             d[0] += e0.elapsed_time(e1); d[1] += f; d[2] += 1
         worst = sorted(per_layer.items(), key=lambda kv: -kv[1][0])[:8]
+        if args.layer_report:
+            rows = [dict(layer=k, ms_per_frame=v[0] / nrep, gflop_per_frame=v[1] / nrep / 1e9, launches_per_frame=v[2] / nrep,
+                         tflops=v[1] / (v[0] * 1e-3) / 1e12) for k, v in sorted(per_layer.items(), key=lambda kv: -kv[1][0])]
+            json.dump(rows, open(args.layer_report, "w"), indent=0)
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
         result["roofline"] = {
-            "bound": "mfma", "kernel": "conv_igemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
-            "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+            "bound": "mfma", "kernel": KERNEL_NAME[eng.precision_name],
+            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": None,
             "launches_per_frame": n / nrep, "avg_launch_ms": tot_ms / n, "algorithmic_gflop_per_launch": tot_fl / n / 1e9,
             "conv_ms_per_frame": tot_ms / nrep, "conv_share_of_frame": (tot_ms / nrep) / (1000.0 * elapsed / K),

@@ -27,6 +27,13 @@ extern "C" {
 #define OTVM_ACT_RELU 1
 #define OTVM_ACT_LEAKY 2 /* negative slope 0.01 (nn.LeakyReLU default, FBA/models.py:305) */
 
+/* Convolution arithmetic.  Both accumulate in fp32 and meet the reference's 1e-3 fp32 contract:
+ *   F32   : v_mfma_f32_32x32x2_f32, exact fp32 products (157 TFLOP/s peak);
+ *   F16X3 : each fp32 operand split into fp16 hi+lo (22 significant bits), three
+ *           v_mfma_f32_32x32x16_f16 passes hi*hi + hi*lo + lo*hi (833 TFLOP/s fp32-equivalent peak). */
+#define OTVM_PREC_F32 0
+#define OTVM_PREC_F16X3 1
+
 const char* otvm_last_error(void);
 int otvm_abi_version(void);
 
@@ -47,7 +54,7 @@ int otvm_fold_bn(const float* gamma, const float* beta, const float* mean, const
                  float* scale, float* bias, void* stream);
 
 /* ---------------------------------------------------------------- convolution ------------------
- * Implicit-GEMM convolution on the fp32 MFMA (v_mfma_f32_32x32x2_f32), replaces every F.conv2d of
+ * Implicit-GEMM convolution on the matrix cores (see OTVM_PREC_*), replaces every F.conv2d of
  * the path (180 per non-first frame).  out = act(conv(in') + bias + residual) where
  * in' = relu(in) if in_relu (STM.py:23-24 pre-activation ResBlock) else in.                       */
 typedef struct {
@@ -58,8 +65,16 @@ typedef struct {
     float* out;       int Ho, Wo, Cout, out_ld;
     int kh, kw, stride, pad, dil;
     int in_relu, act;
+    int precision;                                  /* OTVM_PREC_F32 | OTVM_PREC_F16X3           */
+    const void* w_hi; const void* w_lo;             /* f16x3: split weights [O_pad][K_pad] fp16   */
+    const float* w_scale;                           /* f16x3: per-filter power-of-two scale [Cout] */
 } otvm_conv_params;
 int otvm_conv2d(const otvm_conv_params* p, void* stream);
+
+/* f16x3: derive the split weights from a packed fp32 weight (see otvm_pack_conv_weight):
+ * row o is scaled by 2^-e (|w| <= 1), w_hi = fp16(w), w_lo = fp16(w - w_hi), w_scale[o] = 2^e.   */
+int otvm_split_conv_weight_f16x3(const float* w_packed, int O, int O_pad, int K_pad, void* w_hi, void* w_lo,
+                                 float* w_scale, void* stream);
 
 /* ---------------------------------------------------------------- GroupNorm(32) ----------------
  * nn.GroupNorm(32, C, eps=1e-5, affine) (layers_WS.py:26-27, FBA/models.py:272-276), two passes:
@@ -78,8 +93,10 @@ int otvm_maxpool3x3s2(const float* in, int H, int W, int C, int ld, float* out, 
 int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, int in_ld, const float* add, int add_ld,
                            float* out, int Ho, int Wo, int out_ld, void* stream);
 /* nn.AdaptiveAvgPool2d(s) for s in {1,2,3,6} in one launch (FBA/models.py:300-306);
- * out = 50 bins x C, bins ordered scale-major then row-major.                                     */
-int otvm_ppm_pool(const float* in, int H, int W, int C, int ld, float* out, void* stream);
+ * out = 50 bins x C, bins ordered scale-major then row-major.
+ * ws >= otvm_ppm_pool_ws_bytes(C) (deterministic two-stage reduction).                             */
+int64_t otvm_ppm_pool_ws_bytes(int C);
+int otvm_ppm_pool(const float* in, int H, int W, int C, int ld, float* out, void* ws, void* stream);
 
 /* ---------------------------------------------------------------- memory read (STM.py:140-163) -
  * mem[q, :] = sum_m softmax_m(K[m,:].Q[q,:] / sqrt(128)) V[m,:], m over T slots x hw positions.

@@ -30,6 +30,7 @@ class EvalModel(nn.Module):
         self.trimap = trimap                      # ... which live in the FullModel_eval passed in (alpha/model.py:37)
         self._engine = None
         self._engine_key = None
+        self.precision = None                     # None -> OTVM_PRECISION env or "f16x3"; "f32" = exact-fp32 MFMA
 
     # -- engine lifetime: rebuilt when the weights change or the module moves
     def _get_engine(self):
@@ -37,9 +38,10 @@ class EvalModel(nn.Module):
         if dev.type != "cuda":
             raise RuntimeError("otvm_amd.EvalModel: parameters are on %s; move the model to the GPU (.cuda()) -- "
                                "the HIP path has no CPU fallback" % dev)
-        key = (str(dev), tuple(p._version for p in self.parameters()), tuple(b._version for b in self.buffers()))
+        key = (str(dev), self.precision, tuple(p._version for p in self.parameters()),
+               tuple(b._version for b in self.buffers()))
         if self._engine is None or key != self._engine_key:
-            self._engine = HipEngine(self.state_dict(), dev)
+            self._engine = HipEngine(self.state_dict(), dev, precision=self.precision)
             self._engine_key = key
         return self._engine
 

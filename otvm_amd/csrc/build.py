@@ -13,6 +13,7 @@ OBJ = os.path.join(HERE, "build")
 SOURCES = [
     ("error.cpp", []),
     ("conv_igemm.hip", []),
+    ("conv_f16x3.hip", []),
     ("groupnorm.hip", []),
     ("resample.hip", ["-ffp-contract=off"]),
     ("glue.hip", ["-ffp-contract=off"]),

@@ -1,0 +1,269 @@
+// Implicit-GEMM convolution on the 16-bit matrix cores with fp32-class accuracy ("f16x3").
+//
+// gfx950 has no TF32/xf32 MFMA; its exact-fp32 MFMA runs at the fp32 vector rate (157 TFLOP/s), 1/16
+// of the f16/bf16 rate (2.5 PFLOP/s).  This kernel keeps the reference's fp32 contract on the fast
+// pipe by splitting every fp32 operand into two halves, x = hi + lo with hi = fp16(x) and
+// lo = fp16(x - hi) (22 significant bits), and accumulating  hi*hi + hi*lo + lo*hi  in the fp32 MFMA
+// accumulator (v_mfma_f32_32x32x16_f16; fp16 products are exact in fp32).  The dropped lo*lo term is
+// 2^-22 relative: measured error vs fp64 is within ~2x of a plain fp32 dot product.  Three
+// MFMA passes at the f16 rate = 833 TFLOP/s fp32-equivalent peak, 5.3x the fp32-MFMA ceiling.
+//
+//   activations: fp32 NHWC in HBM, split on the fly while staging A tiles into LDS (3 VALU/element);
+//   weights    : split once at load time (otvm_pack_conv_weight_f16x3), each filter scaled by a power
+//                of two so the lo halves stay in the fp16 normal range; the scale is undone in the
+//                epilogue (exact).
+// Tiling as conv_igemm.hip: BM x BN output tile per workgroup, K walked in chunks of 32 through LDS
+// (80-byte padded rows: conflict-free ds_read_b128), NW wave64 each owning TM x TN 32x32 accumulators.
+#include "common.h"
+#include <hip/hip_fp16.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+struct Conv3Args {
+    const float* in; const _Float16* wh; const _Float16* wl; const float* wscale; const float* bias;
+    const float* residual; float* out;
+    int H, W, Cin, in_ld, K_pad, res_ld, Ho, Wo, Cout, out_ld;
+    int kh, kw, stride, pad, dil, in_relu, act;
+    int M, taps, nchunks, tiles_m, tiles_n;
+};
+
+constexpr int BK = 32;
+constexpr int LDH = 40;          // halfs per LDS row (32 + 8 pad) = 80 bytes
+
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
+    // hi: round-toward-zero pack (any rounding works, lo is computed exactly against it)
+    typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+    const fp16x2 p01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y);
+    const fp16x2 p23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+    const f16x2 h01 = __builtin_bit_cast(f16x2, p01);
+    const f16x2 h23 = __builtin_bit_cast(f16x2, p23);
+    hi = f16x4{h01.x, h01.y, h23.x, h23.y};
+    lo = f16x4{(_Float16)(v.x - (float)h01.x), (_Float16)(v.y - (float)h01.y), (_Float16)(v.z - (float)h23.x),
+               (_Float16)(v.w - (float)h23.y)};
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Conv3Args p) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int A_ROWS = NT / 8, A_LD = BM / A_ROWS;        // 8 float4 per 32-wide row
+    constexpr int B_ROWS = NT / 4, B_LD = (BN + B_ROWS - 1) / B_ROWS;   // 4 x 16 bytes per 32-half row
+    static_assert(A_LD >= 1 && B_LD >= 1 && TM >= 1 && TN >= 1, "bad tile");
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * (BM + BN) * LDH];
+    _Float16* Ah = smem;
+    _Float16* Al = Ah + BM * LDH;
+    _Float16* Bh = Al + BM * LDH;
+    _Float16* Bl = Bh + BN * LDH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tile_n = wgid % p.tiles_n, tile_m = wgid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int arow = tid >> 3, ak = (tid & 7) * 4;
+    const int brow = tid >> 2, bk = (tid & 3) * 8;
+    int iy0[A_LD], ix0[A_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        const int m = m0 + arow + A_ROWS * i;
+        if (m < p.M) {
+            const int oy = m / p.Wo, ox = m - oy * p.Wo;
+            iy0[i] = oy * p.stride - p.pad;
+            ix0[i] = ox * p.stride - p.pad;
+        } else {
+            iy0[i] = -(1 << 28);
+            ix0[i] = -(1 << 28);
+        }
+    }
+    const int64_t woff0 = (int64_t)(n0 + brow) * p.K_pad + bk;
+    const int64_t wstep = (int64_t)B_ROWS * p.K_pad;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    f32x4 ra[A_LD];
+    f16x8 rbh[B_LD], rbl[B_LD];
+    auto load_chunk = [&](int c) __attribute__((always_inline)) {
+        const int kk = c * BK + ak;
+        const int tap = kk / p.Cin;
+        const int ci = kk - tap * p.Cin;
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+        const int dy = ky * p.dil, dx = kx * p.dil;
+        const bool tap_ok = tap < p.taps;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
+                v = *reinterpret_cast<const f32x4*>(p.in + ((int64_t)iy * p.W + ix) * p.in_ld + ci);
+                if (p.in_relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            if (BN % B_ROWS == 0 || brow + B_ROWS * i < BN) {
+                rbh[i] = *reinterpret_cast<const f16x8*>(p.wh + woff0 + i * wstep + c * BK);
+                rbl[i] = *reinterpret_cast<const f16x8*>(p.wl + woff0 + i * wstep + c * BK);
+            }
+        }
+    };
+    auto store_chunk = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i) {
+            f16x4 hi, lo;
+            split4(ra[i], hi, lo);
+            *reinterpret_cast<f16x4*>(&Ah[(arow + A_ROWS * i) * LDH + ak]) = hi;
+            *reinterpret_cast<f16x4*>(&Al[(arow + A_ROWS * i) * LDH + ak]) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < B_LD; ++i) {
+            if (BN % B_ROWS == 0 || brow + B_ROWS * i < BN) {
+                *reinterpret_cast<f16x8*>(&Bh[(brow + B_ROWS * i) * LDH + bk]) = rbh[i];
+                *reinterpret_cast<f16x8*>(&Bl[(brow + B_ROWS * i) * LDH + bk]) = rbl[i];
+            }
+        }
+    };
+
+    load_chunk(0);
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+    for (int c = 0; c < p.nchunks; ++c) {
+        __syncthreads();
+        store_chunk();
+        __syncthreads();
+        if (c + 1 < p.nchunks) load_chunk(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int o = ((wm * TM + a) * 32 + frow) * LDH + 16 * ks + fk;
+                ah[a] = *reinterpret_cast<const f16x8*>(&Ah[o]);
+                al[a] = *reinterpret_cast<const f16x8*>(&Al[o]);
+            }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int o = ((wn * TN + b) * 32 + frow) * LDH + 16 * ks + fk;
+                bh[b] = *reinterpret_cast<const f16x8*>(&Bh[o]);
+                bl[b] = *reinterpret_cast<const f16x8*>(&Bl[o]);
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+                }
+        }
+    }
+
+    const int col = lane & 31, rbase = (lane >> 5) * 4;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + (wn * TN + b) * 32 + col;
+        if (n >= p.Cout) continue;
+        const float ws = p.wscale[n];
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = m0 + (wm * TM + a) * 32 + (e & 3) + 8 * (e >> 2) + rbase;
+                if (m < p.M) {
+                    float v = acc[a][b][e] * ws + bias;
+                    if (p.residual) v += p.residual[(int64_t)m * p.res_ld + n];
+                    p.out[(int64_t)m * p.out_ld + n] = otvm_act(v, p.act);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch3(Conv3Args& a, hipStream_t s) {
+    a.tiles_m = otvm_ceil_div(a.M, BM);
+    a.tiles_n = otvm_ceil_div(a.Cout, BN);
+    hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN>), dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64), 0, s, a);
+    OTVM_CHECK_LAUNCH("otvm_conv2d(f16x3)");
+    return 0;
+}
+
+// split a packed fp32 weight row into power-of-two-scaled fp16 hi/lo halves
+__global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ w, int O, int K_pad, _Float16* __restrict__ wh,
+                                                           _Float16* __restrict__ wl, float* __restrict__ wscale) {
+    const int o = blockIdx.x;
+    const float* row = w + (int64_t)o * K_pad;
+    __shared__ float red[256];
+    float mx = 0.f;
+    for (int k = threadIdx.x; k < K_pad; k += 256) mx = fmaxf(mx, fabsf(row[k]));
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    mx = red[0];
+    int e = 0;
+    if (mx > 0.f) frexpf(mx, &e);                 // mx = f * 2^e, f in [0.5, 1)
+    const float sc = ldexpf(1.f, e);              // |w| / sc <= 1
+    const float inv = ldexpf(1.f, -e);
+    if (threadIdx.x == 0 && o < O) wscale[o] = sc;
+    for (int k = threadIdx.x; k < K_pad; k += 256) {
+        const float v = row[k] * inv;             // exact (power of two)
+        const _Float16 hi = (_Float16)v;
+        wh[(int64_t)o * K_pad + k] = hi;
+        wl[(int64_t)o * K_pad + k] = (_Float16)(v - (float)hi);
+    }
+}
+
+}  // namespace
+
+extern "C" int otvm_split_conv_weight_f16x3(const float* w_packed, int O, int O_pad, int K_pad, void* w_hi, void* w_lo,
+                                            float* w_scale, void* stream) {
+    OTVM_REQUIRE(w_packed && w_hi && w_lo && w_scale, "otvm_split_conv_weight_f16x3: null pointer");
+    hipLaunchKernelGGL(split_weight_kernel, dim3(O_pad), dim3(256), 0, (hipStream_t)stream, w_packed, O, K_pad, (_Float16*)w_hi,
+                       (_Float16*)w_lo, w_scale);
+    OTVM_CHECK_LAUNCH("otvm_split_conv_weight_f16x3");
+    return 0;
+}
+
+int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
+    OTVM_REQUIRE(p->w_hi && p->w_lo && p->w_scale, "otvm_conv2d: precision f16x3 needs w_hi / w_lo / w_scale");
+    Conv3Args a;
+    a.in = p->in; a.wh = (const _Float16*)p->w_hi; a.wl = (const _Float16*)p->w_lo; a.wscale = p->w_scale;
+    a.bias = p->bias; a.residual = p->residual; a.out = p->out;
+    a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.in_ld = p->in_ld; a.K_pad = p->K_pad; a.res_ld = p->res_ld;
+    a.Ho = p->Ho; a.Wo = p->Wo; a.Cout = p->Cout; a.out_ld = p->out_ld;
+    a.kh = p->kh; a.kw = p->kw; a.stride = p->stride; a.pad = p->pad; a.dil = p->dil;
+    a.in_relu = p->in_relu; a.act = p->act;
+    a.M = p->Ho * p->Wo; a.taps = p->kh * p->kw; a.nchunks = p->K_pad / 32;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t M = a.M;
+    if (p->Cout <= 32) return launch3<256, 32, 4, 1>(a, s);
+    if (p->Cout <= 64) return (M >= 256 * 128) ? launch3<256, 64, 4, 1>(a, s) : launch3<64, 64, 2, 2>(a, s);
+    const int64_t big = (int64_t)otvm_ceil_div(M, 256) * otvm_ceil_div(p->Cout, 128);
+    if (big >= 512) return launch3<256, 128, 4, 2>(a, s);
+    const int64_t mid = (int64_t)otvm_ceil_div(M, 128) * otvm_ceil_div(p->Cout, 128);
+    if (mid >= 384) return launch3<128, 128, 2, 2>(a, s);
+    const int64_t sm = (int64_t)otvm_ceil_div(M, 128) * otvm_ceil_div(p->Cout, 64);
+    if (sm >= 384) return launch3<128, 64, 2, 2>(a, s);
+    return launch3<64, 64, 2, 2>(a, s);
+}

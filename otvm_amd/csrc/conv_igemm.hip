@@ -247,15 +247,20 @@ extern "C" int otvm_pack_conv_weight(const float* w_oihw, int O, int I, int kh, 
     return 0;
 }
 
+int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream);   // conv_f16x3.hip
+
 extern "C" int otvm_conv2d(const otvm_conv_params* p, void* stream) {
-    OTVM_REQUIRE(p && p->in && p->w && p->out, "otvm_conv2d: null pointer");
+    OTVM_REQUIRE(p && p->in && p->out && (p->w || p->precision == OTVM_PREC_F16X3), "otvm_conv2d: null pointer");
     OTVM_REQUIRE(p->Cin % 4 == 0 && p->in_ld % 4 == 0, "otvm_conv2d: Cin (%d) and in_ld (%d) must be multiples of 4",
                  p->Cin, p->in_ld);
     OTVM_REQUIRE(((uintptr_t)p->in & 15) == 0 && ((uintptr_t)p->w & 15) == 0, "otvm_conv2d: in/w must be 16-byte aligned");
+    OTVM_REQUIRE(p->precision == OTVM_PREC_F32 || p->precision == OTVM_PREC_F16X3, "otvm_conv2d: unknown precision %d",
+                 p->precision);
     OTVM_REQUIRE(p->K_pad % 32 == 0 && p->K_pad >= p->kh * p->kw * p->Cin, "otvm_conv2d: K_pad %d too small", p->K_pad);
     const int Ho = (p->H + 2 * p->pad - p->dil * (p->kh - 1) - 1) / p->stride + 1;
     const int Wo = (p->W + 2 * p->pad - p->dil * (p->kw - 1) - 1) / p->stride + 1;
     OTVM_REQUIRE(Ho == p->Ho && Wo == p->Wo, "otvm_conv2d: output size mismatch (%dx%d expected %dx%d)", p->Ho, p->Wo, Ho, Wo);
+    if (p->precision == OTVM_PREC_F16X3) return otvm_conv2d_f16x3_impl(p, stream);
     ConvArgs a;
     a.in = p->in; a.w = p->w; a.bias = p->bias; a.residual = p->residual; a.out = p->out;
     a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.in_ld = p->in_ld; a.K_pad = p->K_pad; a.res_ld = p->res_ld;

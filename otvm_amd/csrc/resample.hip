@@ -66,24 +66,35 @@ __global__ void upsample_bilinear_kernel(const float* __restrict__ in, int Hi, i
 }
 
 // AdaptiveAvgPool2d(s), s in {1,2,3,6}: bin i covers [floor(i*N/s), ceil((i+1)*N/s)).
-// grid = (50 bins, C/256 channel slabs); 256 threads = 64 float4 columns x 4 pixel lanes.
-__global__ __launch_bounds__(256) void ppm_pool_kernel(const float* __restrict__ in, int H, int W, int C, int ld,
-                                                       float* __restrict__ out) {
-    int bin = blockIdx.x, s, base;
+// Two deterministic stages: grid = (50 bins, C/256 channel slabs, PPM_CHUNKS row chunks) partial sums,
+// then a fixed-order reduction of the chunks.  256 threads = 64 float4 columns x 4 pixel lanes.
+constexpr int PPM_CHUNKS = 16;
+
+__device__ __forceinline__ void ppm_bin(int bin, int H, int W, int& y0, int& y1, int& x0, int& x1) {
+    int s, base;
     if (bin < 1) { s = 1; base = 0; }
     else if (bin < 5) { s = 2; base = 1; }
     else if (bin < 14) { s = 3; base = 5; }
     else { s = 6; base = 14; }
     const int b = bin - base, by = b / s, bx = b - by * s;
-    const int y0 = (by * H) / s, y1 = ((by + 1) * H + s - 1) / s;
-    const int x0 = (bx * W) / s, x1 = ((bx + 1) * W + s - 1) / s;
+    y0 = (by * H) / s; y1 = ((by + 1) * H + s - 1) / s;
+    x0 = (bx * W) / s; x1 = ((bx + 1) * W + s - 1) / s;
+}
+
+__global__ __launch_bounds__(256) void ppm_pool_partial_kernel(const float* __restrict__ in, int H, int W, int C, int ld,
+                                                               float* __restrict__ part) {
+    const int bin = blockIdx.x, chunk = blockIdx.z;
+    int y0, y1, x0, x1;
+    ppm_bin(bin, H, W, y0, y1, x0, x1);
+    const int rows = y1 - y0, rpc = (rows + PPM_CHUNKS - 1) / PPM_CHUNKS;
+    const int ya = y0 + chunk * rpc, yb = min(y1, ya + rpc);
     const int q = threadIdx.x & 63, lanep = threadIdx.x >> 6;
     const int c = blockIdx.y * 256 + q * 4;
-    const int rw = x1 - x0, n = (y1 - y0) * rw;
+    const int rw = x1 - x0, n = (yb > ya ? (yb - ya) * rw : 0);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
         for (int i = lanep; i < n; i += 4) {
-            const int yy = y0 + i / rw, xx = x0 + i % rw;
+            const int yy = ya + i / rw, xx = x0 + i % rw;
             acc += *reinterpret_cast<const f32x4*>(in + ((int64_t)yy * W + xx) * ld + c);
         }
     }
@@ -91,8 +102,20 @@ __global__ __launch_bounds__(256) void ppm_pool_kernel(const float* __restrict__
     red[threadIdx.x] = acc;
     __syncthreads();
     if (lanep == 0 && c < C) {
-        f32x4 t = red[q] + red[q + 64] + red[q + 128] + red[q + 192];
-        const float inv = 1.f / (float)n;
+        const f32x4 t = (red[q] + red[q + 64]) + (red[q + 128] + red[q + 192]);
+        *reinterpret_cast<f32x4*>(part + ((int64_t)bin * PPM_CHUNKS + chunk) * C + c) = t;
+    }
+}
+
+__global__ void ppm_pool_final_kernel(const float* __restrict__ part, int H, int W, int C, float* __restrict__ out) {
+    const int bin = blockIdx.x;
+    int y0, y1, x0, x1;
+    ppm_bin(bin, H, W, y0, y1, x0, x1);
+    const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
+    for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {
+        f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < PPM_CHUNKS; ++k) t += *reinterpret_cast<const f32x4*>(part + ((int64_t)bin * PPM_CHUNKS + k) * C + c);
         *reinterpret_cast<f32x4*>(out + (int64_t)bin * C + c) = t * inv;
     }
 }
@@ -124,10 +147,13 @@ extern "C" int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, in
     return 0;
 }
 
-extern "C" int otvm_ppm_pool(const float* in, int H, int W, int C, int ld, float* out, void* stream) {
-    OTVM_REQUIRE(C % 4 == 0 && ld % 4 == 0, "otvm_ppm_pool: channels must be multiples of 4");
-    hipLaunchKernelGGL(ppm_pool_kernel, dim3(50, otvm_ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, in, H, W, C, ld,
-                       out);
+extern "C" int64_t otvm_ppm_pool_ws_bytes(int C) { return (int64_t)50 * PPM_CHUNKS * C * sizeof(float); }
+
+extern "C" int otvm_ppm_pool(const float* in, int H, int W, int C, int ld, float* out, void* ws, void* stream) {
+    OTVM_REQUIRE(C % 4 == 0 && ld % 4 == 0 && ws, "otvm_ppm_pool: channels must be multiples of 4, ws required");
+    hipLaunchKernelGGL(ppm_pool_partial_kernel, dim3(50, otvm_ceil_div(C, 256), PPM_CHUNKS), dim3(256), 0,
+                       (hipStream_t)stream, in, H, W, C, ld, (float*)ws);
+    hipLaunchKernelGGL(ppm_pool_final_kernel, dim3(50), dim3(256), 0, (hipStream_t)stream, (const float*)ws, H, W, C, out);
     OTVM_CHECK_LAUNCH("otvm_ppm_pool");
     return 0;
 }

@@ -52,7 +52,7 @@ class Act:
 
 
 class ConvW:
-    __slots__ = ("w", "K_pad", "O", "I", "I_pad", "kh", "kw", "bias")
+    __slots__ = ("w", "K_pad", "O", "I", "I_pad", "kh", "kw", "bias", "w_hi", "w_lo", "w_scale")
 
 
 def pad_amounts(h, w, d):
@@ -83,9 +83,59 @@ def bank_update(bank, new, first_frame, memorize, max_memory_num):
     return nb, released
 
 
+PRECISIONS = {"f32": L.PREC_F32, "f16x3": L.PREC_F16X3}
+
+
+def default_precision():
+    """f16x3 (split-fp16 MFMA, fp32-class accuracy) unless OTVM_PRECISION=f32 asks for the exact-fp32 MFMA."""
+    import os
+    return os.environ.get("OTVM_PRECISION", "f16x3")
+
+
+def pack_conv_weight(lib, dev, w, ws=False, scale=None, i_pad=None, split=True, stream=0):
+    """OIHW fp32 weight -> ConvW (packed fp32 + optional f16x3 split) on ``dev``."""
+    O, I, kh, kw = w.shape
+    cw = ConvW()
+    cw.O, cw.I, cw.kh, cw.kw = O, I, kh, kw
+    cw.I_pad = _rup(I, 4) if i_pad is None else i_pad
+    cw.K_pad = _rup(kh * kw * cw.I_pad, 32)
+    O_pad = _rup(O, 128)
+    cw.w = torch.empty(O_pad * cw.K_pad, dtype=torch.float32, device=dev)
+    cw.bias = None
+    w = w.contiguous()
+    L.check(lib.otvm_pack_conv_weight(w.data_ptr(), O, I, kh, kw, 1 if ws else 0,
+                                      0 if scale is None else scale.data_ptr(), cw.w.data_ptr(), O_pad,
+                                      cw.I_pad, cw.K_pad, stream), "pack_conv_weight")
+    cw.w_hi = cw.w_lo = cw.w_scale = None
+    if split:
+        cw.w_hi = torch.empty(O_pad * cw.K_pad, dtype=torch.float16, device=dev)
+        cw.w_lo = torch.empty(O_pad * cw.K_pad, dtype=torch.float16, device=dev)
+        cw.w_scale = torch.empty(O, dtype=torch.float32, device=dev)
+        L.check(lib.otvm_split_conv_weight_f16x3(cw.w.data_ptr(), O, O_pad, cw.K_pad, cw.w_hi.data_ptr(),
+                                                 cw.w_lo.data_ptr(), cw.w_scale.data_ptr(), stream), "split_conv_weight")
+    return cw
+
+
+def conv_params(x, cw, out, bias=None, stride=1, pad=0, dil=1, act=NONE, in_relu=0, residual=None, precision=L.PREC_F32):
+    Ho = (x.H + 2 * pad - dil * (cw.kh - 1) - 1) // stride + 1
+    Wo = (x.W + 2 * pad - dil * (cw.kw - 1) - 1) // stride + 1
+    if precision == L.PREC_F16X3 and cw.w_hi is None:
+        raise RuntimeError("otvm_amd: f16x3 convolution requested but the weight was packed without a split")
+    return L.ConvParams(x.ptr, x.H, x.W, x.C, x.ld, cw.w.data_ptr(), cw.K_pad,
+                        0 if bias is None else bias.data_ptr(),
+                        0 if residual is None else residual.ptr, 0 if residual is None else residual.ld,
+                        out.ptr, Ho, Wo, cw.O, out.ld, cw.kh, cw.kw, stride, pad, dil, in_relu, act, precision,
+                        0 if cw.w_hi is None else cw.w_hi.data_ptr(), 0 if cw.w_lo is None else cw.w_lo.data_ptr(),
+                        0 if cw.w_scale is None else cw.w_scale.data_ptr())
+
+
 class HipEngine:
-    def __init__(self, state_dict, device):
+    def __init__(self, state_dict, device, precision=None):
         self.lib = L.load()
+        self.precision_name = precision or default_precision()
+        if self.precision_name not in PRECISIONS:
+            raise ValueError("otvm_amd: unknown precision %r (choose from %s)" % (self.precision_name, sorted(PRECISIONS)))
+        self.precision = PRECISIONS[self.precision_name]
         self.dev = torch.device(device)
         if self.dev.type != "cuda":
             raise RuntimeError("otvm_amd: the HIP path needs a GPU device (got %s); there is no CPU fallback" % device)
@@ -105,18 +155,9 @@ class HipEngine:
         return torch.cuda.current_stream(self.dev).cuda_stream
 
     def _pack(self, name, w, ws=False, scale=None, bias=None, i_pad=None):
-        O, I, kh, kw = w.shape
-        cw = ConvW()
-        cw.O, cw.I, cw.kh, cw.kw = O, I, kh, kw
-        cw.I_pad = _rup(I, 4) if i_pad is None else i_pad
-        cw.K_pad = _rup(kh * kw * cw.I_pad, 32)
-        O_pad = _rup(O, 128)
-        cw.w = torch.empty(O_pad * cw.K_pad, dtype=torch.float32, device=self.dev)
+        cw = pack_conv_weight(self.lib, self.dev, w, ws, scale, i_pad, split=(self.precision == L.PREC_F16X3),
+                              stream=self._stream())
         cw.bias = bias
-        w = w.contiguous()
-        L.check(self.lib.otvm_pack_conv_weight(w.data_ptr(), O, I, kh, kw, 1 if ws else 0,
-                                               0 if scale is None else scale.data_ptr(), cw.w.data_ptr(), O_pad,
-                                               cw.I_pad, cw.K_pad, self._stream()), "pack " + name)
         self._keep.append((w, scale))
         self.W[name] = cw
 
@@ -292,10 +333,7 @@ class FramePlan:
         Ho = (x.H + 2 * pad - dil * (w.kh - 1) - 1) // stride + 1
         Wo = (x.W + 2 * pad - dil * (w.kw - 1) - 1) // stride + 1
         assert (out.H, out.W) == (Ho, Wo) and out.C >= w.O, (wname, out.H, out.W, Ho, Wo, out.C, w.O)
-        p = L.ConvParams(x.ptr, x.H, x.W, x.C, x.ld, w.w.data_ptr(), w.K_pad,
-                         0 if w.bias is None else w.bias.data_ptr(),
-                         0 if residual is None else residual.ptr, 0 if residual is None else residual.ld,
-                         out.ptr, Ho, Wo, w.O, out.ld, w.kh, w.kw, stride, pad, dil, in_relu, act)
+        p = conv_params(x, w, out, w.bias, stride, pad, dil, act, in_relu, residual, self.e.precision)
         self._keep.append(p)
         flops = 2 * Ho * Wo * w.O * w.kh * w.kw * w.I           # algorithmic (un-padded) 2*MAC
         S.append((self.lib.otvm_conv2d, (C.byref(p),), "conv " + wname, flops))
@@ -465,7 +503,9 @@ class FramePlan:
         de = "NET.decoder."
         conv5 = self.PPMCAT.ch(0, 2048)
         self.POOL = self.raw("ppm_pool", 50 * 2048)
-        S.append((lib.otvm_ppm_pool, (conv5.ptr, H8, W8, 2048, conv5.ld, self.POOL.data_ptr()), "ppm_pool"))
+        self.POOL_WS = self.raw("ppm_ws", int(lib.otvm_ppm_pool_ws_bytes(2048)) // 4)
+        S.append((lib.otvm_ppm_pool, (conv5.ptr, H8, W8, 2048, conv5.ld, self.POOL.data_ptr(), self.POOL_WS.data_ptr()),
+                  "ppm_pool"))
         base = 0
         for i, s in enumerate((1, 2, 3, 6)):
             pin = Act(self.POOL, s, s, 2048, 2048, base * 2048)

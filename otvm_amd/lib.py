@@ -10,6 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libotvm_hip.so")
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+PREC_F32, PREC_F16X3 = 0, 1
 
 
 class ConvParams(C.Structure):
@@ -19,7 +20,8 @@ class ConvParams(C.Structure):
                 ("residual", vp), ("res_ld", i32),
                 ("out", vp), ("Ho", i32), ("Wo", i32), ("Cout", i32), ("out_ld", i32),
                 ("kh", i32), ("kw", i32), ("stride", i32), ("pad", i32), ("dil", i32),
-                ("in_relu", i32), ("act", i32)]
+                ("in_relu", i32), ("act", i32),
+                ("precision", i32), ("w_hi", vp), ("w_lo", vp), ("w_scale", vp)]
 
 
 class PreprocessParams(C.Structure):
@@ -37,11 +39,13 @@ _PROTOS = {
     "otvm_fold_bn": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp]),
     "otvm_pack_conv_weight": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp]),
     "otvm_conv2d": (i32, [C.POINTER(ConvParams), vp]),
+    "otvm_split_conv_weight_f16x3": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
     "otvm_gn_stats": (i32, [vp, i64, i32, i32, vp, vp]),
     "otvm_gn_apply": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i32, i32, vp, i32, vp]),
     "otvm_maxpool3x3s2": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
     "otvm_upsample_bilinear": (i32, [vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, i32, vp]),
-    "otvm_ppm_pool": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+    "otvm_ppm_pool_ws_bytes": (i64, [i32]),
+    "otvm_ppm_pool": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "otvm_memory_read_ws_bytes": (i64, [i32, i32]),
     "otvm_memory_read": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp), i32, i32, vp, i32, vp, vp]),
     "otvm_preprocess": (i32, [C.POINTER(PreprocessParams), vp]),

@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from otvm_amd import lib as L
-from otvm_amd.engine import Act, ConvW, _rup
+from otvm_amd.engine import Act, ConvW, _rup, pack_conv_weight, conv_params
 
 DEV = "cuda:0"
 
@@ -39,31 +39,15 @@ def from_act(a, Cc=None):
 
 
 def pack_weight(w, ws=False, scale=None, i_pad=None):
-    lib = L.load()
-    O, I, kh, kw = w.shape
-    cw = ConvW()
-    cw.O, cw.kh, cw.kw = O, kh, kw
-    cw.I_pad = _rup(I, 4) if i_pad is None else i_pad
-    cw.K_pad = _rup(kh * kw * cw.I_pad, 32)
-    O_pad = _rup(O, 128)
-    cw.w = torch.empty(O_pad * cw.K_pad, dtype=torch.float32, device=DEV)
-    cw.bias = None
-    wd = w.contiguous().to(DEV)
-    sc = None if scale is None else scale.contiguous().to(DEV)
-    L.check(lib.otvm_pack_conv_weight(wd.data_ptr(), O, I, kh, kw, 1 if ws else 0, 0 if sc is None else sc.data_ptr(),
-                                      cw.w.data_ptr(), O_pad, cw.I_pad, cw.K_pad, stream()), "pack")
+    cw = pack_conv_weight(L.load(), DEV, w.contiguous().to(DEV), ws, None if scale is None else scale.contiguous().to(DEV),
+                          i_pad, split=True, stream=stream())
     torch.cuda.synchronize()
     return cw
 
 
-def conv2d(x, cw, out, bias=None, stride=1, pad=0, dil=1, act=0, in_relu=0, residual=None):
-    lib = L.load()
-    Ho = (x.H + 2 * pad - dil * (cw.kh - 1) - 1) // stride + 1
-    Wo = (x.W + 2 * pad - dil * (cw.kw - 1) - 1) // stride + 1
-    p = L.ConvParams(x.ptr, x.H, x.W, x.C, x.ld, cw.w.data_ptr(), cw.K_pad, 0 if bias is None else bias.data_ptr(),
-                     0 if residual is None else residual.ptr, 0 if residual is None else residual.ld,
-                     out.ptr, Ho, Wo, cw.O, out.ld, cw.kh, cw.kw, stride, pad, dil, in_relu, act)
-    L.check(lib.otvm_conv2d(C.byref(p), stream()), "conv2d")
+def conv2d(x, cw, out, bias=None, stride=1, pad=0, dil=1, act=0, in_relu=0, residual=None, precision=0):
+    p = conv_params(x, cw, out, bias, stride, pad, dil, act, in_relu, residual, precision)
+    L.check(L.load().otvm_conv2d(C.byref(p), stream()), "conv2d")
     torch.cuda.synchronize()
 
 

@@ -29,12 +29,13 @@ def model(synth_sd):
     cfg = helpers.default_cfg()
     cache = {}
 
-    def make(dk):
-        if dk not in cache:
+    def make(dk, precision="f16x3"):
+        if (dk, precision) not in cache:
             m = helpers.get_model_alpha(cfg, helpers.get_model_trimap(cfg, "Test", dk), "Test", dk)
             m.load_state_dict(synth_sd, strict=True)
-            cache[dk] = torch.nn.DataParallel(m.cuda()).eval()        # exactly as eval.py:77-80
-        return cache[dk]
+            m.precision = precision
+            cache[(dk, precision)] = torch.nn.DataParallel(m.cuda()).eval()        # exactly as eval.py:77-80
+        return cache[(dk, precision)]
     return make
 
 
@@ -67,9 +68,9 @@ def stage_report(pl, cap, first_frame):
     return rep
 
 
-def run_sequence(model, synth_sd, meta, max_frames=None):
+def run_sequence(model, synth_sd, meta, max_frames=None, precision="f16x3"):
     from oracle.otvm_oracle import OtvmOracle
-    m = model(meta["dilate_kernel"])
+    m = model(meta["dilate_kernel"], precision)
     eng_model = m.module
     orc = OtvmOracle(synth_sd, dilate_kernel=meta["dilate_kernel"])
     results = []
@@ -106,11 +107,15 @@ def fmt(rep):
     return " ".join("%s=%.1e/%.1e" % (k, v[0], v[1]) for k, v in rep.items())
 
 
-@pytest.mark.parametrize("name", sorted(META.keys()))
-def test_sequence_vs_oracle_and_golden(name, model, synth_sd):
+CASES = [(n, "f16x3") for n in sorted(META.keys())] + [(n, "f32") for n in ("demo_100x150_s5m5", "v108_64x96_s3m3",
+                                                                             "demo_70x90_single")]
+
+
+@pytest.mark.parametrize("name,precision", CASES, ids=["%s-%s" % c for c in CASES])
+def test_sequence_vs_oracle_and_golden(name, precision, model, synth_sd):
     meta = META[name]
     gold = load_golden(name)
-    res = run_sequence(model, synth_sd, meta)
+    res = run_sequence(model, synth_sd, meta, precision=precision)
     total_ties = 0
     for r in res:
         t = r["t"]

@@ -49,8 +49,9 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f16x3"])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "c%d_%d_k%d_s%d_d%d_%dx%d" % (c[0], c[1], c[2], c[3], c[5], c[6], c[7]))
-def test_conv2d(G, case):
+def test_conv2d(G, case, prec):
     Cin, Cout, k, stride, pad, dil, H, W, use_bias, act, in_relu, use_res = case
     x = rnd(1, Cin, H, W, seed=1)
     w = rnd(Cout, Cin, k, k, seed=2, scale=1.0 / math.sqrt(Cin * k * k))
@@ -66,10 +67,30 @@ def test_conv2d(G, case):
     assert xa.C == cw.I_pad
     out = G.empty_act(ref.shape[2], ref.shape[3], max(4, (Cout + 3) // 4 * 4), ld=Cout + 8 - Cout % 4, off=4)
     ra = G.to_act(res) if use_res else None
-    G.conv2d(xa, cw, out, None if b is None else b.to(G.DEV), stride, pad, dil, act, in_relu, ra)
+    G.conv2d(xa, cw, out, None if b is None else b.to(G.DEV), stride, pad, dil, act, in_relu, ra, precision=prec)
     got = G.from_act(out, Cout)
     assert torch.isfinite(got).all()
+    # same bound for the exact-fp32 MFMA and the split-fp16 (f16x3) path: both are fp32-class
     assert G.maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_f16x3_is_fp32_class(G):
+    """Error of the split-fp16 path vs an fp64 reference, next to the exact-fp32 MFMA path, on operands
+    spanning 1e-3 .. 30 (the dropped lo*lo term is 2^-22 relative)."""
+    x = rnd(1, 256, 24, 32, seed=60)
+    x[:, ::7] *= 1e-3
+    x[:, ::11] *= 30
+    w = rnd(128, 256, 3, 3, seed=61, scale=0.02)
+    w[::5] *= 1e-2
+    ref = F.conv2d(x.double(), w.double(), None, 1, 1)
+    cw = G.pack_weight(w)
+    errs = []
+    for prec in (0, 1):
+        out = G.empty_act(24, 32, 128)
+        G.conv2d(G.to_act(x), cw, out, pad=1, precision=prec)
+        errs.append(float((G.from_act(out).double() - ref).abs().max() / ref.abs().max()))
+    print("relative error vs fp64: fp32-MFMA %.2e, f16x3 %.2e" % tuple(errs))
+    assert errs[0] < 2e-6 and errs[1] < 5e-6
 
 
 def test_weight_standardisation_and_bn_fold(G):
@@ -79,9 +100,10 @@ def test_weight_standardisation_and_bn_fold(G):
     x = rnd(1, 24, 20, 28, seed=6)
     cw = G.pack_weight(w, ws=True)
     out = G.empty_act(20, 28, 64)
-    G.conv2d(G.to_act(x), cw, out, pad=1)
     ref = F.conv2d(x, standardise_weight(w), None, 1, 1)
-    assert G.maxdiff(G.from_act(out), ref) <= 3e-5 * float(ref.abs().max())
+    for prec in (0, 1):
+        G.conv2d(G.to_act(x), cw, out, pad=1, precision=prec)
+        assert G.maxdiff(G.from_act(out), ref) <= 3e-5 * float(ref.abs().max())
     # BatchNorm(eval) folded into the conv (scale into weights, shift into bias)
     g_, b_, m_, v_ = rnd(64, seed=7).abs() + 0.5, rnd(64, seed=8), rnd(64, seed=9), rnd(64, seed=10).abs() + 0.5
     dv = [t.to(G.DEV) for t in (g_, b_, m_, v_)]
@@ -90,9 +112,10 @@ def test_weight_standardisation_and_bn_fold(G):
     L.check(L.load().otvm_fold_bn(dv[0].data_ptr(), dv[1].data_ptr(), dv[2].data_ptr(), dv[3].data_ptr(), 1e-5, 64,
                                   scale.data_ptr(), bias.data_ptr(), G.stream()))
     cw = G.pack_weight(w, scale=scale.cpu())
-    G.conv2d(G.to_act(x), cw, out, bias, pad=1, act=1)
     ref = F.relu(F.batch_norm(F.conv2d(x, w, None, 1, 1), m_, v_, g_, b_, False, 0.0, 1e-5))
-    assert G.maxdiff(G.from_act(out), ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    for prec in (0, 1):
+        G.conv2d(G.to_act(x), cw, out, bias, pad=1, act=1, precision=prec)
+        assert G.maxdiff(G.from_act(out), ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
 @pytest.mark.parametrize("Cc,H,W,act,use_res", [(64, 33, 47, 1, False), (128, 16, 20, 2, False), (256, 9, 11, 1, True),
@@ -149,7 +172,8 @@ def test_maxpool_upsample_ppm(G):
     z = rnd(1, 512, 17, 30, seed=30)
     za = G.to_act(z)
     pool = torch.empty(50 * 512, device=G.DEV)
-    L.check(lib.otvm_ppm_pool(za.ptr, 17, 30, 512, za.ld, pool.data_ptr(), G.stream()))
+    pws = torch.empty(int(lib.otvm_ppm_pool_ws_bytes(512)), dtype=torch.uint8, device=G.DEV)
+    L.check(lib.otvm_ppm_pool(za.ptr, 17, 30, 512, za.ld, pool.data_ptr(), pws.data_ptr(), G.stream()))
     torch.cuda.synchronize()
     base = 0
     for s in (1, 2, 3, 6):
