@@ -72,9 +72,11 @@ typedef struct {
 int otvm_conv2d(const otvm_conv_params* p, void* stream);
 
 /* f16x3: derive the split weights from a packed fp32 weight (see otvm_pack_conv_weight):
- * row o is scaled by 2^-e (|w| <= 1), w_hi = fp16(w), w_lo = fp16(w - w_hi), w_scale[o] = 2^e.   */
-int otvm_split_conv_weight_f16x3(const float* w_packed, int O, int O_pad, int K_pad, void* w_hi, void* w_lo,
-                                 float* w_scale, void* stream);
+ * row o is scaled by 2^-e (|w| <= 1), w_hi = fp16(w), w_lo = fp16(w - w_hi), w_scale[o] = 2^e.
+ * When I_pad % 32 == 0 (and taps <= 32) K is re-ordered channel-block major ([c/32][tap][c%32]) so
+ * that the taps of one channel block are consecutive K chunks (input re-reads hit L1/L2).        */
+int otvm_split_conv_weight_f16x3(const float* w_packed, int O, int O_pad, int K_pad, int taps, int I_pad,
+                                 void* w_hi, void* w_lo, float* w_scale, void* stream);
 
 /* ---------------------------------------------------------------- GroupNorm(32) ----------------
  * nn.GroupNorm(32, C, eps=1e-5, affine) (layers_WS.py:26-27, FBA/models.py:272-276), two passes:

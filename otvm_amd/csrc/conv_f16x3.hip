@@ -17,6 +17,10 @@
 #include "common.h"
 #include <hip/hip_fp16.h>
 
+#ifndef OTVM_BRANCHY_LOADS
+#define OTVM_BRANCHY_LOADS 1
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -36,6 +40,8 @@ struct Conv3Args {
 constexpr int BK = 32;
 constexpr int LDH = 40;          // halfs per LDS row (32 + 8 pad) = 80 bytes
 
+inline bool f16x3_fast_layout(int taps, int I_pad) { return I_pad % 32 == 0 && taps <= 32; }
+
 __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
     // hi: round-toward-zero pack (any rounding works, lo is computed exactly against it)
     typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
@@ -48,18 +54,20 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
                (_Float16)(v.w - (float)h23.y)};
 }
 
-template <int BM, int BN, int WM, int WN>
+// FAST: Cin % 32 == 0 and <= 32 taps -> a K chunk never straddles a tap, so the tap walk is wave-uniform
+// (scalar registers) and the per-row work per chunk shrinks to one add and one mask test.
+template <int BM, int BN, int WM, int WN, bool FAST, bool RELU_IN>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Conv3Args p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_ROWS = NT / 8, A_LD = BM / A_ROWS;        // 8 float4 per 32-wide row
     constexpr int B_ROWS = NT / 4, B_LD = (BN + B_ROWS - 1) / B_ROWS;   // 4 x 16 bytes per 32-half row
     static_assert(A_LD >= 1 && B_LD >= 1 && TM >= 1 && TN >= 1, "bad tile");
-    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * (BM + BN) * LDH];
-    _Float16* Ah = smem;
-    _Float16* Al = Ah + BM * LDH;
-    _Float16* Bh = Al + BM * LDH;
-    _Float16* Bl = Bh + BN * LDH;
+    constexpr int STAGE = 2 * (BM + BN) * LDH;                 // halfs per LDS stage (A_hi, A_lo, B_hi, B_lo)
+    // Two LDS stages + one barrier per chunk measured no faster than one stage + two barriers on the big tiles
+    // (295 vs 297 TFLOP/s at 256x256) and slower on the small ones (occupancy); kept selectable for experiments.
+    constexpr bool DBUF = false;
+    __shared__ __attribute__((aligned(16))) _Float16 smem[(DBUF ? 2 : 1) * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -73,6 +81,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     const int arow = tid >> 3, ak = (tid & 7) * 4;
     const int brow = tid >> 2, bk = (tid & 3) * 8;
     int iy0[A_LD], ix0[A_LD];
+    int rowoff[A_LD];            // FAST: element offset of (iy0, ix0, ak) from p.in
+    unsigned tapmask[A_LD];      // FAST: bit t set <=> tap t reads inside the image for this row
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
         const int m = m0 + arow + A_ROWS * i;
@@ -84,7 +94,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
             iy0[i] = -(1 << 28);
             ix0[i] = -(1 << 28);
         }
+        if (FAST) {
+            rowoff[i] = (iy0[i] * p.W + ix0[i]) * p.in_ld + ak;
+            unsigned mk = 0;
+            for (int t = 0; t < p.taps; ++t) {
+                const int ky = t / p.kw, kx = t - ky * p.kw;
+                const int iy = iy0[i] + ky * p.dil, ix = ix0[i] + kx * p.dil;
+                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mk |= 1u << t;
+            }
+            tapmask[i] = mk;
+        }
     }
+    // wave-uniform tap walk (FAST)
+    int u_cb = 0, u_tap = 0, u_ky = 0, u_kx = 0;
     const int64_t woff0 = (int64_t)(n0 + brow) * p.K_pad + bk;
     const int64_t wstep = (int64_t)B_ROWS * p.K_pad;
 
@@ -97,25 +119,46 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
     f32x4 ra[A_LD];
+    unsigned okmask = 0;            // bit i: ra[i] holds image data (else padding -> zero)
     f16x8 rbh[B_LD], rbl[B_LD];
     auto load_chunk = [&](int c) __attribute__((always_inline)) {
-        const int kk = c * BK + ak;
-        const int tap = kk / p.Cin;
-        const int ci = kk - tap * p.Cin;
-        const int ky = tap / p.kw, kx = tap - ky * p.kw;
-        const int dy = ky * p.dil, dx = kx * p.dil;
-        const bool tap_ok = tap < p.taps;
+        if (FAST) {
+            const int delta = (u_ky * p.dil * p.W + u_kx * p.dil) * p.in_ld + (u_cb << 5);   // scalar
+            const unsigned bit = 1u << u_tap;
 #pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            const int iy = iy0[i] + dy, ix = ix0[i] + dx;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-                v = *reinterpret_cast<const f32x4*>(p.in + ((int64_t)iy * p.W + ix) * p.in_ld + ci);
-                if (p.in_relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
+            for (int i = 0; i < A_LD; ++i) {
+                // UNCONDITIONAL load (padding lanes read element 0 and are zeroed afterwards): a branch around
+                // the load would hide the number of outstanding loads from the compiler, which then drains
+                // vmcnt(0) in the middle of the pipeline (guide 5, trap (c)).
+                // The zeroing (and the optional ReLU) happen in store_chunk, NOT here: touching the loaded value
+                // now would put the s_waitcnt in front of the MFMAs and serialise load latency with compute.
+                const bool ok = (tapmask[i] & bit) != 0;
+#if OTVM_BRANCHY_LOADS
+                if (ok) ra[i] = *reinterpret_cast<const f32x4*>(p.in + (int64_t)(rowoff[i] + delta));
+#else
+                ra[i] = *reinterpret_cast<const f32x4*>(p.in + (int64_t)(ok ? rowoff[i] + delta : 0));
+#endif
+                okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));
             }
-            ra[i] = v;
+            // K order of the split weights in the fast path: channel-block major, taps inner, so the taps of one
+            // 32-channel block re-read the same (shifted) pixels back to back -> L1/L2 hits instead of MALL/HBM
+            ++u_tap;
+            if (++u_kx == p.kw) { u_kx = 0; ++u_ky; }
+            if (u_tap == p.taps) { u_tap = 0; u_kx = 0; u_ky = 0; ++u_cb; }
+        } else {
+            const int kk = c * BK + ak;
+            const int tap = kk / p.Cin;
+            const int ci = kk - tap * p.Cin;
+            const int ky = tap / p.kw, kx = tap - ky * p.kw;
+            const int dy = ky * p.dil, dx = kx * p.dil;
+            const bool tap_ok = tap < p.taps;
+#pragma unroll
+            for (int i = 0; i < A_LD; ++i) {
+                const int iy = iy0[i] + dy, ix = ix0[i] + dx;
+                const bool ok = tap_ok && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                ra[i] = *reinterpret_cast<const f32x4*>(p.in + (ok ? ((int64_t)iy * p.W + ix) * p.in_ld + ci : 0));
+                okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));
+            }
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
@@ -125,11 +168,21 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
             }
         }
     };
-    auto store_chunk = [&]() __attribute__((always_inline)) {
+    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
+        _Float16* Ah = smem + buf * STAGE;
+        _Float16* Al = Ah + BM * LDH;
+        _Float16* Bh = Al + BM * LDH;
+        _Float16* Bl = Bh + BN * LDH;
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             f16x4 hi, lo;
-            split4(ra[i], hi, lo);
+            f32x4 v = ra[i];
+            if (RELU_IN) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            v = (okmask >> i) & 1u ? v : z;
+            split4(v, hi, lo);
             *reinterpret_cast<f16x4*>(&Ah[(arow + A_ROWS * i) * LDH + ak]) = hi;
             *reinterpret_cast<f16x4*>(&Al[(arow + A_ROWS * i) * LDH + ak]) = lo;
         }
@@ -141,37 +194,67 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
             }
         }
     };
+    auto compute_ks = [&](int buf, int ks) __attribute__((always_inline)) {
+        const _Float16* Ah = smem + buf * STAGE;
+        const _Float16* Al = Ah + BM * LDH;
+        const _Float16* Bh = Al + BM * LDH;
+        const _Float16* Bl = Bh + BN * LDH;
+        const int frow = lane & 31, fk = (lane >> 5) * 8;
+        f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int o = ((wm * TM + a) * 32 + frow) * LDH + 16 * ks + fk;
+            ah[a] = *reinterpret_cast<const f16x8*>(&Ah[o]);
+            al[a] = *reinterpret_cast<const f16x8*>(&Al[o]);
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int o = ((wn * TN + b) * 32 + frow) * LDH + 16 * ks + fk;
+            bh[b] = *reinterpret_cast<const f16x8*>(&Bh[o]);
+            bl[b] = *reinterpret_cast<const f16x8*>(&Bl[o]);
+        }
+        // three passes over the accumulator tiles, so consecutive MFMAs never share an accumulator
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+    };
 
     load_chunk(0);
-    const int frow = lane & 31, fk = (lane >> 5) * 8;
-    for (int c = 0; c < p.nchunks; ++c) {
+    if (DBUF) {
+        // one barrier per chunk: while the MFMAs of chunk c run out of stage c&1, the same wave converts chunk
+        // c+1 into the other stage (VALU/LDS work issues in the shadow of the 32-cycle MFMAs) and then launches
+        // the global loads of chunk c+2, which have a whole chunk of MFMA time to land.
+        store_chunk(0);
+        if (p.nchunks > 1) load_chunk(1);
         __syncthreads();
-        store_chunk();
-        __syncthreads();
-        if (c + 1 < p.nchunks) load_chunk(c + 1);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            f16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                const int o = ((wm * TM + a) * 32 + frow) * LDH + 16 * ks + fk;
-                ah[a] = *reinterpret_cast<const f16x8*>(&Ah[o]);
-                al[a] = *reinterpret_cast<const f16x8*>(&Al[o]);
-            }
-#pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                const int o = ((wn * TN + b) * 32 + frow) * LDH + 16 * ks + fk;
-                bh[b] = *reinterpret_cast<const f16x8*>(&Bh[o]);
-                bl[b] = *reinterpret_cast<const f16x8*>(&Bl[o]);
-            }
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-                }
+        for (int c = 0; c < p.nchunks; ++c) {
+            const int buf = c & 1;
+            compute_ks(buf, 0);
+            if (c + 1 < p.nchunks) store_chunk(buf ^ 1);
+            if (c + 2 < p.nchunks) load_chunk(c + 2);
+            compute_ks(buf, 1);
+            __syncthreads();
+        }
+    } else {
+        for (int c = 0; c < p.nchunks; ++c) {
+            __syncthreads();
+            store_chunk(0);
+            __syncthreads();
+            if (c + 1 < p.nchunks) load_chunk(c + 1);
+            compute_ks(0, 0);
+            compute_ks(0, 1);
         }
     }
 
@@ -201,13 +284,28 @@ template <int BM, int BN, int WM, int WN>
 int launch3(Conv3Args& a, hipStream_t s) {
     a.tiles_m = otvm_ceil_div(a.M, BM);
     a.tiles_n = otvm_ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN>), dim3(a.tiles_m * a.tiles_n), dim3(WM * WN * 64), 0, s, a);
+    const dim3 grid(a.tiles_m * a.tiles_n), block(WM * WN * 64);
+    // int32 element offsets in the fast path: the whole input view must stay below 2^31 elements
+    // (the split weights of such layers are stored channel-block major: the generic decode cannot read them)
+    const bool fast = f16x3_fast_layout(a.taps, a.Cin);
+    if (fast && (int64_t)a.H * a.W * a.in_ld >= (1ll << 31) - (1 << 20)) {
+        otvm_set_error("otvm_conv2d(f16x3): input view too large for 32-bit offsets");
+        return 1;
+    }
+    if (fast) {
+        if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, a);
+    } else {
+        if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, a);
+    }
     OTVM_CHECK_LAUNCH("otvm_conv2d(f16x3)");
     return 0;
 }
 
 // split a packed fp32 weight row into power-of-two-scaled fp16 hi/lo halves
-__global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ w, int O, int K_pad, _Float16* __restrict__ wh,
+__global__ __launch_bounds__(256) void split_weight_kernel(const float* __restrict__ w, int O, int K_pad, int taps, int I_pad,
+                                                           int reorder, _Float16* __restrict__ wh,
                                                            _Float16* __restrict__ wl, float* __restrict__ wscale) {
     const int o = blockIdx.x;
     const float* row = w + (int64_t)o * K_pad;
@@ -229,18 +327,23 @@ __global__ __launch_bounds__(256) void split_weight_kernel(const float* __restri
     for (int k = threadIdx.x; k < K_pad; k += 256) {
         const float v = row[k] * inv;             // exact (power of two)
         const _Float16 hi = (_Float16)v;
-        wh[(int64_t)o * K_pad + k] = hi;
-        wl[(int64_t)o * K_pad + k] = (_Float16)(v - (float)hi);
+        int kn = k;
+        if (reorder && k < taps * I_pad) {        // [tap][c] -> [c/32][tap][c%32]
+            const int t = k / I_pad, c = k - t * I_pad;
+            kn = ((c >> 5) * taps + t) * 32 + (c & 31);
+        }
+        wh[(int64_t)o * K_pad + kn] = hi;
+        wl[(int64_t)o * K_pad + kn] = (_Float16)(v - (float)hi);
     }
 }
 
 }  // namespace
 
-extern "C" int otvm_split_conv_weight_f16x3(const float* w_packed, int O, int O_pad, int K_pad, void* w_hi, void* w_lo,
-                                            float* w_scale, void* stream) {
+extern "C" int otvm_split_conv_weight_f16x3(const float* w_packed, int O, int O_pad, int K_pad, int taps, int I_pad, void* w_hi,
+                                            void* w_lo, float* w_scale, void* stream) {
     OTVM_REQUIRE(w_packed && w_hi && w_lo && w_scale, "otvm_split_conv_weight_f16x3: null pointer");
-    hipLaunchKernelGGL(split_weight_kernel, dim3(O_pad), dim3(256), 0, (hipStream_t)stream, w_packed, O, K_pad, (_Float16*)w_hi,
-                       (_Float16*)w_lo, w_scale);
+    hipLaunchKernelGGL(split_weight_kernel, dim3(O_pad), dim3(256), 0, (hipStream_t)stream, w_packed, O, K_pad, taps, I_pad,
+                       f16x3_fast_layout(taps, I_pad) ? 1 : 0, (_Float16*)w_hi, (_Float16*)w_lo, w_scale);
     OTVM_CHECK_LAUNCH("otvm_split_conv_weight_f16x3");
     return 0;
 }
@@ -259,8 +362,12 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     const int64_t M = a.M;
     if (p->Cout <= 32) return launch3<256, 32, 4, 1>(a, s);
     if (p->Cout <= 64) return (M >= 256 * 128) ? launch3<256, 64, 4, 1>(a, s) : launch3<64, 64, 2, 2>(a, s);
+    if (p->Cout >= 256) {
+        const int64_t huge = (int64_t)otvm_ceil_div(M, 256) * otvm_ceil_div(p->Cout, 256);
+        if (huge >= 480) return launch3<256, 256, 4, 2>(a, s);
+    }
     const int64_t big = (int64_t)otvm_ceil_div(M, 256) * otvm_ceil_div(p->Cout, 128);
-    if (big >= 512) return launch3<256, 128, 4, 2>(a, s);
+    if (big >= 480) return launch3<256, 128, 4, 2>(a, s);
     const int64_t mid = (int64_t)otvm_ceil_div(M, 128) * otvm_ceil_div(p->Cout, 128);
     if (mid >= 384) return launch3<128, 128, 2, 2>(a, s);
     const int64_t sm = (int64_t)otvm_ceil_div(M, 128) * otvm_ceil_div(p->Cout, 64);

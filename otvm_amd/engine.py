@@ -111,7 +111,7 @@ def pack_conv_weight(lib, dev, w, ws=False, scale=None, i_pad=None, split=True, 
         cw.w_hi = torch.empty(O_pad * cw.K_pad, dtype=torch.float16, device=dev)
         cw.w_lo = torch.empty(O_pad * cw.K_pad, dtype=torch.float16, device=dev)
         cw.w_scale = torch.empty(O, dtype=torch.float32, device=dev)
-        L.check(lib.otvm_split_conv_weight_f16x3(cw.w.data_ptr(), O, O_pad, cw.K_pad, cw.w_hi.data_ptr(),
+        L.check(lib.otvm_split_conv_weight_f16x3(cw.w.data_ptr(), O, O_pad, cw.K_pad, kh * kw, cw.I_pad, cw.w_hi.data_ptr(),
                                                  cw.w_lo.data_ptr(), cw.w_scale.data_ptr(), stream), "split_conv_weight")
     return cw
 

@@ -39,7 +39,7 @@ _PROTOS = {
     "otvm_fold_bn": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp]),
     "otvm_pack_conv_weight": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp]),
     "otvm_conv2d": (i32, [C.POINTER(ConvParams), vp]),
-    "otvm_split_conv_weight_f16x3": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
+    "otvm_split_conv_weight_f16x3": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "otvm_gn_stats": (i32, [vp, i64, i32, i32, vp, vp]),
     "otvm_gn_apply": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i32, i32, vp, i32, vp]),
     "otvm_maxpool3x3s2": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),

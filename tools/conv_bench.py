@@ -1,0 +1,66 @@
+"""Micro-benchmark of otvm_conv2d on single layer shapes (tuning aid; GPU only).
+
+    python tools/conv_bench.py [--prec 1] [--iters 20] [--shape Cin,Cout,k,stride,dil,H,W ...]
+"""
+import argparse
+import ctypes as C
+import math
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from otvm_amd import lib as L                      # noqa: E402
+from otvm_amd.engine import Act, pack_conv_weight, conv_params   # noqa: E402
+
+DEFAULT = [
+    (256, 256, 3, 1, 1, 272, 480),     # STM decoder RF2 / conv_up2-like, OS4
+    (3072, 256, 3, 1, 1, 136, 240),    # conv_up1.0
+    (512, 512, 3, 1, 4, 136, 240),     # layer4 conv2 (dilated)
+    (64, 64, 3, 1, 1, 1088, 1920),     # refine 64->64 full res
+    (1024, 256, 1, 1, 1, 136, 240),    # layer3 conv1 1x1
+    (256, 1024, 1, 1, 1, 136, 240),    # layer3 conv3 1x1
+    (64, 256, 1, 1, 1, 272, 480),      # res2 conv3 1x1
+    (32, 16, 3, 1, 1, 1088, 1920),     # head 32->16
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--prec", type=int, default=1)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--shape", action="append")
+    ap.add_argument("--relu", type=int, default=0)
+    ap.add_argument("--res", type=int, default=0)
+    args = ap.parse_args()
+    shapes = [tuple(int(v) for v in s.split(",")) for s in args.shape] if args.shape else DEFAULT
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    for (Cin, Cout, k, stride, dil, H, W) in shapes:
+        pad = dil * (k - 1) // 2
+        x = Act(torch.randn(H * W * Cin, device=dev), H, W, Cin)
+        w = torch.randn(Cout, Cin, k, k, device=dev) / math.sqrt(Cin * k * k)
+        cw = pack_conv_weight(lib, dev, w, split=True, stream=st)
+        Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+        out = Act(torch.empty(Ho * Wo * max(4, Cout), device=dev), Ho, Wo, Cout)
+        res = Act(torch.randn(Ho * Wo * Cout, device=dev), Ho, Wo, Cout) if args.res else None
+        p = conv_params(x, cw, out, None, stride, pad, dil, 0, args.relu, res, args.prec)
+        for _ in range(3):
+            L.check(lib.otvm_conv2d(C.byref(p), st))
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.iters):
+            L.check(lib.otvm_conv2d(C.byref(p), st))
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.iters
+        fl = 2.0 * Ho * Wo * Cout * k * k * Cin
+        print("Cin %4d Cout %4d k%d s%d d%d %4dx%-4d : %7.3f ms  %7.1f TFLOP/s" % (Cin, Cout, k, stride, dil, H, W, ms, fl / ms / 1e9))
+
+
+if __name__ == "__main__":
+    main()
