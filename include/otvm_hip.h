@@ -68,6 +68,9 @@ typedef struct {
     int precision;                                  /* OTVM_PREC_F32 | OTVM_PREC_F16X3           */
     const void* w_hi; const void* w_lo;             /* f16x3: split weights [O_pad][K_pad] fp16   */
     const float* w_scale;                           /* f16x3: per-filter power-of-two scale [Cout] */
+    double* gn_stats;                               /* optional: fused GroupNorm(32) statistics of the OUTPUT
+                                                       (sum, sum of squares per group, [32][2] fp64, accumulated
+                                                       atomically; Cout % 32 == 0, act == NONE, no residual) or NULL */
 } otvm_conv_params;
 int otvm_conv2d(const otvm_conv_params* p, void* stream);
 
@@ -110,6 +113,16 @@ int otvm_ppm_pool(const float* in, int H, int W, int C, int ld, float* out, void
 int64_t otvm_memory_read_ws_bytes(int hw, int T);
 int otvm_memory_read(const float* q_key, int q_ld, const float* const* keys, const float* const* vals, int T,
                      int hw, float* out, int out_ld, void* ws, void* stream);
+
+/* f16x3 variant (fp32-class accuracy on the f16 MFMA, see OTVM_PREC_F16X3).  The bank is this build's own
+ * structure, so each slot is stored split (fp16 hi/lo) and in MFMA fragment order: otvm_bank_pack_f16x3
+ * converts the fp32 key [hw,128] / value [hw,512] maps of a memorised frame (the KV_M_r4 conv outputs,
+ * STM.py:201-228) into one packed slot of otvm_bank_slot_bytes_f16x3(hw) bytes; the read kernel streams
+ * slots with coalesced 1-KiB wave loads directly into MFMA operands.  ws as otvm_memory_read.            */
+int64_t otvm_bank_slot_bytes_f16x3(int hw);
+int otvm_bank_pack_f16x3(const float* key, const float* val, int hw, void* slot, void* stream);
+int otvm_memory_read_f16x3(const float* q_key, int q_ld, const void* const* slots, int T, int hw, float* out,
+                           int out_ld, void* ws, void* stream);
 
 /* ---------------------------------------------------------------- frame glue --------------------
  * preprocess: alpha/model.py:380-389,408-414 + STM.py:53-57,89-93.  fg,bg: [3,H,W] fp32 BGR 0..255

@@ -19,6 +19,7 @@ SOURCES = [
     ("glue.hip", ["-ffp-contract=off"]),
     ("edt.hip", ["-ffp-contract=off"]),
     ("memory_read.hip", []),
+    ("memory_read_f16x3.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -31,7 +31,7 @@ namespace {
 
 struct Conv3Args {
     const float* in; const _Float16* wh; const _Float16* wl; const float* wscale; const float* bias;
-    const float* residual; float* out;
+    const float* residual; float* out; double* gn_stats;
     int H, W, Cin, in_ld, K_pad, res_ld, Ho, Wo, Cout, out_ld;
     int kh, kw, stride, pad, dil, in_relu, act;
     int M, taps, nchunks, tiles_m, tiles_n;
@@ -278,6 +278,53 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
             }
         }
     }
+
+    // ---- fused GroupNorm statistics of the tile just written (sum / sum of squares per group, fp64 atomics)
+    if (p.gn_stats) {
+        __shared__ double gred[2 * BN];                     // at most BN/2 groups per tile, (sum, sumsq) each
+        const int cg = p.Cout >> 5;                         // channels per group (>= 2)
+        const int seg = cg < 32 ? cg : 32;                  // lanes of one 32-column tile that share a group
+        for (int i = threadIdx.x; i < 2 * BN; i += blockDim.x) gred[i] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int nl = (wn * TN + b) * 32 + col;        // column inside the tile
+            const int n = n0 + nl;
+            float s = 0.f, ss = 0.f;
+            if (n < p.Cout) {
+                const float sc_ = p.wscale[n];
+                const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = m0 + (wm * TM + a) * 32 + (e & 3) + 8 * (e >> 2) + rbase;
+                        if (m < p.M) {
+                            const float v = acc[a][b][e] * sc_ + bias;
+                            s += v;
+                            ss += v * v;
+                        }
+                    }
+            }
+            s += __shfl_xor(s, 32);
+            ss += __shfl_xor(ss, 32);
+            for (int off = 1; off < seg; off <<= 1) {
+                s += __shfl_xor(s, off);
+                ss += __shfl_xor(ss, off);
+            }
+            if (lane < 32 && (lane & (seg - 1)) == 0 && n < p.Cout) {
+                const int gl = nl / cg;                     // group index local to the tile
+                atomicAdd(&gred[2 * gl], (double)s);
+                atomicAdd(&gred[2 * gl + 1], (double)ss);
+            }
+        }
+        __syncthreads();
+        const int ng = (BN + cg - 1) / cg;                  // groups touched by this tile (cg >= 32: BN/cg, else more)
+        for (int i = threadIdx.x; i < 2 * ng; i += blockDim.x) {
+            const int g = n0 / cg + (i >> 1);
+            if (g < 32 && gred[i] != 0.0) atomicAdd(&p.gn_stats[2 * g + (i & 1)], gred[i]);
+        }
+    }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -352,7 +399,7 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     OTVM_REQUIRE(p->w_hi && p->w_lo && p->w_scale, "otvm_conv2d: precision f16x3 needs w_hi / w_lo / w_scale");
     Conv3Args a;
     a.in = p->in; a.wh = (const _Float16*)p->w_hi; a.wl = (const _Float16*)p->w_lo; a.wscale = p->w_scale;
-    a.bias = p->bias; a.residual = p->residual; a.out = p->out;
+    a.bias = p->bias; a.residual = p->residual; a.out = p->out; a.gn_stats = p->gn_stats;
     a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.in_ld = p->in_ld; a.K_pad = p->K_pad; a.res_ld = p->res_ld;
     a.Ho = p->Ho; a.Wo = p->Wo; a.Cout = p->Cout; a.out_ld = p->out_ld;
     a.kh = p->kh; a.kw = p->kw; a.stride = p->stride; a.pad = p->pad; a.dil = p->dil;

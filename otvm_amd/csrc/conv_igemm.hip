@@ -19,7 +19,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace {
 
 struct ConvArgs {
-    const float* in; const float* w; const float* bias; const float* residual; float* out;
+    const float* in; const float* w; const float* bias; const float* residual; float* out; double* gn_stats;
     int H, W, Cin, in_ld, K_pad, res_ld, Ho, Wo, Cout, out_ld;
     int kh, kw, stride, pad, dil, in_relu, act;
     int M, taps, nchunks, tiles_m, tiles_n;
@@ -152,6 +152,53 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
             }
         }
     }
+
+    // ---- fused GroupNorm statistics of the tile just written (sum / sum of squares per group, fp64 atomics)
+    if (p.gn_stats) {
+        __shared__ double gred[2 * BN];                     // at most BN/2 groups per tile, (sum, sumsq) each
+        const int cg = p.Cout >> 5;                         // channels per group (>= 2)
+        const int seg = cg < 32 ? cg : 32;                  // lanes of one 32-column tile that share a group
+        for (int i = threadIdx.x; i < 2 * BN; i += blockDim.x) gred[i] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int nl = (wn * TN + b) * 32 + col;        // column inside the tile
+            const int n = n0 + nl;
+            float s = 0.f, ss = 0.f;
+            if (n < p.Cout) {
+                const float sc_ = 1.f;
+                const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = m0 + (wm * TM + a) * 32 + (e & 3) + 8 * (e >> 2) + rbase;
+                        if (m < p.M) {
+                            const float v = acc[a][b][e] * sc_ + bias;
+                            s += v;
+                            ss += v * v;
+                        }
+                    }
+            }
+            s += __shfl_xor(s, 32);
+            ss += __shfl_xor(ss, 32);
+            for (int off = 1; off < seg; off <<= 1) {
+                s += __shfl_xor(s, off);
+                ss += __shfl_xor(ss, off);
+            }
+            if (lane < 32 && (lane & (seg - 1)) == 0 && n < p.Cout) {
+                const int gl = nl / cg;                     // group index local to the tile
+                atomicAdd(&gred[2 * gl], (double)s);
+                atomicAdd(&gred[2 * gl + 1], (double)ss);
+            }
+        }
+        __syncthreads();
+        const int ng = (BN + cg - 1) / cg;                  // groups touched by this tile (cg >= 32: BN/cg, else more)
+        for (int i = threadIdx.x; i < 2 * ng; i += blockDim.x) {
+            const int g = n0 / cg + (i >> 1);
+            if (g < 32 && gred[i] != 0.0) atomicAdd(&p.gn_stats[2 * g + (i & 1)], gred[i]);
+        }
+    }
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -256,13 +303,15 @@ extern "C" int otvm_conv2d(const otvm_conv_params* p, void* stream) {
     OTVM_REQUIRE(((uintptr_t)p->in & 15) == 0 && ((uintptr_t)p->w & 15) == 0, "otvm_conv2d: in/w must be 16-byte aligned");
     OTVM_REQUIRE(p->precision == OTVM_PREC_F32 || p->precision == OTVM_PREC_F16X3, "otvm_conv2d: unknown precision %d",
                  p->precision);
+    OTVM_REQUIRE(!p->gn_stats || (p->Cout % 64 == 0 && p->act == OTVM_ACT_NONE && !p->residual),
+                 "otvm_conv2d: fused GroupNorm statistics need Cout %% 64 == 0, no activation, no residual");
     OTVM_REQUIRE(p->K_pad % 32 == 0 && p->K_pad >= p->kh * p->kw * p->Cin, "otvm_conv2d: K_pad %d too small", p->K_pad);
     const int Ho = (p->H + 2 * p->pad - p->dil * (p->kh - 1) - 1) / p->stride + 1;
     const int Wo = (p->W + 2 * p->pad - p->dil * (p->kw - 1) - 1) / p->stride + 1;
     OTVM_REQUIRE(Ho == p->Ho && Wo == p->Wo, "otvm_conv2d: output size mismatch (%dx%d expected %dx%d)", p->Ho, p->Wo, Ho, Wo);
     if (p->precision == OTVM_PREC_F16X3) return otvm_conv2d_f16x3_impl(p, stream);
     ConvArgs a;
-    a.in = p->in; a.w = p->w; a.bias = p->bias; a.residual = p->residual; a.out = p->out;
+    a.in = p->in; a.w = p->w; a.bias = p->bias; a.residual = p->residual; a.out = p->out; a.gn_stats = p->gn_stats;
     a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.in_ld = p->in_ld; a.K_pad = p->K_pad; a.res_ld = p->res_ld;
     a.Ho = p->Ho; a.Wo = p->Wo; a.Cout = p->Cout; a.out_ld = p->out_ld;
     a.kh = p->kh; a.kw = p->kw; a.stride = p->stride; a.pad = p->pad; a.dil = p->dil;

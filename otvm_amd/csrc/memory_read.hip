@@ -223,6 +223,14 @@ __global__ void memory_read_combine_kernel(const float* __restrict__ part_o, con
 
 }  // namespace
 
+int otvm_memory_read_combine(const float* part_o, const float* part_ml, int T, int hw, float* out, int out_ld, void* stream) {
+    const int64_t total = (int64_t)hw * (DV / 4);
+    hipLaunchKernelGGL(memory_read_combine_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part_o,
+                       part_ml, T, hw, out, out_ld);
+    OTVM_CHECK_LAUNCH("otvm_memory_read(combine)");
+    return 0;
+}
+
 extern "C" int64_t otvm_memory_read_ws_bytes(int hw, int T) { return (int64_t)T * hw * (DV + 2) * sizeof(float); }
 
 extern "C" int otvm_memory_read(const float* q_key, int q_ld, const float* const* keys, const float* const* vals, int T,
@@ -237,9 +245,6 @@ extern "C" int otvm_memory_read(const float* q_key, int q_ld, const float* const
     a.part_ml = a.part_o + (int64_t)T * hw * DV;
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(memory_read_partial_kernel, dim3(otvm_ceil_div(hw, BQ), T), dim3(256), 0, s, a);
-    const int64_t total = (int64_t)hw * (DV / 4);
-    hipLaunchKernelGGL(memory_read_combine_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, s, a.part_o, a.part_ml, T,
-                       hw, out, out_ld);
     OTVM_CHECK_LAUNCH("otvm_memory_read");
-    return 0;
+    return otvm_memory_read_combine(a.part_o, a.part_ml, T, hw, out, out_ld, stream);
 }

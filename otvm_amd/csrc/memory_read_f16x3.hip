@@ -1,0 +1,299 @@
+// STM memory read (reference models/trimap/STM.py:140-163) on the 16-bit matrix cores with fp32-class
+// accuracy (operand splitting, see conv_f16x3.hip), over a bank stored in MFMA FRAGMENT ORDER.
+//
+// The memory bank is this build's own data structure (the reference concatenates fp32 tensors,
+// alpha/model.py:481-493), so it is laid out for the instruction that consumes it: when a frame is memorised,
+// otvm_bank_pack_f16x3 splits its key/value maps into fp16 hi/lo and writes them as 1-KiB blocks holding exactly
+// the 64 x 16-byte lane fragments of one v_mfma_f32_32x32x16_f16 operand:
+//   keys   Kf[kvb = hw_pad/32][db = 8][hi|lo][lane][8]:  lane l <- K[32 kvb + (l&31)][16 db + 8 (l>>5) + 0..7]   (A of K.Q^T)
+//   values Vf[kvb = hw_pad/16][nb = 16][hi|lo][lane][8]: lane l <- V[16 kvb + 8 (l>>5) + 0..7][32 nb + (l&31)]   (B of P.V)
+// The read kernel then streams the bank with fully coalesced 1-KiB wave loads straight into MFMA operand
+// registers: no LDS staging, no transposes, no conversion of the (T times larger) memory side.  Only the query
+// tile and the probabilities go through LDS.
+//
+// Workgroup = 64 queries x one slot (4 waves), online softmax over the memory axis in fp32, 64x512 fp32 output
+// block in accumulators, per-slot partials merged by the combine kernel of memory_read.hip.
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int DK = 128, DV = 512, BQ = 64, BKV = 64;
+constexpr int LDQH = DK + 8;      // halfs per Q row in LDS (272 B: conflict-free b128)
+constexpr int LDS_S = BKV + 4;    // floats per S row
+constexpr int LDPH = BKV + 8;     // halfs per P row (144 B)
+
+__device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo) {
+    hi = (_Float16)v;
+    lo = (_Float16)(v - (float)hi);
+}
+
+// ---- bank packing: fp32 [hw,128] / [hw,512] -> fragment-major split fp16 -------------------------------
+__global__ __launch_bounds__(256) void bank_pack_keys_kernel(const float* __restrict__ k, int hw, _Float16* __restrict__ kf) {
+    // one block per 32-row kv block: 8 d-blocks x 2 (hi/lo) x 64 lanes x 8 halfs
+    const int kvb = blockIdx.x;
+    for (int i = threadIdx.x; i < 8 * 64; i += 256) {
+        const int db = i >> 6, l = i & 63;
+        const int row = kvb * 32 + (l & 31), d0 = db * 16 + 8 * (l >> 5);
+        f16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float v = row < hw ? k[(int64_t)row * DK + d0 + j] : 0.f;
+            _Float16 h, lw;
+            split1(v, h, lw);
+            hi[j] = h; lo[j] = lw;
+        }
+        _Float16* base = kf + (((int64_t)kvb * 8 + db) * 2) * 512;
+        *reinterpret_cast<f16x8*>(base + l * 8) = hi;
+        *reinterpret_cast<f16x8*>(base + 512 + l * 8) = lo;
+    }
+}
+
+__global__ __launch_bounds__(256) void bank_pack_vals_kernel(const float* __restrict__ v, int hw, _Float16* __restrict__ vf) {
+    // one block per 16-row kv block: 16 n-blocks x 2 x 64 lanes x 8 halfs; lanes read 32 consecutive dv (coalesced)
+    const int kvb = blockIdx.x;
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+        const int nb = i >> 6, l = i & 63;
+        const int dv = nb * 32 + (l & 31), r0 = kvb * 16 + 8 * (l >> 5);
+        f16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = (r0 + j) < hw ? v[(int64_t)(r0 + j) * DV + dv] : 0.f;
+            _Float16 h, lw;
+            split1(x, h, lw);
+            hi[j] = h; lo[j] = lw;
+        }
+        _Float16* base = vf + (((int64_t)kvb * 16 + nb) * 2) * 512;
+        *reinterpret_cast<f16x8*>(base + l * 8) = hi;
+        *reinterpret_cast<f16x8*>(base + 512 + l * 8) = lo;
+    }
+}
+
+struct Mem3Args {
+    const float* q; int q_ld;
+    const _Float16* kf[8]; const _Float16* vf[8];
+    int T, hw;
+    float* part_o;     // [T][hw][512]
+    float* part_ml;    // [T][hw][2]
+};
+
+__global__ __launch_bounds__(256) void memory_read_f16x3_kernel(const Mem3Args p) {
+    __shared__ __attribute__((aligned(16))) _Float16 Qh[BQ * LDQH];
+    __shared__ __attribute__((aligned(16))) _Float16 Ql[BQ * LDQH];
+    __shared__ __attribute__((aligned(16))) float Sl[BQ * LDS_S];
+    __shared__ __attribute__((aligned(16))) _Float16 Ph[BQ * LDPH];
+    __shared__ __attribute__((aligned(16))) _Float16 Pl[BQ * LDPH];
+    __shared__ float red[4 * BQ];
+    __shared__ float m_run[BQ], l_run[BQ], alpha_l[BQ];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int q0 = blockIdx.x * BQ, slot = blockIdx.y;
+    const _Float16* __restrict__ Kf = p.kf[slot];
+    const _Float16* __restrict__ Vf = p.vf[slot];
+    const int hw = p.hw;
+
+    // query tile -> LDS, split (rows beyond hw are zero)
+    for (int i = tid; i < BQ * (DK / 4); i += 256) {
+        const int r = i / (DK / 4), c = (i - r * (DK / 4)) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (q0 + r < hw) v = *reinterpret_cast<const f32x4*>(p.q + (int64_t)(q0 + r) * p.q_ld + c);
+        f16x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { _Float16 h, lw; split1(v[j], h, lw); hi[j] = h; lo[j] = lw; }
+        *reinterpret_cast<f16x4*>(&Qh[r * LDQH + c]) = hi;
+        *reinterpret_cast<f16x4*>(&Ql[r * LDQH + c]) = lo;
+    }
+    if (tid < BQ) { m_run[tid] = -__builtin_huge_valf(); l_run[tid] = 0.f; }
+    __syncthreads();
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    const int sa = wave >> 1, sb = wave & 1;            // S sub-tile of this wave: kv 32sa.., q 32sb..
+    const int frow = lane & 31, fh = lane >> 5;
+    const float scale = 1.0f / sqrtf((float)DK);        // p / math.sqrt(D_e)  (STM.py:154)
+    const int ntiles = (hw + BKV - 1) / BKV;
+
+    // the query fragments of this wave never change: keep them in registers (8 k-steps x hi/lo)
+    f16x8 qh[8], ql[8];
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        qh[ks] = *reinterpret_cast<const f16x8*>(&Qh[(sb * 32 + frow) * LDQH + 16 * ks + 8 * fh]);
+        ql[ks] = *reinterpret_cast<const f16x8*>(&Ql[(sb * 32 + frow) * LDQH + 16 * ks + 8 * fh]);
+    }
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int kv0 = t * BKV;
+        // ---- S = K Q^T for this wave's 32x32 block: A fragments straight from the packed bank
+        f32x16 s;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        const _Float16* kblk = Kf + ((int64_t)(2 * t + sa) * 8 * 2) * 512 + lane * 8;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            const f16x8 kh = *reinterpret_cast<const f16x8*>(kblk + (ks * 2) * 512);
+            const f16x8 kl = *reinterpret_cast<const f16x8*>(kblk + (ks * 2 + 1) * 512);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
+        }
+        // lane: col q = lane&31, rows kv = (e&3) + 8*(e>>2) + 4*(lane>>5); store transposed Sl[q][kv]
+        {
+            const int qq = sb * 32 + frow;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int kvl = sa * 32 + 8 * g + 4 * fh;
+                f32x4 v = {s[4 * g] * scale, s[4 * g + 1] * scale, s[4 * g + 2] * scale, s[4 * g + 3] * scale};
+                const float ninf = -__builtin_huge_valf();
+                if (kv0 + kvl + 0 >= hw) v.x = ninf;
+                if (kv0 + kvl + 1 >= hw) v.y = ninf;
+                if (kv0 + kvl + 2 >= hw) v.z = ninf;
+                if (kv0 + kvl + 3 >= hw) v.w = ninf;
+                *reinterpret_cast<f32x4*>(&Sl[qq * LDS_S + kvl]) = v;
+            }
+        }
+        __syncthreads();
+
+        // ---- online softmax over the memory axis: thread = (query, kv quarter); P written split (hi/lo)
+        {
+            const int qq = tid & 63, part = tid >> 6;
+            f32x4 v[4];
+            float mx = -__builtin_huge_valf();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[i] = *reinterpret_cast<const f32x4*>(&Sl[qq * LDS_S + part * 16 + 4 * i]);
+                mx = fmaxf(mx, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+            }
+            red[part * BQ + qq] = mx;
+            __syncthreads();
+            const float m_old = m_run[qq];
+            const float m_tile = fmaxf(fmaxf(red[qq], red[BQ + qq]), fmaxf(red[2 * BQ + qq], red[3 * BQ + qq]));
+            const float m_new = fmaxf(m_old, m_tile);
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                f16x4 hi, lo;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float e = expf(v[i][j] - m_new);
+                    sum += e;
+                    _Float16 h, lw;
+                    split1(e, h, lw);
+                    hi[j] = h; lo[j] = lw;
+                }
+                *reinterpret_cast<f16x4*>(&Ph[qq * LDPH + part * 16 + 4 * i]) = hi;
+                *reinterpret_cast<f16x4*>(&Pl[qq * LDPH + part * 16 + 4 * i]) = lo;
+            }
+            __syncthreads();
+            red[part * BQ + qq] = sum;
+            __syncthreads();
+            if (part == 0) {
+                const float al = expf(m_old - m_new);
+                alpha_l[qq] = al;
+                l_run[qq] = l_run[qq] * al + ((red[qq] + red[BQ + qq]) + (red[2 * BQ + qq] + red[3 * BQ + qq]));
+                m_run[qq] = m_new;
+            }
+            __syncthreads();
+        }
+
+        // ---- rescale O, accumulate P V: wave w owns output channels [128w, 128w+128)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const float al = alpha_l[a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[a][b][e] *= al;
+            }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f16x8 ph[2], pl[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                ph[a] = *reinterpret_cast<const f16x8*>(&Ph[(a * 32 + frow) * LDPH + 16 * ks + 8 * fh]);
+                pl[a] = *reinterpret_cast<const f16x8*>(&Pl[(a * 32 + frow) * LDPH + 16 * ks + 8 * fh]);
+            }
+            const _Float16* vblk = Vf + (((int64_t)(4 * t + ks) * 16 + wave * 4) * 2) * 512 + lane * 8;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const f16x8 vh = *reinterpret_cast<const f16x8*>(vblk + (b * 2) * 512);
+                const f16x8 vl = *reinterpret_cast<const f16x8*>(vblk + (b * 2 + 1) * 512);
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl[a], vh, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[a], vl, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[a], vh, acc[a][b], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                 // Ph/Pl/Sl/alpha are rewritten by the next tile
+    }
+    // partial results: un-normalised O, running max and sum
+    const int dv0 = wave * 128;
+    float* po = p.part_o + ((int64_t)slot * hw) * DV;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int qq = q0 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+            if (qq < hw) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b) po[(int64_t)qq * DV + dv0 + 32 * b + frow] = acc[a][b][e];
+            }
+        }
+    if (tid < BQ && q0 + tid < hw) {
+        float* ml = p.part_ml + ((int64_t)slot * hw + q0 + tid) * 2;
+        ml[0] = m_run[tid];
+        ml[1] = l_run[tid];
+    }
+}
+
+}  // namespace
+
+int otvm_memory_read_combine(const float* part_o, const float* part_ml, int T, int hw, float* out, int out_ld, void* stream);
+
+static inline int hw_pad64(int hw) { return (hw + 63) / 64 * 64; }
+
+extern "C" int64_t otvm_bank_slot_bytes_f16x3(int hw) {
+    // keys: hw_pad x 128 x (hi,lo) fp16 ; values: hw_pad x 512 x (hi,lo) fp16
+    return (int64_t)hw_pad64(hw) * (DK + DV) * 2 * sizeof(_Float16);
+}
+
+extern "C" int otvm_bank_pack_f16x3(const float* key, const float* val, int hw, void* slot, void* stream) {
+    OTVM_REQUIRE(key && val && slot && hw > 0, "otvm_bank_pack_f16x3: bad arguments");
+    const int hp = hw_pad64(hw);
+    _Float16* kf = (_Float16*)slot;
+    _Float16* vf = kf + (int64_t)hp * DK * 2;
+    hipLaunchKernelGGL(bank_pack_keys_kernel, dim3(hp / 32), dim3(256), 0, (hipStream_t)stream, key, hw, kf);
+    hipLaunchKernelGGL(bank_pack_vals_kernel, dim3(hp / 16), dim3(256), 0, (hipStream_t)stream, val, hw, vf);
+    OTVM_CHECK_LAUNCH("otvm_bank_pack_f16x3");
+    return 0;
+}
+
+extern "C" int otvm_memory_read_f16x3(const float* q_key, int q_ld, const void* const* slots, int T, int hw, float* out,
+                                      int out_ld, void* ws, void* stream) {
+    OTVM_REQUIRE(T >= 1 && T <= 8, "otvm_memory_read_f16x3: T=%d out of range [1,8]", T);
+    OTVM_REQUIRE(q_key && slots && out && ws && hw > 0, "otvm_memory_read_f16x3: bad arguments");
+    OTVM_REQUIRE(q_ld % 4 == 0 && out_ld % 4 == 0, "otvm_memory_read_f16x3: views must be 16-byte aligned");
+    const int hp = hw_pad64(hw);
+    Mem3Args a;
+    a.q = q_key; a.q_ld = q_ld; a.T = T; a.hw = hw;
+    for (int t = 0; t < 8; ++t) {
+        a.kf[t] = t < T ? (const _Float16*)slots[t] : nullptr;
+        a.vf[t] = t < T ? (const _Float16*)slots[t] + (int64_t)hp * DK * 2 : nullptr;
+    }
+    a.part_o = (float*)ws;
+    a.part_ml = a.part_o + (int64_t)T * hw * DV;
+    hipLaunchKernelGGL(memory_read_f16x3_kernel, dim3(otvm_ceil_div(hw, BQ), T), dim3(256), 0, (hipStream_t)stream, a);
+    OTVM_CHECK_LAUNCH("otvm_memory_read_f16x3");
+    return otvm_memory_read_combine(a.part_o, a.part_ml, T, hw, out, out_ld, stream);
+}

@@ -20,6 +20,7 @@ import torch
 from . import lib as L
 
 NONE, RELU, LEAKY = 0, 1, 2
+FUSE_GN_STATS = True       # GroupNorm statistics accumulated in the producing conv's epilogue
 
 
 def _rup(x, m):
@@ -126,7 +127,7 @@ def conv_params(x, cw, out, bias=None, stride=1, pad=0, dil=1, act=NONE, in_relu
                         0 if residual is None else residual.ptr, 0 if residual is None else residual.ld,
                         out.ptr, Ho, Wo, cw.O, out.ld, cw.kh, cw.kw, stride, pad, dil, in_relu, act, precision,
                         0 if cw.w_hi is None else cw.w_hi.data_ptr(), 0 if cw.w_lo is None else cw.w_lo.data_ptr(),
-                        0 if cw.w_scale is None else cw.w_scale.data_ptr())
+                        0 if cw.w_scale is None else cw.w_scale.data_ptr(), 0)
 
 
 class HipEngine:
@@ -307,6 +308,7 @@ class FramePlan:
         self.P = self.Hp * self.Wp
         self._bufs = {}
         self._keep = []
+        self._fused_stats = []
         self.n_gn = 0
         self.steps = {}
         self._build()
@@ -337,13 +339,19 @@ class FramePlan:
         self._keep.append(p)
         flops = 2 * Ho * Wo * w.O * w.kh * w.kw * w.I           # algorithmic (un-padded) 2*MAC
         S.append((self.lib.otvm_conv2d, (C.byref(p),), "conv " + wname, flops))
+        return p
 
-    def gn(self, S, x, name, act, out=None, residual=None):
+    def gn(self, S, x, name, act, out=None, residual=None, conv_p=None):
+        """GroupNorm(32) of the raw conv output ``x``.  With ``conv_p`` (the params of the conv that produced x)
+        the statistics are accumulated in that conv's epilogue and the separate stats pass is dropped."""
         out = x if out is None else out
         sd = self.e.sd
         idx = self.n_gn
         self.n_gn += 1
-        S.append(("gn_stats", (x.ptr, x.P, x.C, x.ld), idx, "gn_stats " + name))
+        if conv_p is not None and FUSE_GN_STATS:
+            self._fused_stats.append((conv_p, idx))
+        else:
+            S.append(("gn_stats", (x.ptr, x.P, x.C, x.ld), idx, "gn_stats " + name))
         S.append(("gn_apply", (x.ptr, x.P, x.C, x.ld), idx,
                   (sd[name + ".weight"].data_ptr(), sd[name + ".bias"].data_ptr(),
                    0 if residual is None else residual.ptr, 0 if residual is None else residual.ld, act,
@@ -351,6 +359,8 @@ class FramePlan:
 
     def _bind_stats(self):
         base = self.stats.data_ptr()
+        for conv_p, idx in self._fused_stats:
+            conv_p.gn_stats = base + idx * 512
         for key, S in self.steps.items():
             for i, st in enumerate(S):
                 if st[0] == "gn_stats":
@@ -372,20 +382,20 @@ class FramePlan:
     def gn_bottleneck(self, S, x, p, planes, stride, dil, has_ds, out):
         Ho, Wo = x.H // stride, x.W // stride
         t1 = self.buf("bt1", x.H, x.W, planes)
-        self.conv(S, x, p + ".conv1", t1)
-        self.gn(S, t1, p + ".bn1", RELU)
+        cp = self.conv(S, x, p + ".conv1", t1)
+        self.gn(S, t1, p + ".bn1", RELU, conv_p=cp)
         t2 = self.buf("bt2", Ho, Wo, planes)
-        self.conv(S, t1, p + ".conv2", t2, stride=stride, pad=dil, dil=dil)
-        self.gn(S, t2, p + ".bn2", RELU)
+        cp = self.conv(S, t1, p + ".conv2", t2, stride=stride, pad=dil, dil=dil)
+        self.gn(S, t2, p + ".bn2", RELU, conv_p=cp)
         t3 = self.buf("bt3", Ho, Wo, planes * 4)
-        self.conv(S, t2, p + ".conv3", t3)
+        cp3 = self.conv(S, t2, p + ".conv3", t3)
         if has_ds:
             idt = self.buf("btd", Ho, Wo, planes * 4)
-            self.conv(S, x, p + ".downsample.0", idt, stride=stride)
-            self.gn(S, idt, p + ".downsample.1", NONE)
+            cp = self.conv(S, x, p + ".downsample.0", idt, stride=stride)
+            self.gn(S, idt, p + ".downsample.1", NONE, conv_p=cp)
         else:
             idt = x
-        self.gn(S, t3, p + ".bn3", RELU, out=out, residual=idt)
+        self.gn(S, t3, p + ".bn3", RELU, out=out, residual=idt, conv_p=cp3)
 
     def bn_bottleneck(self, S, x, p, planes, stride, has_ds, out, tag):
         Ho, Wo = x.H // stride, x.W // stride
@@ -479,9 +489,9 @@ class FramePlan:
         self.U2 = self.buf("U2", H4, W4, 512)            # [up(conv_up1) 256 | l1 256]
         self.PPMCAT = self.buf("PPMCAT", H8, W8, 3072)   # [l4 2048 | ppm 4x256]
         c1raw = self.buf("c1raw", H2, W2, 64)
-        self.conv(S, self.X11, en + "conv1", c1raw, stride=2, pad=3)
+        cp = self.conv(S, self.X11, en + "conv1", c1raw, stride=2, pad=3)
         c1 = self.U3.ch(256, 64)
-        self.gn(S, c1raw, en + "bn1", RELU, out=c1)
+        self.gn(S, c1raw, en + "bn1", RELU, out=c1, conv_p=cp)
         x = self.buf("e_pool", H4, W4, 64)
         self.maxpool(S, c1, x)
         cfg = {"layer1": (64, 3, 1, 1, 1), "layer2": (128, 4, 2, 1, 1), "layer3": (256, 6, 1, 1, 2),
@@ -510,24 +520,24 @@ class FramePlan:
         for i, s in enumerate((1, 2, 3, 6)):
             pin = Act(self.POOL, s, s, 2048, 2048, base * 2048)
             y = self.buf("ppm_y%d" % i, s, s, 256)
-            self.conv(S, pin, de + "ppm.%d.1" % i, y)
-            self.gn(S, y, de + "ppm.%d.2" % i, LEAKY)
+            cp = self.conv(S, pin, de + "ppm.%d.1" % i, y)
+            self.gn(S, y, de + "ppm.%d.2" % i, LEAKY, conv_p=cp)
             self.upsample(S, y, self.PPMCAT.ch(2048 + 256 * i, 256))
             base += s * s
         u1 = self.buf("u1a", H8, W8, 256)
-        self.conv(S, self.PPMCAT, de + "conv_up1.0", u1, pad=1)
-        self.gn(S, u1, de + "conv_up1.1", LEAKY)
+        cp = self.conv(S, self.PPMCAT, de + "conv_up1.0", u1, pad=1)
+        self.gn(S, u1, de + "conv_up1.1", LEAKY, conv_p=cp)
         u1b = self.buf("u1b", H8, W8, 256)
-        self.conv(S, u1, de + "conv_up1.3", u1b, pad=1)
-        self.gn(S, u1b, de + "conv_up1.4", LEAKY)
+        cp = self.conv(S, u1, de + "conv_up1.3", u1b, pad=1)
+        self.gn(S, u1b, de + "conv_up1.4", LEAKY, conv_p=cp)
         self.upsample(S, u1b, self.U2.ch(0, 256))
         u2 = self.buf("u2", H4, W4, 256)
-        self.conv(S, self.U2, de + "conv_up2.0", u2, pad=1)
-        self.gn(S, u2, de + "conv_up2.1", LEAKY)
+        cp = self.conv(S, self.U2, de + "conv_up2.0", u2, pad=1)
+        self.gn(S, u2, de + "conv_up2.1", LEAKY, conv_p=cp)
         self.upsample(S, u2, self.U3.ch(0, 256))
         u3 = self.buf("u3", H2, W2, 64)
-        self.conv(S, self.U3, de + "conv_up3.0", u3, pad=1)
-        self.gn(S, u3, de + "conv_up3.1", LEAKY)
+        cp = self.conv(S, self.U3, de + "conv_up3.0", u3, pad=1)
+        self.gn(S, u3, de + "conv_up3.1", LEAKY, conv_p=cp)
         self.upsample(S, u3, self.D80.ch(0, 64))
         h32 = self.buf("h32", Hp, Wp, 32)
         self.conv(S, self.D80.ch(0, 72), de + "conv_up4.0", h32, pad=1, act=LEAKY)
@@ -540,17 +550,17 @@ class FramePlan:
         # ---------------- refinement (FBA/models.py:417-435)
         rf = "NET.refine."
         r0 = self.buf("r0", Hp, Wp, 64)
-        self.conv(S, self.D80.ch(0, 76), rf + "conv1.0", r0, pad=1)
-        self.gn(S, r0, rf + "conv1.1", LEAKY)
+        cp = self.conv(S, self.D80.ch(0, 76), rf + "conv1.0", r0, pad=1)
+        self.gn(S, r0, rf + "conv1.1", LEAKY, conv_p=cp)
         x = r0
         for l in ("layer1", "layer2"):
             t1 = self.buf("rt1", Hp, Wp, 64)
-            self.conv(S, x, rf + l + ".conv1", t1, pad=1)
-            self.gn(S, t1, rf + l + ".bn1", RELU)
+            cp = self.conv(S, x, rf + l + ".conv1", t1, pad=1)
+            self.gn(S, t1, rf + l + ".bn1", RELU, conv_p=cp)
             t2 = self.buf("rt2", Hp, Wp, 64)
-            self.conv(S, t1, rf + l + ".conv2", t2, pad=1)
+            cp = self.conv(S, t1, rf + l + ".conv2", t2, pad=1)
             o = self.buf("r_" + l, Hp, Wp, 64)
-            self.gn(S, t2, rf + l + ".bn2", RELU, out=o, residual=x)
+            self.gn(S, t2, rf + l + ".bn2", RELU, out=o, residual=x, conv_p=cp)
             x = o
         self.conv(S, x, rf + "pred.0", h32, pad=1, act=LEAKY)
         hid = self.SM.ch(0, 16)
@@ -598,17 +608,25 @@ class FramePlan:
             if s["hw"] == self.hw:
                 return e.free_slots.pop(i)
         H16, W16 = self.Hp // 16, self.Wp // 16
-        return dict(hw=self.hw, k=Act(torch.zeros(self.hw * 128, dtype=torch.float32, device=self.dev), H16, W16, 128),
+        slot = dict(hw=self.hw, k=Act(torch.zeros(self.hw * 128, dtype=torch.float32, device=self.dev), H16, W16, 128),
                     v=Act(torch.zeros(self.hw * 512, dtype=torch.float32, device=self.dev), H16, W16, 512), frame=-1)
+        if e.precision == L.PREC_F16X3:        # packed (split fp16, MFMA fragment order) copy read by the f16x3 kernel
+            slot["packed"] = torch.zeros(int(self.lib.otvm_bank_slot_bytes_f16x3(self.hw)), dtype=torch.uint8, device=self.dev)
+        return slot
 
     def memory_read(self, bank, stream):
         T = len(bank)
         need = int(self.lib.otvm_memory_read_ws_bytes(self.hw, T))
         if self.mem_ws is None or self.mem_ws.numel() < need:
             self.mem_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
+        out = self.M4.ch(0, 512)
+        if self.e.precision == L.PREC_F16X3:
+            slots = (C.c_void_p * T)(*[s["packed"].data_ptr() for s in bank])
+            L.check(self.lib.otvm_memory_read_f16x3(self.QK.ptr, self.QK.ld, slots, T, self.hw, out.ptr, out.ld,
+                                                    self.mem_ws.data_ptr(), stream), "memory_read_f16x3")
+            return
         keys = (C.c_void_p * T)(*[s["k"].ptr for s in bank])
         vals = (C.c_void_p * T)(*[s["v"].ptr for s in bank])
-        out = self.M4.ch(0, 512)
         L.check(self.lib.otvm_memory_read(self.QK.ptr, self.QK.ld, keys, vals, T, self.hw, out.ptr, out.ld,
                                           self.mem_ws.data_ptr(), stream), "memory_read")
 
@@ -627,6 +645,9 @@ class FramePlan:
             if prof is not None:
                 e1.record()
                 prof.append((st[2], st[3], e0, e1))
+        if "packed" in slot:
+            L.check(self.lib.otvm_bank_pack_f16x3(slot["k"].ptr, slot["v"].ptr, self.hw, slot["packed"].data_ptr(), stream),
+                    "bank_pack")
 
     def encode(self, stream, cls_override=None):
         """8-channel trimap encoding of PROBS into X11[3:11] / D80[70:72] (alpha/model.py:40-53)."""

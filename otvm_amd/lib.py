@@ -21,7 +21,7 @@ class ConvParams(C.Structure):
                 ("out", vp), ("Ho", i32), ("Wo", i32), ("Cout", i32), ("out_ld", i32),
                 ("kh", i32), ("kw", i32), ("stride", i32), ("pad", i32), ("dil", i32),
                 ("in_relu", i32), ("act", i32),
-                ("precision", i32), ("w_hi", vp), ("w_lo", vp), ("w_scale", vp)]
+                ("precision", i32), ("w_hi", vp), ("w_lo", vp), ("w_scale", vp), ("gn_stats", vp)]
 
 
 class PreprocessParams(C.Structure):
@@ -48,6 +48,9 @@ _PROTOS = {
     "otvm_ppm_pool": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "otvm_memory_read_ws_bytes": (i64, [i32, i32]),
     "otvm_memory_read": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp), i32, i32, vp, i32, vp, vp]),
+    "otvm_bank_slot_bytes_f16x3": (i64, [i32]),
+    "otvm_bank_pack_f16x3": (i32, [vp, vp, i32, vp, vp]),
+    "otvm_memory_read_f16x3": (i32, [vp, i32, C.POINTER(vp), i32, i32, vp, i32, vp, vp]),
     "otvm_preprocess": (i32, [C.POINTER(PreprocessParams), vp]),
     "otvm_pad_trimap": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, vp]),
     "otvm_upsample4_softmax3": (i32, [vp, i32, i32, i32, vp, vp]),

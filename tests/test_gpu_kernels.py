@@ -74,6 +74,23 @@ def test_conv2d(G, case, prec):
     assert G.maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f16x3"])
+@pytest.mark.parametrize("Cin,Cout,H,W", [(64, 64, 50, 70), (32, 128, 33, 47), (128, 256, 20, 31), (64, 1024, 9, 13), (256, 2048, 6, 7)])
+def test_conv_fused_groupnorm_stats(G, prec, Cin, Cout, H, W):
+    """The conv epilogue accumulates the GroupNorm(32) sums of its output (replaces the separate stats pass)."""
+    x = rnd(1, Cin, H, W, seed=70)
+    w = rnd(Cout, Cin, 3, 3, seed=71, scale=1.0 / math.sqrt(Cin * 9))
+    b = rnd(Cout, seed=72)
+    ref = F.conv2d(x, w, b, 1, 1).double()
+    g = ref.reshape(32, Cout // 32, H * W)
+    want = torch.stack([g.sum((1, 2)), (g * g).sum((1, 2))], 1).flatten()
+    stats = torch.zeros(64, dtype=torch.float64, device=G.DEV)
+    out = G.empty_act(H, W, Cout)
+    G.conv2d(G.to_act(x), G.pack_weight(w), out, b.to(G.DEV), pad=1, precision=prec, gn_stats=stats)
+    got = stats.cpu()
+    assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
 def test_f16x3_is_fp32_class(G):
     """Error of the split-fp16 path vs an fp64 reference, next to the exact-fp32 MFMA path, on operands
     spanning 1e-3 .. 30 (the dropped lo*lo term is 2^-22 relative)."""
@@ -201,6 +218,19 @@ def test_memory_read(G, T, h, w):
     kp = (C.c_void_p * T)(*[k.data_ptr() for k in keys])
     vp = (C.c_void_p * T)(*[v.data_ptr() for v in vals])
     L.check(lib.otvm_memory_read(q.data_ptr(), 128, kp, vp, T, hw, out.data_ptr(), 1024, ws.data_ptr(), G.stream()))
+    torch.cuda.synchronize()
+    got = out[:, :512].cpu()
+    assert torch.isfinite(got).all()
+    assert G.maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    # f16x3 variant over the packed (split, fragment-major) bank
+    slots = []
+    for t in range(T):
+        sl = torch.zeros(int(lib.otvm_bank_slot_bytes_f16x3(hw)), dtype=torch.uint8, device=G.DEV)
+        L.check(lib.otvm_bank_pack_f16x3(keys[t].data_ptr(), vals[t].data_ptr(), hw, sl.data_ptr(), G.stream()))
+        slots.append(sl)
+    out.fill_(float("nan"))
+    sp = (C.c_void_p * T)(*[s_.data_ptr() for s_ in slots])
+    L.check(lib.otvm_memory_read_f16x3(q.data_ptr(), 128, sp, T, hw, out.data_ptr(), 1024, ws.data_ptr(), G.stream()))
     torch.cuda.synchronize()
     got = out[:, :512].cpu()
     assert torch.isfinite(got).all()
