@@ -47,6 +47,12 @@ int otvm_abi_version(void);
 int otvm_pack_conv_weight(const float* w_oihw, int O, int I, int kh, int kw, int ws, const float* scale,
                           float* w_packed, int O_pad, int I_pad, int K_pad, void* stream);
 
+/* f16x3, 3x3 stride-1 convolutions with I_pad % 32 == 0: weights in MFMA B-fragment order for the patch kernel
+ * (conv_patch_f16x3.hip), [I_pad/32][9 taps][ceil(O/32)][2 k-steps][hi|lo][64 lanes][8 halfs].  w_scale as above. */
+int64_t otvm_patch_weight_bytes_f16x3(int O, int I_pad);
+int otvm_pack_patch_weight_f16x3(const float* w_packed, int O, int K_pad, int I_pad, void* w_frag, float* w_scale,
+                                 void* stream);
+
 /* Fold an eval-mode BatchNorm (eps 1e-5, running statistics; torchvision Bottleneck used by
  * STM.py:43-51,79-87) into a per-channel scale/bias: scale = gamma/sqrt(var+eps),
  * bias = beta - mean*scale.                                                                       */
@@ -68,6 +74,8 @@ typedef struct {
     int precision;                                  /* OTVM_PREC_F32 | OTVM_PREC_F16X3           */
     const void* w_hi; const void* w_lo;             /* f16x3: split weights [O_pad][K_pad] fp16   */
     const float* w_scale;                           /* f16x3: per-filter power-of-two scale [Cout] */
+    const void* w_frag;                             /* f16x3, optional: fragment-major weights for the 3x3 patch kernel
+                                                       (otvm_pack_patch_weight_f16x3) or NULL                    */
     double* gn_stats;                               /* optional: fused GroupNorm(32) statistics of the OUTPUT
                                                        (sum, sum of squares per group, [32][2] fp64, accumulated
                                                        atomically; Cout % 32 == 0, act == NONE, no residual) or NULL */

@@ -14,6 +14,7 @@ SOURCES = [
     ("error.cpp", []),
     ("conv_igemm.hip", []),
     ("conv_f16x3.hip", []),
+    ("conv_patch_f16x3.hip", []),
     ("groupnorm.hip", []),
     ("resample.hip", ["-ffp-contract=off"]),
     ("glue.hip", ["-ffp-contract=off"]),

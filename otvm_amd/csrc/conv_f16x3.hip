@@ -429,8 +429,14 @@ extern "C" int otvm_split_conv_weight_f16x3(const float* w_packed, int O, int O_
     return 0;
 }
 
+int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream);    // conv_patch_f16x3.hip, -1 = not eligible
+
 int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     OTVM_REQUIRE(p->w_hi && p->w_lo && p->w_scale, "otvm_conv2d: precision f16x3 needs w_hi / w_lo / w_scale");
+    {
+        const int rc = otvm_conv2d_patch_f16x3_impl(p, stream);
+        if (rc != -1) return rc;
+    }
     Conv3Args a;
     a.in = p->in; a.wh = (const _Float16*)p->w_hi; a.wl = (const _Float16*)p->w_lo; a.wscale = p->w_scale;
     a.bias = p->bias; a.residual = p->residual; a.out = p->out; a.gn_stats = p->gn_stats;

@@ -1,0 +1,365 @@
+// 3x3 (stride 1, dilation d) convolution as a "patch" kernel on the f16 MFMA with split-fp16 operands (f16x3).
+//
+// The implicit-GEMM kernel (conv_f16x3.hip) re-gathers and re-splits every input element once per tap: 9 global
+// loads, 9 fp32->(hi,lo) conversions and 9 LDS writes per element.  For the layers with few output channels
+// (full-resolution refinement / head convs, N = 16..64) that staging work, not the MFMA, sets the time.  Here a
+// workgroup owns a TH x 32 block of output pixels: per 32-channel block it stages the (TH+2d) x (32+2d) input patch
+// into LDS ONCE (one conversion per element), and the 9 taps read shifted windows of that patch as MFMA A operands
+// (pixel rows are 80 bytes apart in LDS -> conflict-free ds_read_b128 for 32 consecutive pixels).
+//
+// Weights never touch LDS: like the memory bank they are packed at load time in MFMA B-fragment order
+// (otvm_pack_patch_weight_f16x3: [cin/32][tap][n/32][k-step][hi|lo][lane][8 halfs] = 1-KiB blocks), so a wave fetches
+// a B operand with one coalesced 16-byte-per-lane load from L2.
+//
+// One wave owns TM = TH/NW output rows (M tiles of 32 pixels) x TN = BN/32 channel tiles.  fp32 accumulate; epilogue
+// as conv_f16x3.hip (filter scale, bias, residual, activation, optional fused GroupNorm statistics).
+#include "common.h"
+#include <stdlib.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+struct PatchArgs {
+    const float* in; const _Float16* wf; const float* wscale; const float* bias; const float* residual; float* out;
+    double* gn_stats;
+    int H, W, Cin, in_ld, res_ld, Cout, out_ld, n_pad32, in_relu, act;
+    int tiles_x, tiles_y, tiles_n;
+};
+
+constexpr int CB = 16;           // channels per stage = one MFMA k-step
+constexpr int LDP = 24;          // halfs per patch pixel (16 channels + 8 pad) = 48 bytes: 3r mod 16 distinct -> conflict-free b128
+
+__device__ __forceinline__ void split4p(const f32x4 v, f16x4& hi, f16x4& lo) {
+    typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+    const fp16x2 p01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y);
+    const fp16x2 p23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+    const f16x2 h01 = __builtin_bit_cast(f16x2, p01);
+    const f16x2 h23 = __builtin_bit_cast(f16x2, p23);
+    hi = f16x4{h01.x, h01.y, h23.x, h23.y};
+    lo = f16x4{(_Float16)(v.x - (float)h01.x), (_Float16)(v.y - (float)h01.y), (_Float16)(v.z - (float)h23.x),
+               (_Float16)(v.w - (float)h23.y)};
+}
+
+// Per stage (16 input channels) a workgroup holds in LDS: the split input patch and the 9 taps' B fragments of its
+// BN output channels, copied verbatim from the fragment-major weight array (1-KiB blocks, lane-linear).
+template <int TH, int BN, int NW, int DIL>
+__global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchArgs p) {
+    constexpr int NT = NW * 64;
+    constexpr int TM = TH / NW, TN = BN / 32;
+    constexpr int PW = 32 + 2 * DIL, PH = TH + 2 * DIL, NPIX = PH * PW;
+    static_assert(TH % NW == 0 && BN % 32 == 0, "bad tile");
+    constexpr int PATCH_HALFS = 2 * NPIX * LDP;                        // hi + lo
+    constexpr int B_HALFS = 9 * TN * 2 * 512;                          // taps x channel tiles x (hi, lo) x 1 KiB
+    constexpr int EPI_HALFS = NW * 32 * 36 * 2;                        // epilogue patches (fp32) expressed in halfs
+    constexpr int SM_HALFS = PATCH_HALFS + B_HALFS > EPI_HALFS ? PATCH_HALFS + B_HALFS : EPI_HALFS;
+    __shared__ __attribute__((aligned(16))) _Float16 smem[SM_HALFS];
+    _Float16* Ph = smem;
+    _Float16* Pl = smem + NPIX * LDP;
+    _Float16* Bs = smem + PATCH_HALFS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // tile decode: channel tile fastest, then x, then y (neighbouring tiles share halo rows in L2)
+    int bid = blockIdx.x;
+    const int tile_n = bid % p.tiles_n; bid /= p.tiles_n;
+    const int tile_x = bid % p.tiles_x;
+    const int tile_y = bid / p.tiles_x;
+    const int ty0 = tile_y * TH, tx0 = tile_x * 32, n0 = tile_n * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    const int frow = lane & 31, fh = lane >> 5;
+    const int ncb = p.Cin / CB;
+    const int nbs = p.n_pad32 >> 5;
+    const int nb0 = n0 >> 5;
+    // register prefetch of the next stage (global -> registers under the MFMAs of the current stage)
+    constexpr int NP = (NPIX * 4 + NT - 1) / NT;                       // patch float4 per thread
+    constexpr int NB = (9 * TN * 2 * 64 + NT - 1) / NT;                // B 16-byte pieces per thread
+    f32x4 rp[NP];
+    f16x8 rb[NB];
+    auto prefetch = [&](int cb) __attribute__((always_inline)) {
+        const int cb32 = cb >> 1, ks = cb & 1;
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int i = tid + k * NT;
+            if (i < 9 * TN * 2 * 64) {
+                const int l = i & 63, blk = i >> 6;                     // blk = (tap*TN + b)*2 + hl
+                const int hl = blk & 1, tb = blk >> 1, b = tb % TN, tap = tb / TN;
+                const int64_t src = (((((int64_t)cb32 * 9 + tap) * nbs + nb0 + b) * 2 + ks) * 2 + hl) * 512 + l * 8;
+                rb[k] = *reinterpret_cast<const f16x8*>(p.wf + src);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int idx = tid + k * NT;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (idx < NPIX * 4) {
+                const int pix = idx >> 2, c4 = (idx & 3) * 4;
+                const int py = pix / PW, px = pix - py * PW;
+                const int iy = ty0 - DIL + py, ix = tx0 - DIL + px;
+                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                    v = *reinterpret_cast<const f32x4*>(p.in + ((int64_t)iy * p.W + ix) * p.in_ld + cb * CB + c4);
+            }
+            rp[k] = v;
+        }
+    };
+    auto commit = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int i = tid + k * NT;
+            if (i < 9 * TN * 2 * 64) *reinterpret_cast<f16x8*>(&Bs[i * 8]) = rb[k];
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int idx = tid + k * NT;
+            if (idx < NPIX * 4) {
+                f32x4 v = rp[k];
+                if (p.in_relu) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                f16x4 hi, lo;
+                split4p(v, hi, lo);
+                const int pix = idx >> 2, c4 = (idx & 3) * 4;
+                *reinterpret_cast<f16x4*>(&Ph[pix * LDP + c4]) = hi;
+                *reinterpret_cast<f16x4*>(&Pl[pix * LDP + c4]) = lo;
+            }
+        }
+    };
+    prefetch(0);
+    for (int cb = 0; cb < ncb; ++cb) {
+        __syncthreads();                                                // the previous stage's LDS reads are done
+        commit();
+        __syncthreads();
+        if (cb + 1 < ncb) prefetch(cb + 1);
+        // ---- 9 taps out of LDS
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            f16x8 bh[TN], bl[TN], ah[TM], al[TM];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                bh[b] = *reinterpret_cast<const f16x8*>(&Bs[((tap * TN + b) * 2) * 512 + lane * 8]);
+                bl[b] = *reinterpret_cast<const f16x8*>(&Bs[((tap * TN + b) * 2 + 1) * 512 + lane * 8]);
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int o = ((wave * TM + a + ky * DIL) * PW + kx * DIL + frow) * LDP + 8 * fh;
+                ah[a] = *reinterpret_cast<const f16x8*>(&Ph[o]);
+                al[a] = *reinterpret_cast<const f16x8*>(&Pl[o]);
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: accumulator tile -> wave-private LDS patch -> 16-byte row-major stores (see conv_f16x3.hip)
+    const int col = lane & 31, rbase = (lane >> 5) * 4;
+    __syncthreads();
+    {
+        float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
+        const int prow = lane >> 3, pc = (lane & 7) * 4;
+        const bool vec_ok = ((p.out_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
+                            (!p.residual || (((p.res_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0)));
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int n4 = n0 + b * 32 + pc;
+            f32x4 sc4 = {0.f, 0.f, 0.f, 0.f}, bi4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (n4 + j < p.Cout) {
+                    sc4[j] = p.wscale[n4 + j];
+                    bi4[j] = p.bias ? p.bias[n4 + j] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int y = ty0 + wave * TM + a;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int xi = r4 * 8 + prow;
+                    const int x = tx0 + xi;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&patch[xi * 36 + pc]);
+                    v = v * sc4 + bi4;
+                    if (y < p.H && x < p.W) {
+                        const int64_t m = (int64_t)y * p.W + x;
+                        if (vec_ok && n4 + 3 < p.Cout) {
+                            if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + m * p.res_ld + n4);
+                            v.x = otvm_act(v.x, p.act); v.y = otvm_act(v.y, p.act);
+                            v.z = otvm_act(v.z, p.act); v.w = otvm_act(v.w, p.act);
+                            *reinterpret_cast<f32x4*>(p.out + m * p.out_ld + n4) = v;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if (n4 + j < p.Cout) {
+                                    float xv = v[j];
+                                    if (p.residual) xv += p.residual[m * p.res_ld + n4 + j];
+                                    p.out[m * p.out_ld + n4 + j] = otvm_act(xv, p.act);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- fused GroupNorm statistics (sum / sum of squares per group, fp64 atomics)
+    if (p.gn_stats) {
+        __shared__ double gred[2 * BN];
+        const int cg = p.Cout >> 5;
+        const int seg = cg < 32 ? cg : 32;
+        for (int i = tid; i < 2 * BN; i += NT) gred[i] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int nl = b * 32 + col;
+            const int n = n0 + nl;
+            float s = 0.f, ss = 0.f;
+            if (n < p.Cout) {
+                const float sc_ = p.wscale[n];
+                const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const int y = ty0 + wave * TM + a;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int x = tx0 + (e & 3) + 8 * (e >> 2) + rbase;
+                        if (y < p.H && x < p.W) {
+                            const float v = acc[a][b][e] * sc_ + bias;
+                            s += v;
+                            ss += v * v;
+                        }
+                    }
+                }
+            }
+            s += __shfl_xor(s, 32);
+            ss += __shfl_xor(ss, 32);
+            for (int off = 1; off < seg; off <<= 1) {
+                s += __shfl_xor(s, off);
+                ss += __shfl_xor(ss, off);
+            }
+            if (lane < 32 && (lane & (seg - 1)) == 0 && n < p.Cout) {
+                const int gl = nl / cg;
+                atomicAdd(&gred[2 * gl], (double)s);
+                atomicAdd(&gred[2 * gl + 1], (double)ss);
+            }
+        }
+        __syncthreads();
+        const int ng = (BN + cg - 1) / cg;
+        for (int i = tid; i < 2 * ng; i += NT) {
+            const int g = n0 / cg + (i >> 1);
+            if (g < 32 && gred[i] != 0.0) atomicAdd(&p.gn_stats[2 * g + (i & 1)], gred[i]);
+        }
+    }
+}
+
+// packed fp32 weight [O_pad][K_pad] (k = tap*I_pad + c) -> fragment-major split fp16 for the patch kernel
+__global__ __launch_bounds__(256) void pack_patch_weight_kernel(const float* __restrict__ w, int O, int K_pad, int I_pad, int n_pad32,
+                                                                _Float16* __restrict__ wf, float* __restrict__ wscale) {
+    // one block per output filter row n: compute its power-of-two scale, then scatter its 9*I_pad values
+    const int n = blockIdx.x;
+    __shared__ float red[256];
+    float mx = 0.f;
+    const float* row = w + (int64_t)n * K_pad;
+    const bool real = n < O;
+    if (real)
+        for (int k = threadIdx.x; k < 9 * I_pad; k += 256) mx = fmaxf(mx, fabsf(row[k]));
+    red[threadIdx.x] = mx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + s]);
+        __syncthreads();
+    }
+    int e = 0;
+    if (red[0] > 0.f) frexpf(red[0], &e);
+    const float inv = ldexpf(1.f, -e);
+    if (threadIdx.x == 0 && real) wscale[n] = ldexpf(1.f, e);
+    const int nb = n >> 5, nl = n & 31, nbs = n_pad32 >> 5;
+    for (int k = threadIdx.x; k < 9 * I_pad; k += 256) {
+        const int tap = k / I_pad, c = k - tap * I_pad;
+        const float v = real ? row[k] * inv : 0.f;
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        const int cb = c >> 5, ks = (c >> 4) & 1, h = (c >> 3) & 1, j = c & 7;
+        const int l = nl + 32 * h;
+        const int64_t blk = ((((int64_t)cb * 9 + tap) * nbs + nb) * 2 + ks) * 2;
+        wf[(blk + 0) * 512 + l * 8 + j] = hi;
+        wf[(blk + 1) * 512 + l * 8 + j] = lo;
+    }
+}
+
+template <int TH, int BN, int NW, int DIL>
+int launch_patch(PatchArgs& a, hipStream_t s) {
+    a.tiles_x = otvm_ceil_div(a.W, 32);
+    a.tiles_y = otvm_ceil_div(a.H, TH);
+    a.tiles_n = otvm_ceil_div(a.Cout, BN);
+    hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL>), dim3(a.tiles_x * a.tiles_y * a.tiles_n), dim3(NW * 64), 0, s, a);
+    OTVM_CHECK_LAUNCH("otvm_conv2d(patch f16x3)");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t otvm_patch_weight_bytes_f16x3(int O, int I_pad) {
+    const int64_t n_pad32 = (O + 31) / 32 * 32;
+    return (int64_t)(I_pad / 32) * 9 * n_pad32 * 32 * 2 * sizeof(_Float16);
+}
+
+extern "C" int otvm_pack_patch_weight_f16x3(const float* w_packed, int O, int K_pad, int I_pad, void* w_frag, float* w_scale,
+                                            void* stream) {
+    OTVM_REQUIRE(w_packed && w_frag && w_scale && I_pad % 32 == 0, "otvm_pack_patch_weight_f16x3: needs I_pad %% 32 == 0");
+    const int n_pad32 = (O + 31) / 32 * 32;
+    hipLaunchKernelGGL(pack_patch_weight_kernel, dim3(n_pad32), dim3(256), 0, (hipStream_t)stream, w_packed, O, K_pad, I_pad, n_pad32,
+                       (_Float16*)w_frag, w_scale);
+    OTVM_CHECK_LAUNCH("otvm_pack_patch_weight_f16x3");
+    return 0;
+}
+
+// returns -1 when the layer is not eligible (caller falls back to the implicit-GEMM kernel)
+int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream) {
+    if (!p->w_frag || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->Cin % 32 != 0) return -1;
+    static const int max_cout = getenv("OTVM_PATCH_MAX_COUT") ? atoi(getenv("OTVM_PATCH_MAX_COUT")) : 64;
+    // wide layers: the 256x256 implicit-GEMM tile is faster, except 128..256 output channels on large maps (measured:
+    // 256->256 at 272x480: 307 vs 284 TFLOP/s; at 136x240: 201 vs 287)
+    const bool wide_ok = p->Cout <= 256 && p->dil == 1 && (int64_t)p->H * p->W >= 100000;
+    if (p->Cout > max_cout && !wide_ok) return -1;
+    if (p->dil != 1 && p->dil != 2 && p->dil != 4) return -1;
+    PatchArgs a;
+    a.in = p->in; a.wf = (const _Float16*)p->w_frag; a.wscale = p->w_scale; a.bias = p->bias; a.residual = p->residual;
+    a.out = p->out; a.gn_stats = p->gn_stats;
+    a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.in_ld = p->in_ld; a.res_ld = p->res_ld; a.Cout = p->Cout; a.out_ld = p->out_ld;
+    a.n_pad32 = (p->Cout + 31) / 32 * 32; a.in_relu = p->in_relu; a.act = p->act;
+    hipStream_t s = (hipStream_t)stream;
+    if (p->dil == 1) {
+        if (p->Cout <= 32) return launch_patch<8, 32, 4, 1>(a, s);
+        if (p->Cout <= 64) return launch_patch<8, 64, 4, 1>(a, s);
+        return launch_patch<8, 128, 4, 1>(a, s);
+    }
+    if (p->dil == 2) return p->Cout <= 64 ? launch_patch<8, 64, 4, 2>(a, s) : launch_patch<8, 128, 4, 2>(a, s);
+    return p->Cout <= 64 ? launch_patch<8, 64, 4, 4>(a, s) : launch_patch<8, 128, 4, 4>(a, s);
+}

@@ -53,7 +53,7 @@ class Act:
 
 
 class ConvW:
-    __slots__ = ("w", "K_pad", "O", "I", "I_pad", "kh", "kw", "bias", "w_hi", "w_lo", "w_scale")
+    __slots__ = ("w", "K_pad", "O", "I", "I_pad", "kh", "kw", "bias", "w_hi", "w_lo", "w_scale", "w_frag")
 
 
 def pad_amounts(h, w, d):
@@ -107,13 +107,17 @@ def pack_conv_weight(lib, dev, w, ws=False, scale=None, i_pad=None, split=True, 
     L.check(lib.otvm_pack_conv_weight(w.data_ptr(), O, I, kh, kw, 1 if ws else 0,
                                       0 if scale is None else scale.data_ptr(), cw.w.data_ptr(), O_pad,
                                       cw.I_pad, cw.K_pad, stream), "pack_conv_weight")
-    cw.w_hi = cw.w_lo = cw.w_scale = None
+    cw.w_hi = cw.w_lo = cw.w_scale = cw.w_frag = None
     if split:
         cw.w_hi = torch.empty(O_pad * cw.K_pad, dtype=torch.float16, device=dev)
         cw.w_lo = torch.empty(O_pad * cw.K_pad, dtype=torch.float16, device=dev)
         cw.w_scale = torch.empty(O, dtype=torch.float32, device=dev)
         L.check(lib.otvm_split_conv_weight_f16x3(cw.w.data_ptr(), O, O_pad, cw.K_pad, kh * kw, cw.I_pad, cw.w_hi.data_ptr(),
                                                  cw.w_lo.data_ptr(), cw.w_scale.data_ptr(), stream), "split_conv_weight")
+        if kh == 3 and kw == 3 and cw.I_pad % 32 == 0:          # 3x3: also the fragment-major copy for the patch kernel
+            cw.w_frag = torch.zeros(int(lib.otvm_patch_weight_bytes_f16x3(O, cw.I_pad)), dtype=torch.uint8, device=dev)
+            L.check(lib.otvm_pack_patch_weight_f16x3(cw.w.data_ptr(), O, cw.K_pad, cw.I_pad, cw.w_frag.data_ptr(),
+                                                     cw.w_scale.data_ptr(), stream), "pack_patch_weight")
     return cw
 
 
@@ -127,7 +131,8 @@ def conv_params(x, cw, out, bias=None, stride=1, pad=0, dil=1, act=NONE, in_relu
                         0 if residual is None else residual.ptr, 0 if residual is None else residual.ld,
                         out.ptr, Ho, Wo, cw.O, out.ld, cw.kh, cw.kw, stride, pad, dil, in_relu, act, precision,
                         0 if cw.w_hi is None else cw.w_hi.data_ptr(), 0 if cw.w_lo is None else cw.w_lo.data_ptr(),
-                        0 if cw.w_scale is None else cw.w_scale.data_ptr(), 0)
+                        0 if cw.w_scale is None else cw.w_scale.data_ptr(),
+                        0 if cw.w_frag is None else cw.w_frag.data_ptr(), 0)
 
 
 class HipEngine:

@@ -21,7 +21,8 @@ class ConvParams(C.Structure):
                 ("out", vp), ("Ho", i32), ("Wo", i32), ("Cout", i32), ("out_ld", i32),
                 ("kh", i32), ("kw", i32), ("stride", i32), ("pad", i32), ("dil", i32),
                 ("in_relu", i32), ("act", i32),
-                ("precision", i32), ("w_hi", vp), ("w_lo", vp), ("w_scale", vp), ("gn_stats", vp)]
+                ("precision", i32), ("w_hi", vp), ("w_lo", vp), ("w_scale", vp), ("w_frag", vp),
+                ("gn_stats", vp)]
 
 
 class PreprocessParams(C.Structure):
@@ -36,6 +37,8 @@ class PreprocessParams(C.Structure):
 
 _PROTOS = {
     "otvm_abi_version": (i32, []),
+    "otvm_patch_weight_bytes_f16x3": (i64, [i32, i32]),
+    "otvm_pack_patch_weight_f16x3": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "otvm_fold_bn": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp]),
     "otvm_pack_conv_weight": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp]),
     "otvm_conv2d": (i32, [C.POINTER(ConvParams), vp]),
