@@ -327,12 +327,12 @@ int launch_patch(PatchArgs& a, hipStream_t s) {
 
 extern "C" int64_t otvm_patch_weight_bytes_f16x3(int O, int I_pad) {
     const int64_t n_pad32 = (O + 31) / 32 * 32;
-    return (int64_t)(I_pad / 32) * 9 * n_pad32 * 32 * 2 * sizeof(_Float16);
+    return (int64_t)((I_pad + 31) / 32) * 9 * n_pad32 * 32 * 2 * sizeof(_Float16);
 }
 
 extern "C" int otvm_pack_patch_weight_f16x3(const float* w_packed, int O, int K_pad, int I_pad, void* w_frag, float* w_scale,
                                             void* stream) {
-    OTVM_REQUIRE(w_packed && w_frag && w_scale && I_pad % 32 == 0, "otvm_pack_patch_weight_f16x3: needs I_pad %% 32 == 0");
+    OTVM_REQUIRE(w_packed && w_frag && w_scale && I_pad % 16 == 0, "otvm_pack_patch_weight_f16x3: needs I_pad %% 16 == 0");
     const int n_pad32 = (O + 31) / 32 * 32;
     hipLaunchKernelGGL(pack_patch_weight_kernel, dim3(n_pad32), dim3(256), 0, (hipStream_t)stream, w_packed, O, K_pad, I_pad, n_pad32,
                        (_Float16*)w_frag, w_scale);
@@ -342,7 +342,7 @@ extern "C" int otvm_pack_patch_weight_f16x3(const float* w_packed, int O, int K_
 
 // returns -1 when the layer is not eligible (caller falls back to the implicit-GEMM kernel)
 int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream) {
-    if (!p->w_frag || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->Cin % 32 != 0) return -1;
+    if (!p->w_frag || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->Cin % 16 != 0) return -1;
     static const int max_cout = getenv("OTVM_PATCH_MAX_COUT") ? atoi(getenv("OTVM_PATCH_MAX_COUT")) : 64;
     // wide layers: the 256x256 implicit-GEMM tile is faster, except 128..256 output channels on large maps (measured:
     // 256->256 at 272x480: 307 vs 284 TFLOP/s; at 136x240: 201 vs 287)

@@ -114,7 +114,7 @@ def pack_conv_weight(lib, dev, w, ws=False, scale=None, i_pad=None, split=True, 
         cw.w_scale = torch.empty(O, dtype=torch.float32, device=dev)
         L.check(lib.otvm_split_conv_weight_f16x3(cw.w.data_ptr(), O, O_pad, cw.K_pad, kh * kw, cw.I_pad, cw.w_hi.data_ptr(),
                                                  cw.w_lo.data_ptr(), cw.w_scale.data_ptr(), stream), "split_conv_weight")
-        if kh == 3 and kw == 3 and cw.I_pad % 32 == 0:          # 3x3: also the fragment-major copy for the patch kernel
+        if kh == 3 and kw == 3 and cw.I_pad % 16 == 0:          # 3x3: also the fragment-major copy for the patch kernel
             cw.w_frag = torch.zeros(int(lib.otvm_patch_weight_bytes_f16x3(O, cw.I_pad)), dtype=torch.uint8, device=dev)
             L.check(lib.otvm_pack_patch_weight_f16x3(cw.w.data_ptr(), O, cw.K_pad, cw.I_pad, cw.w_frag.data_ptr(),
                                                      cw.w_scale.data_ptr(), stream), "pack_patch_weight")
@@ -187,7 +187,10 @@ class HipEngine:
                 ws = not ("conv_up4" in k or ".pred." in k)               # layers_WS.Conv2d vs nn.Conv2d
                 if name in ("NET.decoder.conv_up4.4", "NET.refine.pred.4"):
                     continue                                             # 1x1 heads run inside otvm_fba_head
-                self._pack(name, v, ws=ws, bias=sd.get(name + ".bias"))
+                # the two convs reading the 80-channel D80 buffer take all 80 channels (zero weights on the tail) so
+                # that Cin is a multiple of 16 and the 3x3 patch kernel applies
+                i_pad = 80 if name in ("NET.decoder.conv_up4.0", "NET.refine.conv1.0") else None
+                self._pack(name, v, ws=ws, bias=sd.get(name + ".bias"), i_pad=i_pad)
             elif ".Encoder_" in k:
                 if ".conv1_" in k or name.endswith("Encoder_M.conv1"):
                     continue                                             # merged stem, below
@@ -545,7 +548,7 @@ class FramePlan:
         self.gn(S, u3, de + "conv_up3.1", LEAKY, conv_p=cp)
         self.upsample(S, u3, self.D80.ch(0, 64))
         h32 = self.buf("h32", Hp, Wp, 32)
-        self.conv(S, self.D80.ch(0, 72), de + "conv_up4.0", h32, pad=1, act=LEAKY)
+        self.conv(S, self.D80, de + "conv_up4.0", h32, pad=1, act=LEAKY)      # ch 72.. carry zero weights
         hid_d = self.buf("hid_d", Hp, Wp, 16)
         self.conv(S, h32, de + "conv_up4.2", hid_d, pad=1, act=LEAKY)
         img = self.D80.ch(67, 3)
@@ -555,7 +558,7 @@ class FramePlan:
         # ---------------- refinement (FBA/models.py:417-435)
         rf = "NET.refine."
         r0 = self.buf("r0", Hp, Wp, 64)
-        cp = self.conv(S, self.D80.ch(0, 76), rf + "conv1.0", r0, pad=1)
+        cp = self.conv(S, self.D80, rf + "conv1.0", r0, pad=1)
         self.gn(S, r0, rf + "conv1.1", LEAKY, conv_p=cp)
         x = r0
         for l in ("layer1", "layer2"):
