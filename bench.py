@@ -167,11 +167,12 @@ def main():
         run_frames(T - nrep, T)
         torch.cuda.synchronize(dev)
         prof, eng.prof = eng.prof, None
-        tot_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1 in prof)
-        tot_fl = float(sum(f for _, f, _, _ in prof))
+        tot_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1, _ in prof)
+        tot_fl = float(sum(f for _, f, _, _, _ in prof))
+        tot_by = float(sum(b for _, _, _, _, b in prof))
         n = len(prof)
         per_layer = {}
-        for label, f, e0, e1 in prof:
+        for label, f, e0, e1, _ in prof:
             d = per_layer.setdefault(label, [0.0, 0.0, 0])
             d[0] += e0.elapsed_time(e1); d[1] += f; d[2] += 1
         worst = sorted(per_layer.items(), key=lambda kv: -kv[1][0])[:8]
@@ -180,10 +181,17 @@ def main():
                          tflops=v[1] / (v[0] * 1e-3) / 1e12) for k, v in sorted(per_layer.items(), key=lambda kv: -kv[1][0])]
             json.dump(rows, open(args.layer_report, "w"), indent=0)
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
+        # HBM bytes per conv launch from the committed PMC passes of this same command (profiles/, tools/pmc_traffic.py);
+        # only quoted when that run matches this configuration
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic_%s_%dx%d.json" % (eng.precision_name, W, H))
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
         result["roofline"] = {
             "bound": "mfma", "kernel": KERNEL_NAME[eng.precision_name],
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": None,
+            "traffic": traffic,
+            "algorithmic_bytes_per_launch": tot_by / n,
             "launches_per_frame": n / nrep, "avg_launch_ms": tot_ms / n, "algorithmic_gflop_per_launch": tot_fl / n / 1e9,
             "conv_ms_per_frame": tot_ms / nrep, "conv_share_of_frame": (tot_ms / nrep) / (1000.0 * elapsed / K),
             "slowest_layers_ms_per_frame": {k: round(v[0] / nrep, 3) for k, v in worst},

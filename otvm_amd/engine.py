@@ -346,7 +346,9 @@ class FramePlan:
         p = conv_params(x, w, out, w.bias, stride, pad, dil, act, in_relu, residual, self.e.precision)
         self._keep.append(p)
         flops = 2 * Ho * Wo * w.O * w.kh * w.kw * w.I           # algorithmic (un-padded) 2*MAC
-        S.append((self.lib.otvm_conv2d, (C.byref(p),), "conv " + wname, flops))
+        # algorithmic bytes: read the input once, the weights once, write the output once (+ residual read), fp32
+        abytes = 4 * (x.H * x.W * w.I + w.O * w.I * w.kh * w.kw + Ho * Wo * w.O * (2 if residual is not None else 1))
+        S.append((self.lib.otvm_conv2d, (C.byref(p),), "conv " + wname, flops, abytes))
         return p
 
     def gn(self, S, x, name, act, out=None, residual=None, conv_p=None):
@@ -604,7 +606,7 @@ class FramePlan:
                 e0.record()
                 rc = st[0](*st[1], stream)
                 e1.record()
-                prof.append((st[2], st[3], e0, e1))
+                prof.append((st[2], st[3], e0, e1, st[4]))
             else:
                 rc = st[0](*st[1], stream)
             if rc != 0:
@@ -652,7 +654,7 @@ class FramePlan:
             L.check(st[0](*st[1], stream), st[2])
             if prof is not None:
                 e1.record()
-                prof.append((st[2], st[3], e0, e1))
+                prof.append((st[2], st[3], e0, e1, st[4]))
         if "packed" in slot:
             L.check(self.lib.otvm_bank_pack_f16x3(slot["k"].ptr, slot["v"].ptr, self.hw, slot["packed"].data_ptr(), stream),
                     "bank_pack")
