@@ -207,6 +207,7 @@ def main():
         t_s = 2
         # replay frames 0..t_s-1 on the device to obtain the bank state at frame t_s
         run_frames(0, t_s)
+        eng.flush()
         torch.cuda.synchronize(dev)
         orc.bank = [(s["k"].t.reshape(hw, 128).t().reshape(128, Hp // 16, Wp // 16).cpu().contiguous(),
                      s["v"].t.reshape(hw, 512).t().reshape(512, Hp // 16, Wp // 16).cpu().contiguous(), s["frame"])

@@ -49,7 +49,9 @@ class EvalModel(nn.Module):
     def memories(self):
         """Bank introspection (reference: self.memories['key'].shape[3] slots)."""
         eng = self._engine
-        return {"frames": [] if eng is None else [s["frame"] for s in eng.bank]}
+        if eng is None:
+            return {"frames": []}
+        return {"frames": eng.bank_frames()}
 
     @torch.no_grad()
     def forward(self, a, fg, bg, tri=None, tri_gt=None, first_frame=False, last_frame=False, memorize=False,

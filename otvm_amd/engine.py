@@ -154,6 +154,11 @@ class HipEngine:
         self.free_slots = []
         self.stream = 0
         self.prof = None
+        self.pending = None          # deferred memorize of the previous frame
+        self.parity = 0
+        self.side = None
+        import os
+        self.use_side_stream = os.environ.get("OTVM_SIDE_STREAM", "1") != "0"
         self._pack_all()
 
     # ------------------------------------------------------------------ weights
@@ -242,6 +247,32 @@ class HipEngine:
         alpha_u8 = torch.empty((H, W), dtype=torch.uint8, device=dev)
         tri_out = torch.empty((1, 1, 3, H, W), dtype=f32, device=dev)
         tri_gt_out = torch.empty((1, 1, 3, H, W), dtype=f32, device=dev)
+        # ---- deferred memorize of the previous frame (reference order: memorize(t) ends frame t, alpha/model.py:461-493;
+        # here it opens frame t+1 so that Encoder_M(t) and Encoder_Q(t+1), two chains of small launches that cannot fill
+        # 256 CUs on their own, run concurrently on two HIP streams; they meet before the memory read)
+        if first_frame:
+            self.pending = None
+            self.reset()
+        pend, self.pending = self.pending, None
+        if pend is not None and pend["plan"] is not pl:
+            self._memorize(pend, stream)                      # resolution changed: finish it in order
+            pend = None
+        par = self.parity
+        self.parity ^= 1
+        main = torch.cuda.current_stream(dev)
+        ev_side = None
+        if pend is not None:
+            if self.prof is None and self.use_side_stream:
+                if self.side is None:
+                    self.side = torch.cuda.Stream(device=dev)
+                ev_main = torch.cuda.Event()
+                ev_main.record(main)
+                self.side.wait_event(ev_main)
+                self._memorize(pend, self.side.cuda_stream)
+                ev_side = torch.cuda.Event()
+                ev_side.record(self.side)
+            else:
+                self._memorize(pend, stream)
         pl.stats.zero_()
         pp = L.PreprocessParams()
         pp.fg, pp.bg, pp.a = fg.data_ptr(), bg.data_ptr(), a.data_ptr()
@@ -253,7 +284,7 @@ class HipEngine:
         pp.scaled_imgs = scaled_imgs.data_ptr()
         pp.x11, pp.x11_ld = pl.X11.ptr, pl.X11.ld
         pp.sq, pp.sq_ld = pl.SQ.ptr, pl.SQ.ld
-        smv = pl.SM.ch(16, 8)
+        smv = pl.SMs[par].ch(16, 8)
         pp.sm, pp.sm_ld = smv.ptr, smv.ld
         pp.d80, pp.d80_ld = pl.D80.ptr, pl.D80.ld
         L.check(lib.otvm_preprocess(C.byref(pp), stream), "preprocess")
@@ -270,29 +301,54 @@ class HipEngine:
             tri_src = tri_gt_out
 
         if first_frame:
-            self.reset()
             L.check(lib.otvm_pad_trimap(tri_src.data_ptr(), H, W, pl.PROBS.data_ptr(), pl.Hp, pl.Wp, pl.lh, pl.lw, stream),
                     "pad_trimap")
         else:
+            pl.run("segment_a", stream)
+            if ev_side is not None:
+                main.wait_event(ev_side)
             if not self.bank:
                 raise RuntimeError("otvm_amd: non-first frame with an empty memory bank (call with first_frame=True first)")
-            pl.run("segment_a", stream)
             pl.memory_read(self.bank, stream)
             pl.run("segment_b", stream)
+        if first_frame and ev_side is not None:
+            main.wait_event(ev_side)
         pl.encode(stream, cls_override)
         pl.run("fba", stream)
+        pl.run("fba_tail%d" % par, stream)
         if not last_frame:
             slot = pl.new_slot()
             slot["frame"] = frame_id
-            pl.run("memorize", stream)
-            pl.kv_into_slot(slot, stream)
-            self.bank, released = bank_update(self.bank, slot, first_frame, memorize, max_memory_num)
-            self.free_slots.extend(released)
+            self.pending = dict(plan=pl, par=par, slot=slot, first_frame=first_frame, memorize=memorize,
+                                max_memory_num=max_memory_num)
         L.check(lib.otvm_crop_outputs(pl.ALPHA_P.data_ptr(), pl.TRI_P.data_ptr(), pl.Hp, pl.Wp, H, W, pl.lh, pl.lw,
                                       alpha.data_ptr(), alpha_u8.data_ptr(), tri_out.data_ptr(), stream), "crop")
         self.last_alpha_u8 = alpha_u8
         self.last_plan = pl
         return scaled_imgs, tri_out, tri_gt_out, alpha, a
+
+    def _memorize(self, pend, stream):
+        """STM.memorize of a finished frame + the bank policy (alpha/model.py:466-493), on ``stream``."""
+        pl, slot = pend["plan"], pend["slot"]
+        pl.run("mem_stem%d" % pend["par"], stream)
+        pl.run("mem_trunk", stream)
+        pl.kv_into_slot(slot, stream)
+        self.bank, released = bank_update(self.bank, slot, pend["first_frame"], pend["memorize"], pend["max_memory_num"])
+        self.free_slots.extend(released)
+
+    def bank_frames(self):
+        """Frame ids resident in the bank, including a memorize that is still deferred (host-side policy only)."""
+        bank = list(self.bank)
+        pend = self.pending
+        if pend is not None:
+            bank, _ = bank_update(bank, pend["slot"], pend["first_frame"], pend["memorize"], pend["max_memory_num"])
+        return [s["frame"] for s in bank]
+
+    def flush(self):
+        """Run a deferred memorize now (bank introspection, end of stream)."""
+        pend, self.pending = self.pending, None
+        if pend is not None:
+            self._memorize(pend, self._stream())
 
     def _consts(self, key):
         c = getattr(self, "_const_cache", None)
@@ -450,7 +506,10 @@ class FramePlan:
         # ---------------- frame-level buffers
         self.X11 = self.buf("X11", Hp, Wp, 12)          # 0-2 normalised RGB, 3-8 distance encoding, 9-10 soft, 11 zero
         self.SQ = self.buf("SQ", Hp, Wp, 4)             # Encoder_Q input (normalised RGB)
-        self.SM = self.buf("SM", Hp, Wp, 24)            # Encoder_M input: hid16 | rgb | p_un p_fg alpha | pad
+        # Encoder_M input: hid16 | rgb | p_un p_fg alpha | pad.  Two copies (frame parity): frame t's memorize is
+        # deferred to the start of frame t+1 and overlaps Encoder_Q(t+1) on a second stream, so SM(t) must survive
+        # while frame t+1 writes its own.
+        self.SMs = [self.buf("SM0", Hp, Wp, 24), self.buf("SM1", Hp, Wp, 24)]
         self.D80 = self.buf("D80", Hp, Wp, 80)          # conv_up3 out 0-63 | rgb_n 64-66 | rgb 67-69 | tri2 70-71 | alpha 72
         self.PROBS = self.raw("probs", 3 * P)           # planar trimap probabilities fed to the encoding
         self.CLS = self.raw("cls", P, torch.uint8)
@@ -573,21 +632,28 @@ class FramePlan:
             self.gn(S, t2, rf + l + ".bn2", RELU, out=o, residual=x, conv_p=cp)
             x = o
         self.conv(S, x, rf + "pred.0", h32, pad=1, act=LEAKY)
-        hid = self.SM.ch(0, 16)
-        self.conv(S, h32, rf + "pred.2", hid, pad=1, act=LEAKY)
-        S.append((lib.otvm_fba_head,
-                  (hid.ptr, hid.ld, sd[rf + "pred.4.weight"].data_ptr(), sd[rf + "pred.4.bias"].data_ptr(), 10,
-                   img.ptr, img.ld, P, self.ALPHA_P.data_ptr(), 1, self.TRI_P.data_ptr(),
-                   self.SM.ch(16, 8).ptr, self.SM.ld), "fba_head10"))
         self.steps["fba"] = S
+        for par in (0, 1):
+            S = []
+            SM = self.SMs[par]
+            hid = SM.ch(0, 16)
+            self.conv(S, h32, rf + "pred.2", hid, pad=1, act=LEAKY)
+            S.append((lib.otvm_fba_head,
+                      (hid.ptr, hid.ld, sd[rf + "pred.4.weight"].data_ptr(), sd[rf + "pred.4.bias"].data_ptr(), 10,
+                       img.ptr, img.ld, P, self.ALPHA_P.data_ptr(), 1, self.TRI_P.data_ptr(),
+                       SM.ch(16, 8).ptr, SM.ld), "fba_head10"))
+            self.steps["fba_tail%d" % par] = S
 
         # ---------------- STM memorize (STM.py:201-228); key/value convs are bound to a slot at run time
-        S = []
         m_ = "trimap.model.Encoder_M."
         stem = self.buf("m_stem", H2, W2, 64)
-        self.conv(S, self.SM, m_ + "stem", stem, stride=2, pad=3, act=RELU)
+        for par in (0, 1):
+            S = []
+            self.conv(S, self.SMs[par], m_ + "stem", stem, stride=2, pad=3, act=RELU)
+            self.steps["mem_stem%d" % par] = S
+        S = []
         self.r4m, _, _ = self.stm_trunk(S, stem, m_, "m_")
-        self.steps["memorize"] = S
+        self.steps["mem_trunk"] = S
         self.mem_ws = None
 
     # ------------------------------------------------------------------ run

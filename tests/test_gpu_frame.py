@@ -58,7 +58,7 @@ def stage_report(pl, cap, first_frame):
     d("l4", nchw(pl.PPMCAT.ch(0, 2048)), feats[5])
     d("x_dec", nchw(pl.D80.ch(0, 70)), cap["x_dec"])
     d("dec_alpha", nchw(pl.D80.ch(72, 1)), cap["dec_out"][:, :1])
-    d("hid", nchw(pl.SM.ch(0, 16)), cap["hid"])
+    d("hid", nchw(pl.SMs[pl.e.parity ^ 1].ch(0, 16)), cap["hid"])
     d("alpha_p", pl.ALPHA_P.reshape(1, 1, Hp, Wp).cpu(), cap["alpha_p"])
     d("tri_out_p", pl.TRI_P.reshape(1, 3, Hp, Wp).cpu(), cap["tri_out_p"])
     if not first_frame:
@@ -99,7 +99,7 @@ def run_sequence(model, synth_sd, meta, max_frames=None, precision="f16x3"):
         da = float((out[3].cpu() - ref[3]).abs().max())
         dt = float((out[1].cpu() - ref[1]).abs().max())
         results.append(dict(t=t, alpha=da, tri=dt, ties=ties, rep=rep, out=out, ref=ref,
-                            bank=[s["frame"] for s in eng_model._engine.bank], obank=[b[2] for b in orc.bank]))
+                            bank=eng_model.memories["frames"], obank=[b[2] for b in orc.bank]))
     return results
 
 
