@@ -284,6 +284,16 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 const int mb = m0 + (wm * TM + a) * 32;
+                // residual: all four 16-byte loads of this tile are issued before anything waits on them (the
+                // load -> add -> store chain per row group was latency-bound: 1.5 TB/s on the K=64 residual layers)
+                f32x4 rres[4];
+                const bool res_vec = p.residual && vec_ok && n4 + 3 < p.Cout;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int m = mb + r4 * 8 + prow;
+                    rres[r4] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (res_vec && m < p.M) rres[r4] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)m * p.res_ld + n4);
+                }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
 #pragma unroll
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
                     v = v * sc4 + bi4;
                     if (m < p.M) {
                         if (vec_ok && n4 + 3 < p.Cout) {
-                            if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (int64_t)m * p.res_ld + n4);
+                            v += rres[r4];
                             v.x = otvm_act(v.x, p.act); v.y = otvm_act(v.y, p.act);
                             v.z = otvm_act(v.z, p.act); v.w = otvm_act(v.w, p.act);
                             *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.out_ld + n4) = v;

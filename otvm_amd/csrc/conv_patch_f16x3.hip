@@ -197,6 +197,16 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
                 const int y = ty0 + wave * TM + a;
+                // residual: all four 16-byte loads of this tile are issued before anything waits on them
+                f32x4 rres[4];
+                const bool res_vec = p.residual && vec_ok && n4 + 3 < p.Cout;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int x = tx0 + r4 * 8 + prow;
+                    rres[r4] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (res_vec && y < p.H && x < p.W)
+                        rres[r4] = *reinterpret_cast<const f32x4*>(p.residual + ((int64_t)y * p.W + x) * p.res_ld + n4);
+                }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
 #pragma unroll
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
                     if (y < p.H && x < p.W) {
                         const int64_t m = (int64_t)y * p.W + x;
                         if (vec_ok && n4 + 3 < p.Cout) {
-                            if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + m * p.res_ld + n4);
+                            v += rres[r4];
                             v.x = otvm_act(v.x, p.act); v.y = otvm_act(v.y, p.act);
                             v.z = otvm_act(v.z, p.act); v.w = otvm_act(v.w, p.act);
                             *reinterpret_cast<f32x4*>(p.out + m * p.out_ld + n4) = v;
