@@ -16,6 +16,7 @@
 // (80-byte padded rows: conflict-free ds_read_b128), NW wave64 each owning TM x TN 32x32 accumulators.
 #include "common.h"
 #include <hip/hip_fp16.h>
+#include <stdlib.h>
 
 #ifndef OTVM_BRANCHY_LOADS
 #define OTVM_BRANCHY_LOADS 1
