@@ -45,16 +45,20 @@ __device__ __forceinline__ void split4p(const f32x4 v, f16x4& hi, f16x4& lo) {
                (_Float16)(v.w - (float)h23.y)};
 }
 
-// Per stage (16 input channels) a workgroup holds in LDS: the split input patch and the 9 taps' B fragments of its
-// BN output channels, copied verbatim from the fragment-major weight array (1-KiB blocks, lane-linear).
-template <int TH, int BN, int NW, int DIL>
+// Per stage (16 input channels) a workgroup holds in LDS the split input patch and, per group of TAPG taps, the B
+// fragments of its BN output channels, copied verbatim from the fragment-major weight array (1-KiB blocks).
+// TAPG = 9: one weight stage per channel stage (narrow layers); TAPG = 3: wide layers (BN = 256), where nine taps of
+// weights (144 KiB) would not fit beside the patch.
+template <int TH, int BN, int NW, int DIL, int TAPG>
 __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchArgs p) {
     constexpr int NT = NW * 64;
     constexpr int TM = TH / NW, TN = BN / 32;
     constexpr int PW = 32 + 2 * DIL, PH = TH + 2 * DIL, NPIX = PH * PW;
-    static_assert(TH % NW == 0 && BN % 32 == 0, "bad tile");
+    constexpr int NG = 9 / TAPG;
+    static_assert(TH % NW == 0 && BN % 32 == 0 && 9 % TAPG == 0, "bad tile");
     constexpr int PATCH_HALFS = 2 * NPIX * LDP;                        // hi + lo
-    constexpr int B_HALFS = 9 * TN * 2 * 512;                          // taps x channel tiles x (hi, lo) x 1 KiB
+    constexpr int B_PIECES = TAPG * TN * 2 * 64;                       // 16-byte pieces of one weight stage
+    constexpr int B_HALFS = B_PIECES * 8;
     constexpr int EPI_HALFS = NW * 32 * 36 * 2;                        // epilogue patches (fp32) expressed in halfs
     constexpr int SM_HALFS = PATCH_HALFS + B_HALFS > EPI_HALFS ? PATCH_HALFS + B_HALFS : EPI_HALFS;
     __shared__ __attribute__((aligned(16))) _Float16 smem[SM_HALFS];
@@ -84,94 +88,95 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
     const int nb0 = n0 >> 5;
     // register prefetch of the next stage (global -> registers under the MFMAs of the current stage)
     constexpr int NP = (NPIX * 4 + NT - 1) / NT;                       // patch float4 per thread
-    constexpr int NB = (9 * TN * 2 * 64 + NT - 1) / NT;                // B 16-byte pieces per thread
+    constexpr int NB = (B_PIECES + NT - 1) / NT;                       // B 16-byte pieces per thread
     f32x4 rp[NP];
     f16x8 rb[NB];
-    auto prefetch = [&](int cb) __attribute__((always_inline)) {
+    auto prefetch = [&](int cb, int g) __attribute__((always_inline)) {
         const int cb32 = cb >> 1, ks = cb & 1;
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int i = tid + k * NT;
-            if (i < 9 * TN * 2 * 64) {
-                const int l = i & 63, blk = i >> 6;                     // blk = (tap*TN + b)*2 + hl
-                const int hl = blk & 1, tb = blk >> 1, b = tb % TN, tap = tb / TN;
+            if (i < B_PIECES) {
+                const int l = i & 63, blk = i >> 6;                     // blk = (tapl*TN + b)*2 + hl
+                const int hl = blk & 1, tb = blk >> 1, b = tb % TN, tap = g * TAPG + tb / TN;
                 const int64_t src = (((((int64_t)cb32 * 9 + tap) * nbs + nb0 + b) * 2 + ks) * 2 + hl) * 512 + l * 8;
                 rb[k] = *reinterpret_cast<const f16x8*>(p.wf + src);
             }
         }
+        if (g == 0) {
 #pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const int idx = tid + k * NT;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (idx < NPIX * 4) {
-                const int pix = idx >> 2, c4 = (idx & 3) * 4;
-                const int py = pix / PW, px = pix - py * PW;
-                const int iy = ty0 - DIL + py, ix = tx0 - DIL + px;
-                if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                    v = *reinterpret_cast<const f32x4*>(p.in + ((int64_t)iy * p.W + ix) * p.in_ld + cb * CB + c4);
+            for (int k = 0; k < NP; ++k) {
+                const int idx = tid + k * NT;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (idx < NPIX * 4) {
+                    const int pix = idx >> 2, c4 = (idx & 3) * 4;
+                    const int py = pix / PW, px = pix - py * PW;
+                    const int iy = ty0 - DIL + py, ix = tx0 - DIL + px;
+                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                        v = *reinterpret_cast<const f32x4*>(p.in + ((int64_t)iy * p.W + ix) * p.in_ld + cb * CB + c4);
+                }
+                rp[k] = v;
             }
-            rp[k] = v;
         }
     };
-    auto commit = [&]() __attribute__((always_inline)) {
+    auto commit = [&](int g) __attribute__((always_inline)) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int i = tid + k * NT;
-            if (i < 9 * TN * 2 * 64) *reinterpret_cast<f16x8*>(&Bs[i * 8]) = rb[k];
+            if (i < B_PIECES) *reinterpret_cast<f16x8*>(&Bs[i * 8]) = rb[k];
         }
+        if (g == 0) {
 #pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const int idx = tid + k * NT;
-            if (idx < NPIX * 4) {
-                f32x4 v = rp[k];
-                if (p.in_relu) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            for (int k = 0; k < NP; ++k) {
+                const int idx = tid + k * NT;
+                if (idx < NPIX * 4) {
+                    f32x4 v = rp[k];
+                    if (p.in_relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                    f16x4 hi, lo;
+                    split4p(v, hi, lo);
+                    const int pix = idx >> 2, c4 = (idx & 3) * 4;
+                    *reinterpret_cast<f16x4*>(&Ph[pix * LDP + c4]) = hi;
+                    *reinterpret_cast<f16x4*>(&Pl[pix * LDP + c4]) = lo;
                 }
-                f16x4 hi, lo;
-                split4p(v, hi, lo);
-                const int pix = idx >> 2, c4 = (idx & 3) * 4;
-                *reinterpret_cast<f16x4*>(&Ph[pix * LDP + c4]) = hi;
-                *reinterpret_cast<f16x4*>(&Pl[pix * LDP + c4]) = lo;
             }
         }
     };
-    prefetch(0);
+    prefetch(0, 0);
     for (int cb = 0; cb < ncb; ++cb) {
-        __syncthreads();                                                // the previous stage's LDS reads are done
-        commit();
-        __syncthreads();
-        if (cb + 1 < ncb) prefetch(cb + 1);
-        // ---- 9 taps out of LDS
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int ky = tap / 3, kx = tap - ky * 3;
-            f16x8 bh[TN], bl[TN], ah[TM], al[TM];
+        for (int g = 0; g < NG; ++g) {
+            __syncthreads();                                            // the previous stage's LDS reads are done
+            commit(g);
+            __syncthreads();
+            if (g + 1 < NG) prefetch(cb, g + 1);
+            else if (cb + 1 < ncb) prefetch(cb + 1, 0);
+            // ---- TAPG taps out of LDS
 #pragma unroll
-            for (int b = 0; b < TN; ++b) {
-                bh[b] = *reinterpret_cast<const f16x8*>(&Bs[((tap * TN + b) * 2) * 512 + lane * 8]);
-                bl[b] = *reinterpret_cast<const f16x8*>(&Bs[((tap * TN + b) * 2 + 1) * 512 + lane * 8]);
+            for (int tl = 0; tl < TAPG; ++tl) {
+                const int tap = g * TAPG + tl;
+                const int ky = tap / 3, kx = tap - ky * 3;
+                f16x8 ah[TM], al[TM];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const int o = ((wave * TM + a + ky * DIL) * PW + kx * DIL + frow) * LDP + 8 * fh;
+                    ah[a] = *reinterpret_cast<const f16x8*>(&Ph[o]);
+                    al[a] = *reinterpret_cast<const f16x8*>(&Pl[o]);
+                }
+                // B fragments are read per channel tile right before use (keeps 8 instead of 8*TN operand registers live)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) {
+                    const f16x8 bh = *reinterpret_cast<const f16x8*>(&Bs[((tl * TN + b) * 2) * 512 + lane * 8]);
+                    const f16x8 bl = *reinterpret_cast<const f16x8*>(&Bs[((tl * TN + b) * 2 + 1) * 512 + lane * 8]);
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh, acc[a][b], 0, 0, 0);
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl, acc[a][b], 0, 0, 0);
+#pragma unroll
+                    for (int a = 0; a < TM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh, acc[a][b], 0, 0, 0);
+                }
             }
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
-                const int o = ((wave * TM + a + ky * DIL) * PW + kx * DIL + frow) * LDP + 8 * fh;
-                ah[a] = *reinterpret_cast<const f16x8*>(&Ph[o]);
-                al[a] = *reinterpret_cast<const f16x8*>(&Pl[o]);
-            }
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-#pragma unroll
-                for (int b = 0; b < TN; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
         }
     }
 
@@ -323,12 +328,12 @@ __global__ __launch_bounds__(256) void pack_patch_weight_kernel(const float* __r
     }
 }
 
-template <int TH, int BN, int NW, int DIL>
+template <int TH, int BN, int NW, int DIL, int TAPG = 9>
 int launch_patch(PatchArgs& a, hipStream_t s) {
     a.tiles_x = otvm_ceil_div(a.W, 32);
     a.tiles_y = otvm_ceil_div(a.H, TH);
     a.tiles_n = otvm_ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL>), dim3(a.tiles_x * a.tiles_y * a.tiles_n), dim3(NW * 64), 0, s, a);
+    hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL, TAPG>), dim3(a.tiles_x * a.tiles_y * a.tiles_n), dim3(NW * 64), 0, s, a);
     OTVM_CHECK_LAUNCH("otvm_conv2d(patch f16x3)");
     return 0;
 }
@@ -353,23 +358,28 @@ extern "C" int otvm_pack_patch_weight_f16x3(const float* w_packed, int O, int K_
 // returns -1 when the layer is not eligible (caller falls back to the implicit-GEMM kernel)
 int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream) {
     if (!p->w_frag || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->Cin % 16 != 0) return -1;
-    static const int max_cout = getenv("OTVM_PATCH_MAX_COUT") ? atoi(getenv("OTVM_PATCH_MAX_COUT")) : 64;
-    // wide layers: the 256x256 implicit-GEMM tile is faster, except 128..256 output channels on large maps (measured:
-    // 256->256 at 272x480: 307 vs 284 TFLOP/s; at 136x240: 201 vs 287)
-    const bool wide_ok = p->Cout <= 256 && p->dil == 1 && (int64_t)p->H * p->W >= 100000;
-    if (p->Cout > max_cout && !wide_ok) return -1;
-    if (p->dil != 1 && p->dil != 2 && p->dil != 4) return -1;
+    static const int wide = getenv("OTVM_PATCH_WIDE") ? atoi(getenv("OTVM_PATCH_WIDE")) : 1;
+    const bool is_wide = p->Cout > 64;
+    if (is_wide && (!wide || p->Cout % 256 != 0)) return -1;       // wide path: 256-channel tiles, 8 waves, 3-tap weight stages
     PatchArgs a;
     a.in = p->in; a.wf = (const _Float16*)p->w_frag; a.wscale = p->w_scale; a.bias = p->bias; a.residual = p->residual;
     a.out = p->out; a.gn_stats = p->gn_stats;
     a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.in_ld = p->in_ld; a.res_ld = p->res_ld; a.Cout = p->Cout; a.out_ld = p->out_ld;
     a.n_pad32 = (p->Cout + 31) / 32 * 32; a.in_relu = p->in_relu; a.act = p->act;
     hipStream_t s = (hipStream_t)stream;
-    if (p->dil == 1) {
-        if (p->Cout <= 32) return launch_patch<8, 32, 4, 1>(a, s);
-        if (p->Cout <= 64) return launch_patch<8, 64, 4, 1>(a, s);
-        return launch_patch<8, 128, 4, 1>(a, s);
+    if (is_wide) {
+        // needs enough 8x32 x 256-channel tiles to fill 256 CUs (OS4 maps at 1080p): 327 vs 285 TFLOP/s (256->256) and
+        // 390 vs 348 (512->256) against the implicit-GEMM kernel.  On smaller maps the implicit-GEMM tiles win
+        // (a 4x32-tile variant of this kernel measured 160-230 TFLOP/s vs 290-315 and was dropped).
+        const int64_t t8 = (int64_t)otvm_ceil_div(p->H, 8) * otvm_ceil_div(p->W, 32) * (p->Cout / 256);
+        if (t8 >= 400) {
+            if (p->dil == 1) return launch_patch<8, 256, 8, 1, 3>(a, s);
+            if (p->dil == 2) return launch_patch<8, 256, 8, 2, 3>(a, s);
+            return launch_patch<8, 256, 8, 4, 3>(a, s);
+        }
+        return -1;
     }
-    if (p->dil == 2) return p->Cout <= 64 ? launch_patch<8, 64, 4, 2>(a, s) : launch_patch<8, 128, 4, 2>(a, s);
-    return p->Cout <= 64 ? launch_patch<8, 64, 4, 4>(a, s) : launch_patch<8, 128, 4, 4>(a, s);
+    if (p->dil == 1) return p->Cout <= 32 ? launch_patch<8, 32, 4, 1>(a, s) : launch_patch<8, 64, 4, 1>(a, s);
+    if (p->dil == 2) return launch_patch<8, 64, 4, 2>(a, s);
+    return launch_patch<8, 64, 4, 4>(a, s);
 }
