@@ -55,7 +55,7 @@ class EvalModel(nn.Module):
 
     @torch.no_grad()
     def forward(self, a, fg, bg, tri=None, tri_gt=None, first_frame=False, last_frame=False, memorize=False,
-                max_memory_num=2, large_input=False, _frame_id=0, _cls_override=None):
+                max_memory_num=2, large_input=False, _frame_id=None, _cls_override=None):
         if tri is not None:
             # alpha/model.py:395-396: unreachable from eval.py (EvalDataset is built with trimap=None, eval.py:133)
             raise NotImplementedError("per-frame `tri` input is not part of the reference eval path")

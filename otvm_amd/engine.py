@@ -155,6 +155,7 @@ class HipEngine:
         self.stream = 0
         self.prof = None
         self.pending = None          # deferred memorize of the previous frame
+        self.frame_counter = 0
         self.parity = 0
         self.side = None
         import os
@@ -227,7 +228,7 @@ class HipEngine:
         return [float(x) for x in self.sd[key].flatten().tolist()]
 
     def frame(self, a, fg, bg, tri_gt=None, first_frame=False, last_frame=False, memorize=False, max_memory_num=2,
-              dilate_kernel=None, frame_id=0, cls_override=None):
+              dilate_kernel=None, frame_id=None, cls_override=None):
         """One call of EvalModel.forward (reference models/alpha/model.py:391-512) on the HIP path.
 
         a [1,1,1,H,W] in [0,1]; fg, bg [1,1,3,H,W] BGR 0..255; tri_gt [1,1,3,H,W] or None.
@@ -253,6 +254,10 @@ class HipEngine:
         if first_frame:
             self.pending = None
             self.reset()
+            self.frame_counter = 0
+        if frame_id is None:                                  # position in the sequence since the last first_frame
+            frame_id = self.frame_counter
+        self.frame_counter += 1
         pend, self.pending = self.pending, None
         if pend is not None and pend["plan"] is not pl:
             self._memorize(pend, stream)                      # resolution changed: finish it in order
