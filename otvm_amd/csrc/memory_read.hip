@@ -31,7 +31,7 @@ constexpr int LDS_S = BKV + 4;   // 68
 struct MemArgs {
     const float* q; int q_ld;
     const float* keys[8]; const float* vals[8];
-    int T, hw;
+    int T, hw, slot0;
     float* part_o;     // [T][hw][512]
     float* part_ml;    // [T][hw][2]
 };
@@ -44,9 +44,9 @@ __global__ __launch_bounds__(256) void memory_read_partial_kernel(const MemArgs 
     __shared__ float m_run[BQ], l_run[BQ], alpha_l[BQ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q0 = blockIdx.x * BQ, slot = blockIdx.y;
-    const float* __restrict__ Kg = p.keys[slot];
-    const float* __restrict__ Vg = p.vals[slot];
+    const int q0 = blockIdx.x * BQ, slot = p.slot0 + blockIdx.y;
+    const float* __restrict__ Kg = p.keys[blockIdx.y];
+    const float* __restrict__ Vg = p.vals[blockIdx.y];
     const int hw = p.hw;
 
     // Q tile -> LDS (rows beyond hw zero-filled)
@@ -235,16 +235,20 @@ extern "C" int64_t otvm_memory_read_ws_bytes(int hw, int T) { return (int64_t)T 
 
 extern "C" int otvm_memory_read(const float* q_key, int q_ld, const float* const* keys, const float* const* vals, int T,
                                 int hw, float* out, int out_ld, void* ws, void* stream) {
-    OTVM_REQUIRE(T >= 1 && T <= 8, "otvm_memory_read: T=%d out of range [1,8]", T);
+    OTVM_REQUIRE(T >= 1 && T <= 4096, "otvm_memory_read: T=%d out of range [1,4096]", T);
     OTVM_REQUIRE(q_key && keys && vals && out && ws && hw > 0, "otvm_memory_read: bad arguments");
     OTVM_REQUIRE(q_ld % 4 == 0 && out_ld % 4 == 0, "otvm_memory_read: views must be 16-byte aligned");
     MemArgs a;
     a.q = q_key; a.q_ld = q_ld; a.T = T; a.hw = hw;
-    for (int t = 0; t < 8; ++t) { a.keys[t] = t < T ? keys[t] : nullptr; a.vals[t] = t < T ? vals[t] : nullptr; }
     a.part_o = (float*)ws;
     a.part_ml = a.part_o + (int64_t)T * hw * DV;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(memory_read_partial_kernel, dim3(otvm_ceil_div(hw, BQ), T), dim3(256), 0, s, a);
+    for (int s0 = 0; s0 < T; s0 += 8) {            // 8 slots per launch (see memory_read_f16x3.hip)
+        const int n = T - s0 < 8 ? T - s0 : 8;
+        a.slot0 = s0;
+        for (int t = 0; t < 8; ++t) { a.keys[t] = t < n ? keys[s0 + t] : nullptr; a.vals[t] = t < n ? vals[s0 + t] : nullptr; }
+        hipLaunchKernelGGL(memory_read_partial_kernel, dim3(otvm_ceil_div(hw, BQ), n), dim3(256), 0, s, a);
+    }
     OTVM_CHECK_LAUNCH("otvm_memory_read");
     return otvm_memory_read_combine(a.part_o, a.part_ml, T, hw, out, out_ld, stream);
 }

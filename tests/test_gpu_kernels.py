@@ -200,7 +200,7 @@ def test_maxpool_upsample_ppm(G):
         base += s * s
 
 
-@pytest.mark.parametrize("T,h,w", [(1, 5, 7), (2, 8, 12), (5, 9, 13), (3, 16, 20)])
+@pytest.mark.parametrize("T,h,w", [(1, 5, 7), (2, 8, 12), (5, 9, 13), (3, 16, 20), (19, 6, 11)])
 def test_memory_read(G, T, h, w):
     from oracle.otvm_oracle import memory_read
     from otvm_amd import lib as L
