@@ -57,6 +57,61 @@ def run_sequence(H, W, T, style, skip, max_num, dk, clip_seed, wseed=0):
                 tri_gt=out[2][0, 0].numpy().copy(), key_probe=np.concatenate(keys0))
 
 
+def stage_fixture(H=64, W=64, clip_seed=6, dk=12):
+    """Per-stage tensors of the REFERENCE (forward hooks) for two consecutive frames."""
+    m = build_reference_model(dk)
+    m.load_state_dict(synthetic_state_dict(0), strict=True)
+    cap = {}
+    stm = m.trimap.model
+
+    def keep(name):
+        def hook(mod, inp, out):
+            cap.setdefault(name, []).append(out)
+        return hook
+    stm.Encoder_Q.register_forward_hook(keep("enc_q"))
+    stm.Encoder_M.register_forward_hook(keep("enc_m"))
+    stm.KV_Q_r4.register_forward_hook(keep("kv_q"))
+    stm.KV_M_r4.register_forward_hook(keep("kv_m"))
+    stm.Memory.register_forward_hook(keep("mem"))
+    stm.Decoder.register_forward_hook(keep("dec"))
+    def enc_hook(mod, i, o):                       # (a hook must return None, or it replaces the output)
+        cap.setdefault("x11", []).append(i[0])
+        cap.setdefault("feats", []).append(o[0])
+    m.NET.encoder.register_forward_hook(enc_hook)
+    m.NET.decoder.register_forward_hook(keep("fba_dec"))
+    m.NET.refine.register_forward_hook(keep("fba_ref"))
+    frames, tri = synthetic_clip(H, W, 2, clip_seed)
+    for t in range(2):
+        a, fg, bg, tri_gt = frame_inputs(frames, t, trimap=tri)
+        m(a, fg, bg, tri=None, tri_gt=tri_gt, first_frame=(t == 0), last_frame=False, memorize=(t == 0), max_memory_num=5)
+    f = lambda x: x.detach().numpy().copy()
+    out = dict(H=H, W=W, clip_seed=clip_seed, dk=dk)
+    out["r4_q"], out["r3_q"], out["r2_q"] = (f(v) for v in cap["enc_q"][0][:3])
+    out["k4"], out["v4"] = (f(v) for v in cap["kv_q"][0])
+    out["m4"] = f(cap["mem"][0])
+    out["seg_logits"] = f(cap["dec"][0])
+    for t in range(2):
+        out["x11_%d" % t] = f(cap["x11"][t])
+        out["l1_%d" % t] = f(cap["feats"][t][2])
+        out["l4_%d" % t] = f(cap["feats"][t][5])
+        out["dec_hid_%d" % t], out["dec_out_%d" % t] = f(cap["fba_dec"][t][0]), f(cap["fba_dec"][t][1])
+        out["hid_%d" % t], out["ref7_%d" % t], out["tri_logits_%d" % t] = (f(v) for v in cap["fba_ref"][t])
+        out["r4_m_%d" % t] = f(cap["enc_m"][t][0])
+        out["key_m_%d" % t], out["val_m_%d" % t] = (f(v) for v in cap["kv_m"][t])
+    return out
+
+
+def self_noise(H, W, T, style, skip, max_num, dk, clip_seed):
+    """Reference vs reference with a different fp32 summation order (oneDNN off): the floor any fp32
+    re-implementation is compared against.  Per-frame alpha max-abs and class flips."""
+    torch.backends.mkldnn.enabled = False
+    try:
+        res = run_sequence(H, W, T, style, skip, max_num, dk, clip_seed)
+    finally:
+        torch.backends.mkldnn.enabled = True
+    return res
+
+
 def op_fixtures():
     """Per-function vectors from the reference's own functions."""
     load_reference()
@@ -124,10 +179,15 @@ def main():
     for (name, H, W, T, style, skip, max_num, dk, cs) in SEQUENCES:
         res = run_sequence(H, W, T, style, skip, max_num, dk, cs)
         np.savez_compressed(os.path.join(HERE, "seq_%s.npz" % name), **res)
+        alt = self_noise(H, W, T, style, skip, max_num, dk, cs)
+        noise = [float(np.abs(alt["alpha"][t] - res["alpha"][t]).max()) for t in range(T)]
+        flips = [int((alt["trimap"][t].argmax(0) != res["trimap"][t].argmax(0)).sum()) for t in range(T)]
         meta[name] = dict(H=H, W=W, T=T, style=style, skip=skip, max_num=max_num, dilate_kernel=dk,
-                          clip_seed=cs, weight_seed=0, bank=res["bank"].tolist())
+                          clip_seed=cs, weight_seed=0, bank=res["bank"].tolist(),
+                          reference_self_noise_alpha_maxabs=noise, reference_self_noise_trimap_flips=flips)
         print(name, "bank", res["bank"].tolist(), "alpha mean %.4f" % res["alpha"].mean())
     np.savez_compressed(os.path.join(HERE, "ops.npz"), **op_fixtures())
+    np.savez_compressed(os.path.join(HERE, "stages_64x64.npz"), **stage_fixture())
     json.dump(meta, open(os.path.join(HERE, "sequences.json"), "w"), indent=1)
 
 

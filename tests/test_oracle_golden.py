@@ -99,3 +99,35 @@ def test_oracle_sequence_vs_reference(name, synth_sd):
         # bitwise on the machine that generated the fixtures; 1e-3 is the fp32 contract elsewhere
         assert da <= 1e-3 and dt <= 5e-3, (name, t, da, dt)
     np.testing.assert_array_equal(out[2][0, 0].numpy(), gold["tri_gt"])
+
+
+def test_oracle_stages_vs_reference(synth_sd):
+    """Per-stage tensors of two consecutive frames (reference forward hooks) against the oracle's captures."""
+    from otvm_amd.synth_data import synthetic_clip
+    g = np.load(os.path.join(GOLDEN, "stages_64x64.npz"))
+    H, W = int(g["H"]), int(g["W"])
+    frames, tri = synthetic_clip(H, W, 2, int(g["clip_seed"]))
+    orc = O.OtvmOracle(synth_sd, dilate_kernel=int(g["dk"]))
+    for t in range(2):
+        fg = torch.from_numpy(frames[t].astype(np.float32)).permute(2, 0, 1)[None, None].contiguous()
+        a = torch.ones(1, 1, 1, H, W)
+        cap = {}
+        orc.frame(a, fg, fg.clone(), tri_gt=torch.from_numpy(tri)[None, None], first_frame=(t == 0), last_frame=False,
+                  memorize=(t == 0), max_memory_num=5, frame_id=t, capture=cap)
+        pairs = [("x11_%d" % t, cap["x11"]), ("l1_%d" % t, cap["feats"][2]), ("l4_%d" % t, cap["feats"][5]),
+                 ("dec_hid_%d" % t, cap["dec_hid"]), ("dec_out_%d" % t, cap["dec_out"]), ("hid_%d" % t, cap["hid"]),
+                 ("ref7_%d" % t, cap["ref7"]), ("tri_logits_%d" % t, cap["tri_logits"]),
+                 ("key_m_%d" % t, cap["new_kv"][0][None]), ("val_m_%d" % t, cap["new_kv"][1][None])]
+        if t == 1:
+            pairs += [("r4_q", cap["r4"]), ("r3_q", cap["r3"]), ("r2_q", cap["r2"]), ("k4", cap["k4"]), ("v4", cap["v4"]),
+                      ("m4", cap["m4"]), ("seg_logits", cap["seg_logits"])]
+        for name, got in pairs:
+            ref = g[name]
+            d = float(np.abs(got.numpy() - ref).max())
+            assert d <= 2e-4 * max(1.0, float(np.abs(ref).max())), (name, d)
+
+
+def test_reference_self_noise_is_recorded():
+    """The fixtures carry the reference's own fp32 reorder noise (oneDNN on/off) as the tolerance floor."""
+    for name, meta in META.items():
+        assert len(meta["reference_self_noise_alpha_maxabs"]) == meta["T"]
