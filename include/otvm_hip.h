@@ -190,6 +190,13 @@ int otvm_trimap_from_alpha(const float* a, int H, int W, int r, float* out, void
 /* one-hot of the argmax of a planar [3,H,W] trimap (alpha/model.py:356-362, returned tri_gt) */
 int otvm_onehot_argmax3(const float* tri, int64_t P, float* out, void* stream);
 
+/* ---------------------------------------------------------------- metrics ------
+ * SAD / MSE / dtSSD partial sums of one frame (reference utils/tmp/metric.py:177-189,252-264) on 8-bit alphas
+ * [n] = trunc(alpha*255) (eval.py:209); mask (unknown band) and the prev_* pointers may be NULL.  acc[5] (fp64,
+ * caller-zeroed) accumulates  sum|p-t|m, sum(p-t)^2 m, sum m, sum((p-p')-(t-t'))^2 m', sum m'  -- integer-exact. */
+int otvm_matting_metrics(const uint8_t* pred, const uint8_t* target, const uint8_t* mask, const uint8_t* prev_pred,
+                         const uint8_t* prev_target, const uint8_t* prev_mask, int64_t n, double* acc, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

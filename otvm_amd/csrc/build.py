@@ -21,6 +21,7 @@ SOURCES = [
     ("edt.hip", ["-ffp-contract=off"]),
     ("memory_read.hip", []),
     ("memory_read_f16x3.hip", []),
+    ("metrics.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -63,6 +63,7 @@ _PROTOS = {
     "otvm_crop_outputs": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "otvm_trimap_from_alpha": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "otvm_onehot_argmax3": (i32, [vp, i64, vp, vp]),
+    "otvm_matting_metrics": (i32, [vp, vp, vp, vp, vp, vp, i64, vp, vp]),
 }
 
 EXPORTED = sorted(list(_PROTOS) + ["otvm_last_error"])

@@ -38,7 +38,8 @@ def trimap_file_to_onehot(tri):
 
 @torch.no_grad()
 def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, skip=10, max_num=5,
-                    frames_are_rgb=False, on_frame=None, device=None, keep_on_device=False):
+                    frames_are_rgb=False, on_frame=None, device=None, keep_on_device=False, gt_alpha_u8=None,
+                    gt_mask_u8=None):
     """Matte one sequence.
 
     model       : EvalModel (optionally wrapped in nn.DataParallel), on the GPU
@@ -46,6 +47,8 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
     trimap      : first-frame trimap, one-hot float [3,H,W] (demo flow, dataset.py:866-893) or None
     alphas      : per-frame GT alpha [H,W] in [0,1] (VideoMatting108 flow: first-frame trimap derived
                   from alpha with the model's dilate kernel) -- required when trimap is None
+    gt_alpha_u8 : optional per-frame ground-truth alpha, uint8 [H,W]; with it SAD/MSE/dtSSD are accumulated on
+                  the device (ClipMetrics) and returned under "metrics"; gt_mask_u8 = optional {0,1} evaluation masks
     backgrounds : optional per-frame BG images (V108 composites fg*a + bg*(1-a)); default bg = fg
     Returns dict(alpha=[T,H,W] float32, alpha_u8=[T,H,W] uint8 (truncated, eval.py:209), trimap=[T,3,H,W]).
     """
@@ -54,6 +57,7 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
     dev = device or next(model.parameters()).device
     out_a, out_u8, out_t = [], [], []
     core = model.module if hasattr(model, "module") else model
+    metrics = ClipMetrics(dev) if gt_alpha_u8 is not None else None
     for i in range(T):
         fr = frames[i]
         f = fr if torch.is_tensor(fr) else torch.from_numpy(np.ascontiguousarray(fr))
@@ -82,13 +86,55 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
                     memorize=memorize, max_memory_num=max_memory_num, large_input=large)
         alpha = out[3][0, 0, 0]
         u8 = core._engine.last_alpha_u8
+        if metrics is not None:
+            g = gt_alpha_u8[i]
+            g = g if torch.is_tensor(g) else torch.from_numpy(np.ascontiguousarray(g))
+            mk = None
+            if gt_mask_u8 is not None:
+                mk = gt_mask_u8[i]
+                mk = (mk if torch.is_tensor(mk) else torch.from_numpy(np.ascontiguousarray(mk))).to(dev)
+            metrics.add(u8, g.to(dev), mk)
         if on_frame is not None:
             on_frame(i, alpha, u8, out)
         if keep_on_device:
             out_a.append(alpha), out_u8.append(u8), out_t.append(out[1][0, 0])
         else:
             out_a.append(alpha.cpu()), out_u8.append(u8.cpu()), out_t.append(out[1][0, 0].cpu())
-    return dict(alpha=torch.stack(out_a), alpha_u8=torch.stack(out_u8), trimap=torch.stack(out_t))
+    res = dict(alpha=torch.stack(out_a), alpha_u8=torch.stack(out_u8), trimap=torch.stack(out_t))
+    if metrics is not None:
+        res["metrics"] = metrics.result()
+    return res
+
+
+class ClipMetrics:
+    """SAD / MSE / dtSSD of a clip accumulated on the device (otvm_matting_metrics), reference definitions
+    utils/tmp/metric.py:177-189,252-264 on the 8-bit alphas the path writes (eval.py:209)."""
+
+    def __init__(self, device):
+        from . import lib as L
+        self.L, self.lib = L, L.load()
+        self.acc = torch.zeros(5, dtype=torch.float64, device=device)
+        self.prev = None
+        self.frames = 0
+        self.sad_per_frame = []
+
+    def add(self, pred_u8, target_u8, mask_u8=None):
+        """pred/target: uint8 [H,W] device tensors (0..255); mask: uint8 {0,1} or None (all pixels)."""
+        st = torch.cuda.current_stream(pred_u8.device).cuda_stream
+        pred_u8, target_u8 = pred_u8.contiguous(), target_u8.contiguous()
+        mask_u8 = None if mask_u8 is None else mask_u8.contiguous()
+        pp, tp, mp = self.prev if self.prev is not None else (None, None, None)
+        ptr = lambda x: 0 if x is None else x.data_ptr()
+        self.L.check(self.lib.otvm_matting_metrics(ptr(pred_u8), ptr(target_u8), ptr(mask_u8), ptr(pp), ptr(tp), ptr(mp),
+                                                   pred_u8.numel(), self.acc.data_ptr(), st), "matting_metrics")
+        self.prev = (pred_u8, target_u8, mask_u8)
+        self.frames += 1
+
+    def result(self):
+        a = self.acc.tolist()
+        return dict(frames=self.frames, sad_sum=a[0] / 255.0 / 1000.0, mse_num=a[1] / 255.0 ** 2, mask_sum=a[2],
+                    dt_err2_sum=a[3] / 255.0 ** 2, dt_mask_sum=a[4],
+                    sad_mean=a[0] / 255.0 / 1000.0 / max(1, self.frames))
 
 
 def sad(pred, ref, mask=None):

@@ -112,6 +112,25 @@ def self_noise(H, W, T, style, skip, max_num, dk, clip_seed):
     return res
 
 
+def metric_fixtures():
+    """SAD / MSE / dtSSD from the reference's own BatchMetric methods (utils/tmp/metric.py:177-189,252-264).
+    The module imports skimage (absent here) at the top; only for this import a stub module is registered."""
+    import types
+    load_reference()
+    sk = types.ModuleType("skimage"); skm = types.ModuleType("skimage.measure"); sk.measure = skm
+    sys.modules.setdefault("skimage", sk); sys.modules.setdefault("skimage.measure", skm)
+    from utils.tmp.metric import BatchMetric                    # reference utils/tmp/metric.py:89
+    rng = np.random.Generator(np.random.PCG64(11))
+    B, H, W = 5, 23, 31
+    pred = torch.from_numpy(rng.integers(0, 256, (B, H, W)).astype(np.float32))
+    target = torch.from_numpy(rng.integers(0, 256, (B, H, W)).astype(np.float32))
+    mask = torch.from_numpy((rng.uniform(0, 1, (B, H, W)) < 0.4).astype(np.float32))
+    bm = BatchMetric.__new__(BatchMetric)
+    e, n = bm.dtSSD(pred, target, mask)
+    return dict(met_pred=pred.numpy(), met_target=target.numpy(), met_mask=mask.numpy(),
+                met_sad=bm.BatchSAD(pred, target, mask), met_mse=bm.BatchMSE(pred, target, mask), met_dt_err=e, met_dt_num=n)
+
+
 def op_fixtures():
     """Per-function vectors from the reference's own functions."""
     load_reference()
@@ -186,7 +205,9 @@ def main():
                           clip_seed=cs, weight_seed=0, bank=res["bank"].tolist(),
                           reference_self_noise_alpha_maxabs=noise, reference_self_noise_trimap_flips=flips)
         print(name, "bank", res["bank"].tolist(), "alpha mean %.4f" % res["alpha"].mean())
-    np.savez_compressed(os.path.join(HERE, "ops.npz"), **op_fixtures())
+    ops = op_fixtures()
+    ops.update(metric_fixtures())
+    np.savez_compressed(os.path.join(HERE, "ops.npz"), **ops)
     np.savez_compressed(os.path.join(HERE, "stages_64x64.npz"), **stage_fixture())
     json.dump(meta, open(os.path.join(HERE, "sequences.json"), "w"), indent=1)
 

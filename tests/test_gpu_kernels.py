@@ -360,3 +360,26 @@ def test_glue_kernels(G):
     L.check(lib.otvm_onehot_argmax3(td.data_ptr(), H * W, oh.data_ptr(), G.stream()))
     torch.cuda.synchronize()
     assert torch.equal(oh.reshape(3, H, W).cpu(), F.one_hot(tri.max(0)[1], 3).permute(2, 0, 1).float())
+
+
+def test_matting_metrics(G):
+    """On-device SAD / MSE / dtSSD (integer-exact sums) against the metrics oracle and the reference-generated fixture."""
+    import os
+    from oracle import metrics_oracle as M
+    from otvm_amd.video import ClipMetrics
+    from tests.common import GOLDEN
+    ops = np.load(os.path.join(GOLDEN, "ops.npz"))
+    p, t, m = (torch.from_numpy(ops[k]) for k in ("met_pred", "met_target", "met_mask"))
+    cm = ClipMetrics(G.DEV)
+    for i in range(p.shape[0]):
+        cm.add(p[i].to(torch.uint8).to(G.DEV), t[i].to(torch.uint8).to(G.DEV), m[i].to(torch.uint8).to(G.DEV))
+    torch.cuda.synchronize()
+    r = cm.result()
+    assert abs(r["sad_sum"] - float(ops["met_sad"].sum())) <= 1e-6 * float(ops["met_sad"].sum())
+    assert abs(r["sad_sum"] - float(M.sad(p, t, m).double().sum())) <= 1e-6
+    # MSE / dtSSD are per-frame ratios in the reference; the device accumulates their exact numerators/denominators
+    num = float(((p - t).double().pow(2) * m.double()).sum()) / 255.0 ** 2
+    assert abs(r["mse_num"] - num) <= 1e-9 * num and r["mask_sum"] == float(m.sum())
+    e, n = M.dtssd(p, t, m)
+    assert abs(r["dt_err2_sum"] - float(e.double().pow(2).sum())) <= 1e-5 * r["dt_err2_sum"]
+    assert r["dt_mask_sum"] == float(m[:-1].sum())

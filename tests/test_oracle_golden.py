@@ -131,3 +131,13 @@ def test_reference_self_noise_is_recorded():
     """The fixtures carry the reference's own fp32 reorder noise (oneDNN on/off) as the tolerance floor."""
     for name, meta in META.items():
         assert len(meta["reference_self_noise_alpha_maxabs"]) == meta["T"]
+
+
+def test_metrics_oracle_vs_reference(ops):
+    from oracle import metrics_oracle as M
+    p, t, m = (torch.from_numpy(ops[k]) for k in ("met_pred", "met_target", "met_mask"))
+    np.testing.assert_allclose(M.sad(p, t, m).numpy(), ops["met_sad"], rtol=1e-6)
+    np.testing.assert_allclose(M.mse(p, t, m).numpy(), ops["met_mse"], rtol=1e-6)
+    e, n = M.dtssd(p, t, m)
+    np.testing.assert_allclose(e.numpy(), ops["met_dt_err"], rtol=1e-6)
+    np.testing.assert_allclose(n.numpy(), ops["met_dt_num"], rtol=0)
