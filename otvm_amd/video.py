@@ -52,7 +52,7 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
     backgrounds : optional per-frame BG images (V108 composites fg*a + bg*(1-a)); default bg = fg
     Returns dict(alpha=[T,H,W] float32, alpha_u8=[T,H,W] uint8 (truncated, eval.py:209), trimap=[T,3,H,W]).
     """
-    frames = list(frames) if not hasattr(frames, "shape") else frames
+    frames = list(frames) if not (hasattr(frames, "shape") or hasattr(frames, "__getitem__")) else frames
     T = len(frames)
     dev = device or next(model.parameters()).device
     out_a, out_u8, out_t = [], [], []

@@ -155,3 +155,27 @@ def test_cpu_module_fails_loudly(synth_sd):
     with pytest.raises(RuntimeError):
         m(torch.ones(1, 1, 1, 32, 32), torch.zeros(1, 1, 3, 32, 32), torch.zeros(1, 1, 3, 32, 32),
           tri_gt=torch.zeros(1, 1, 3, 32, 32), first_frame=True)
+
+
+def test_io_pipeline_matches_direct_run(model, synth_sd):
+    """JPEG decode -> pinned upload -> matte -> async PNG encode gives exactly the alphas of the direct call."""
+    import io
+    from PIL import Image
+    from otvm_amd.io_pipeline import run_video_matte_io
+    from otvm_amd.synth_data import synthetic_clip
+    from otvm_amd.video import run_video_matte
+    H, W, T = 72, 104, 6
+    frames_bgr, tri = synthetic_clip(H, W, T, seed=31)
+    enc = []
+    for t in range(T):
+        buf = io.BytesIO()
+        Image.fromarray(frames_bgr[t][..., ::-1].copy()).save(buf, format="PNG")          # lossless, RGB
+        enc.append(buf.getvalue())
+    m = model(12).module
+    r_io = run_video_matte_io(m, enc, trimap=tri, skip=3, max_num=3, keep_encoded=True)
+    rgb = [np.asarray(Image.open(io.BytesIO(b)).convert("RGB")) for b in enc]
+    r_dir = run_video_matte(m, rgb, trimap=tri, skip=3, max_num=3, frames_are_rgb=True)
+    assert torch.equal(r_io["alpha"].cpu(), r_dir["alpha"])
+    for t in range(T):
+        back = np.asarray(Image.open(io.BytesIO(r_io["encoded"][t])))
+        assert np.array_equal(back, r_dir["alpha_u8"][t].numpy())
