@@ -65,9 +65,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     constexpr int B_ROWS = NT / 4, B_LD = (BN + B_ROWS - 1) / B_ROWS;   // 4 x 16 bytes per 32-half row
     static_assert(A_LD >= 1 && B_LD >= 1 && TM >= 1 && TN >= 1, "bad tile");
     constexpr int STAGE = 2 * (BM + BN) * LDH;                 // halfs per LDS stage (A_hi, A_lo, B_hi, B_lo)
-    // Two LDS stages + one barrier per chunk measured no faster than one stage + two barriers on the big tiles
-    // (295 vs 297 TFLOP/s at 256x256) and slower on the small ones (occupancy); kept selectable for experiments.
-    constexpr bool DBUF = false;
+    // Two LDS stages + one barrier per chunk on the 256-row tiles (+5..14 % on the layers that use them; the smaller
+    // tiles lose more from the halved occupancy than they gain: 32.7 vs 33.1 frames/s with DBUF everywhere).
+    constexpr bool DBUF = BM == 256 && BN >= 128;
     __shared__ __attribute__((aligned(16))) _Float16 smem[(DBUF ? 2 : 1) * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -240,14 +240,19 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
         store_chunk(0);
         if (p.nchunks > 1) load_chunk(1);
         __syncthreads();
-        for (int c = 0; c < p.nchunks; ++c) {
+        // the conversion of chunk c+1 sits between the two k-steps of chunk c in ONE basic block (no branch around
+        // it: the last chunk is peeled), so the scheduler can interleave its VALU / LDS writes with the MFMAs
+        int c = 0;
+        for (; c + 1 < p.nchunks; ++c) {
             const int buf = c & 1;
             compute_ks(buf, 0);
-            if (c + 1 < p.nchunks) store_chunk(buf ^ 1);
+            store_chunk(buf ^ 1);
             if (c + 2 < p.nchunks) load_chunk(c + 2);
             compute_ks(buf, 1);
             __syncthreads();
         }
+        compute_ks(c & 1, 0);
+        compute_ks(c & 1, 1);
     } else {
         for (int c = 0; c < p.nchunks; ++c) {
             __syncthreads();
@@ -326,7 +331,10 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     }
     // ---- fused GroupNorm statistics of the tile just written (sum / sum of squares per group, fp64 atomics)
     if (p.gn_stats) {
-        __shared__ double gred[2 * BN];                     // at most BN/2 groups per tile, (sum, sumsq) each
+        // (sum, sumsq) per group of the tile, at most BN/2 groups; lives behind the waves' epilogue patches in the
+        // stage memory (the two-stage 256x256 tile uses the whole 160 KB of LDS)
+        static_assert((NT / 64) * (32 * 36 * 4) + 2 * BN * 8 <= STAGE * 2, "gred does not fit behind the patches");
+        double* gred = reinterpret_cast<double*>(reinterpret_cast<char*>(smem) + (NT / 64) * (32 * 36 * 4));
         const int cg = p.Cout >> 5;                         // channels per group (>= 2)
         const int seg = cg < 32 ? cg : 32;                  // lanes of one 32-column tile that share a group
         for (int i = threadIdx.x; i < 2 * BN; i += blockDim.x) gred[i] = 0.0;

@@ -46,6 +46,9 @@ CONV_CASES = [
     (2048, 256, 1, 1, 0, 1, 6, 6, True, 0, 0, False),
     (64, 64, 3, 1, 1, 1, 130, 258, False, 0, 0, False),     # > 256*128 pixels -> the 128x64 tile
     (512, 2048, 1, 1, 0, 1, 40, 70, False, 0, 0, False),    # many tiles -> the 128x128 tile
+    (96, 256, 1, 1, 0, 1, 352, 353, True, 1, 1, True),      # large M, Cout 256: the two-stage 256-row tiles
+    (40, 128, 3, 2, 1, 1, 704, 705, True, 2, 0, False),     # large M, generic K decode (Cin % 32 != 0), stride 2
+    (64, 384, 1, 1, 0, 1, 351, 353, False, 0, 0, False),    # ragged M and N tiles on the big tiles
 ]
 
 
@@ -89,6 +92,22 @@ def test_conv_fused_groupnorm_stats(G, prec, Cin, Cout, H, W):
     G.conv2d(G.to_act(x), G.pack_weight(w), out, b.to(G.DEV), pad=1, precision=prec, gn_stats=stats)
     got = stats.cpu()
     assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def test_conv_big_tile_fused_groupnorm_stats(G):
+    """GroupNorm sums out of the two-stage 256-row tiles (the group sums live behind the epilogue patches in LDS)."""
+    Cin, Cout, H, W = 64, 256, 352, 353
+    x = rnd(1, Cin, H, W, seed=73)
+    w = rnd(Cout, Cin, 1, 1, seed=74, scale=1.0 / math.sqrt(Cin))
+    b = rnd(Cout, seed=75)
+    ref = F.conv2d(x, w, b).double()
+    g = ref.reshape(32, Cout // 32, H * W)
+    want = torch.stack([g.sum((1, 2)), (g * g).sum((1, 2))], 1).flatten()
+    stats = torch.zeros(64, dtype=torch.float64, device=G.DEV)
+    out = G.empty_act(H, W, Cout)
+    G.conv2d(G.to_act(x), G.pack_weight(w), out, b.to(G.DEV), precision=1, gn_stats=stats)
+    assert G.maxdiff(G.from_act(out), ref.float()) <= 2e-5 * float(ref.abs().max())
+    assert float((stats.cpu() - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
 def test_f16x3_is_fp32_class(G):
