@@ -39,7 +39,8 @@ int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
  * Pack an OIHW fp32 conv weight into the K-major layout the implicit-GEMM kernel reads:
- * w_packed[O_pad][K_pad], k = (ky*kw + kx)*I_pad + c, zero padded.
+ * w_packed[O_pad][K_pad], k = (ky*kw + kx)*I_pad + c, zero padded.  otvm_conv2d reads whole N tiles of
+ * weight rows: O_pad must be O rounded up to a multiple of 128 (the same holds for w_hi / w_lo).
  *   ws != 0  : apply weight standardisation first (layers_WS.py:15-21: subtract per-filter mean,
  *              divide by sqrt(unbiased var + 1e-12) + 1e-5) -- done ONCE here instead of per forward.
  *   scale    : optional per-output-channel multiplier (BatchNorm eval fold gamma/sqrt(var+eps),

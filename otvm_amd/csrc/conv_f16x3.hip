@@ -468,7 +468,9 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     const int64_t M = a.M;
     if (p->Cout <= 32) return launch3<256, 32, 4, 1>(a, s);
     if (p->Cout <= 64) return (M >= 256 * 128) ? launch3<256, 64, 4, 1>(a, s) : launch3<64, 64, 2, 2>(a, s);
-    if (p->Cout >= 256) {
+    // the weight arrays hold O_pad = Cout rounded up to 128 rows (include/otvm_hip.h): a 256-wide N tile may only be
+    // used when that is a multiple of 256, or its last tile would read rows past the allocation
+    if (p->Cout >= 256 && (otvm_ceil_div(p->Cout, 128) & 1) == 0) {
         const int64_t huge = (int64_t)otvm_ceil_div(M, 256) * otvm_ceil_div(p->Cout, 256);
         if (huge >= 480) return launch3<256, 256, 4, 2>(a, s);
     }

@@ -231,7 +231,13 @@ int otvm_memory_read_combine(const float* part_o, const float* part_ml, int T, i
     return 0;
 }
 
-extern "C" int64_t otvm_memory_read_ws_bytes(int hw, int T) { return (int64_t)T * hw * (DV + 2) * sizeof(float); }
+int otvm_memory_read_f16x3_partials(int T, int hw);     // memory_read_f16x3.hip
+
+extern "C" int64_t otvm_memory_read_ws_bytes(int hw, int T) {
+    // one partial (O block + running max / sum) per slot here, per memory-axis chunk in the f16x3 kernel
+    const int np3 = otvm_memory_read_f16x3_partials(T, hw);
+    return (int64_t)(np3 > T ? np3 : T) * hw * (DV + 2) * sizeof(float);
+}
 
 extern "C" int otvm_memory_read(const float* q_key, int q_ld, const float* const* keys, const float* const* vals, int T,
                                 int hw, float* out, int out_ld, void* ws, void* stream) {

@@ -11,8 +11,11 @@
 // registers: no LDS staging, no transposes, no conversion of the (T times larger) memory side.  Only the query
 // tile and the probabilities go through LDS.
 //
-// Workgroup = 64 queries x one slot (4 waves), online softmax over the memory axis in fp32, 64x512 fp32 output
-// block in accumulators, per-slot partials merged by the combine kernel of memory_read.hip.
+// Workgroup = 64 queries x one CHUNK of the memory axis (4 waves), online softmax over the memory axis in fp32,
+// 64x512 fp32 output block in accumulators, per-chunk partials merged by the combine kernel of memory_read.hip.
+// The memory axis is the concatenation of the slots, cut into equal chunks of 64-row tiles (a chunk may cross slot
+// boundaries) so that queries/64 x chunks fills the chip's 512 resident workgroups evenly: one workgroup per
+// (64 queries, slot) gave 640 workgroups at 1080p / T = 5, i.e. a second round at 25 % occupancy (2.16 -> 1.4 ms).
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -24,7 +27,6 @@ namespace {
 
 constexpr int DK = 128, DV = 512, BQ = 64, BKV = 64;
 constexpr int LDQH = DK + 8;      // halfs per Q row in LDS (272 B: conflict-free b128)
-constexpr int LDS_S = BKV + 4;    // floats per S row
 constexpr int LDPH = BKV + 8;     // halfs per P row (144 B)
 
 __device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo) {
@@ -76,24 +78,24 @@ __global__ __launch_bounds__(256) void bank_pack_vals_kernel(const float* __rest
 struct Mem3Args {
     const float* q; int q_ld;
     const _Float16* kf[8]; const _Float16* vf[8];
-    int T, hw, slot0;        // this launch handles bank slots [slot0, slot0 + gridDim.y)
-    float* part_o;     // [T][hw][512]
-    float* part_ml;    // [T][hw][2]
+    int hw;
+    int tiles_per_slot, total_tiles, chunk_tiles;   // memory axis of this launch in 64-row tiles; tiles per workgroup
+    int part0;         // index of this launch's first partial
+    float* part_o;     // [partials][hw][512]
+    float* part_ml;    // [partials][hw][2]
 };
 
-__global__ __launch_bounds__(256) void memory_read_f16x3_kernel(const Mem3Args p) {
+__global__ __launch_bounds__(256, 2) void memory_read_f16x3_kernel(const Mem3Args p) {
     __shared__ __attribute__((aligned(16))) _Float16 Qh[BQ * LDQH];
     __shared__ __attribute__((aligned(16))) _Float16 Ql[BQ * LDQH];
-    __shared__ __attribute__((aligned(16))) float Sl[BQ * LDS_S];
     __shared__ __attribute__((aligned(16))) _Float16 Ph[BQ * LDPH];
     __shared__ __attribute__((aligned(16))) _Float16 Pl[BQ * LDPH];
-    __shared__ float red[4 * BQ];
-    __shared__ float m_run[BQ], l_run[BQ], alpha_l[BQ];
+    __shared__ float red_m[2 * BQ], red_s[2 * BQ], alpha_l[BQ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int q0 = blockIdx.x * BQ, slot = p.slot0 + blockIdx.y;
-    const _Float16* __restrict__ Kf = p.kf[blockIdx.y];
-    const _Float16* __restrict__ Vf = p.vf[blockIdx.y];
+    const int q0 = blockIdx.x * BQ, part = p.part0 + blockIdx.y;
+    const int g0 = blockIdx.y * p.chunk_tiles;
+    const int g1 = g0 + p.chunk_tiles < p.total_tiles ? g0 + p.chunk_tiles : p.total_tiles;
     const int hw = p.hw;
 
     // query tile -> LDS, split (rows beyond hw are zero)
@@ -107,8 +109,8 @@ __global__ __launch_bounds__(256) void memory_read_f16x3_kernel(const Mem3Args p
         *reinterpret_cast<f16x4*>(&Qh[r * LDQH + c]) = hi;
         *reinterpret_cast<f16x4*>(&Ql[r * LDQH + c]) = lo;
     }
-    if (tid < BQ) { m_run[tid] = -__builtin_huge_valf(); l_run[tid] = 0.f; }
     __syncthreads();
+    float m_run = -__builtin_huge_valf(), l_run = 0.f;   // of query sb*32 + (lane & 31)
 
     f32x16 acc[2][4];
 #pragma unroll
@@ -121,99 +123,104 @@ __global__ __launch_bounds__(256) void memory_read_f16x3_kernel(const Mem3Args p
     const int sa = wave >> 1, sb = wave & 1;            // S sub-tile of this wave: kv 32sa.., q 32sb..
     const int frow = lane & 31, fh = lane >> 5;
     const float scale = 1.0f / sqrtf((float)DK);        // p / math.sqrt(D_e)  (STM.py:154)
-    const int ntiles = (hw + BKV - 1) / BKV;
 
-    // the query fragments of this wave never change: keep them in registers (8 k-steps x hi/lo)
-    f16x8 qh[8], ql[8];
-#pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
-        qh[ks] = *reinterpret_cast<const f16x8*>(&Qh[(sb * 32 + frow) * LDQH + 16 * ks + 8 * fh]);
-        ql[ks] = *reinterpret_cast<const f16x8*>(&Ql[(sb * 32 + frow) * LDQH + 16 * ks + 8 * fh]);
-    }
+    // the query fragments are re-read from LDS every tile (16 ds_read_b128): holding them costs 64 VGPRs, which at
+    // two workgroups per CU are worth more as bank fragments in flight
+    const _Float16* qhp = &Qh[(sb * 32 + frow) * LDQH + 8 * fh];
+    const _Float16* qlp = &Ql[(sb * 32 + frow) * LDQH + 8 * fh];
 
-    for (int t = 0; t < ntiles; ++t) {
+    int si = g0 / p.tiles_per_slot, t = g0 - si * p.tiles_per_slot;       // slot and tile inside it
+    for (int g = g0; g < g1; ++g, ++t) {
+        if (t == p.tiles_per_slot) { t = 0; ++si; }
+        const _Float16* __restrict__ Kf = p.kf[si];
+        const _Float16* __restrict__ Vf = p.vf[si];
         const int kv0 = t * BKV;
         // ---- S = K Q^T for this wave's 32x32 block: A fragments straight from the packed bank
-        f32x16 s;
+        f32x16 s, s2;                                    // two accumulators: half the dependent-MFMA chain (a third
+                                                         // one measured slower: its 16 registers cost prefetch depth)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) s[e] = 0.f;
+        for (int e = 0; e < 16; ++e) { s[e] = 0.f; s2[e] = 0.f; }
         const _Float16* kblk = Kf + ((int64_t)(2 * t + sa) * 8 * 2) * 512 + lane * 8;
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             const f16x8 kh = *reinterpret_cast<const f16x8*>(kblk + (ks * 2) * 512);
             const f16x8 kl = *reinterpret_cast<const f16x8*>(kblk + (ks * 2 + 1) * 512);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], s, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], s, 0, 0, 0);
+            const f16x8 qh = *reinterpret_cast<const f16x8*>(qhp + 16 * ks);
+            const f16x8 ql = *reinterpret_cast<const f16x8*>(qlp + 16 * ks);
+            s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh, s2, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh, s, 0, 0, 0);
+            s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql, s2, 0, 0, 0);
         }
-        // lane: col q = lane&31, rows kv = (e&3) + 8*(e>>2) + 4*(lane>>5); store transposed Sl[q][kv]
+        s += s2;                                         // small terms first, then onto the hi*hi sum
+        // ---- online softmax over the memory axis, in registers.  The S^T block keeps a QUERY per lane (column
+        // q = lane & 31, rows kv = (e&3) + 8 (e>>2) + 4 (lane>>5)): max and sum over kv are 16 in-lane values plus one
+        // exchange with lane ^ 32; the two waves that share a query block (sa = 0, 1) meet through red_m / red_s.
+        // Every lane carries the running max / sum of its query in registers (both waves of a pair redundantly).
+        const int qq = sb * 32 + frow;
+        float v[16];
         {
-            const int qq = sb * 32 + frow;
+            const float ninf = -__builtin_huge_valf();
+            float mx = ninf;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int kvl = sa * 32 + 8 * g + 4 * fh;
-                f32x4 v = {s[4 * g] * scale, s[4 * g + 1] * scale, s[4 * g + 2] * scale, s[4 * g + 3] * scale};
-                const float ninf = -__builtin_huge_valf();
-                if (kv0 + kvl + 0 >= hw) v.x = ninf;
-                if (kv0 + kvl + 1 >= hw) v.y = ninf;
-                if (kv0 + kvl + 2 >= hw) v.z = ninf;
-                if (kv0 + kvl + 3 >= hw) v.w = ninf;
-                *reinterpret_cast<f32x4*>(&Sl[qq * LDS_S + kvl]) = v;
+            for (int e = 0; e < 16; ++e) {
+                const int kvl = sa * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
+                v[e] = kv0 + kvl < hw ? s[e] * scale : ninf;
+                mx = fmaxf(mx, v[e]);
             }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            if (fh == 0) red_m[sa * BQ + qq] = mx;
         }
-        __syncthreads();
-
-        // ---- online softmax over the memory axis: thread = (query, kv quarter); P written split (hi/lo)
+        __syncthreads();                                 // (A) tile maxima visible; P / alpha of the last tile consumed
         {
-            const int qq = tid & 63, part = tid >> 6;
-            f32x4 v[4];
-            float mx = -__builtin_huge_valf();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[i] = *reinterpret_cast<const f32x4*>(&Sl[qq * LDS_S + part * 16 + 4 * i]);
-                mx = fmaxf(mx, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
-            }
-            red[part * BQ + qq] = mx;
-            __syncthreads();
-            const float m_old = m_run[qq];
-            const float m_tile = fmaxf(fmaxf(red[qq], red[BQ + qq]), fmaxf(red[2 * BQ + qq], red[3 * BQ + qq]));
-            const float m_new = fmaxf(m_old, m_tile);
+            const float m_new = fmaxf(m_run, fmaxf(red_m[qq], red_m[BQ + qq]));
+            const float al = expf(m_run - m_new);
             float sum = 0.f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int g = 0; g < 4; ++g) {
                 f16x4 hi, lo;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float e = expf(v[i][j] - m_new);
+                    const float e = expf(v[4 * g + j] - m_new);
                     sum += e;
                     _Float16 h, lw;
                     split1(e, h, lw);
                     hi[j] = h; lo[j] = lw;
                 }
-                *reinterpret_cast<f16x4*>(&Ph[qq * LDPH + part * 16 + 4 * i]) = hi;
-                *reinterpret_cast<f16x4*>(&Pl[qq * LDPH + part * 16 + 4 * i]) = lo;
+                const int kvl = sa * 32 + 8 * g + 4 * fh;
+                *reinterpret_cast<f16x4*>(&Ph[qq * LDPH + kvl]) = hi;
+                *reinterpret_cast<f16x4*>(&Pl[qq * LDPH + kvl]) = lo;
             }
-            __syncthreads();
-            red[part * BQ + qq] = sum;
-            __syncthreads();
-            if (part == 0) {
-                const float al = expf(m_old - m_new);
-                alpha_l[qq] = al;
-                l_run[qq] = l_run[qq] * al + ((red[qq] + red[BQ + qq]) + (red[2 * BQ + qq] + red[3 * BQ + qq]));
-                m_run[qq] = m_new;
+            sum += __shfl_xor(sum, 32);
+            if (fh == 0) {
+                red_s[sa * BQ + qq] = sum;
+                if (sa == 0) alpha_l[qq] = al;
             }
-            __syncthreads();
+            m_run = m_new;
+            l_run *= al;
         }
+        __syncthreads();                                 // (B) P, alpha and the partial sums are visible
+        l_run += red_s[qq] + red_s[BQ + qq];
 
         // ---- rescale O, accumulate P V: wave w owns output channels [128w, 128w+128)
+        {
+            float alr[2][16];
+            bool moved = false;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const float al = alpha_l[a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh];
+                for (int e = 0; e < 16; ++e) {
+                    alr[a][e] = alpha_l[a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh];
+                    moved |= alr[a][e] != 1.f;
+                }
+            if (__any(moved)) {                          // the running maxima settle after the first tiles
 #pragma unroll
-                for (int b = 0; b < 4; ++b) acc[a][b][e] *= al;
+                for (int a = 0; a < 2; ++a)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acc[a][b][e] *= alr[a][e];
             }
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             f16x8 ph[2], pl[2];
@@ -223,23 +230,35 @@ __global__ __launch_bounds__(256) void memory_read_f16x3_kernel(const Mem3Args p
                 pl[a] = *reinterpret_cast<const f16x8*>(&Pl[(a * 32 + frow) * LDPH + 16 * ks + 8 * fh]);
             }
             const _Float16* vblk = Vf + (((int64_t)(4 * t + ks) * 16 + wave * 4) * 2) * 512 + lane * 8;
+            f16x8 vh[4], vl[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const f16x8 vh = *reinterpret_cast<const f16x8*>(vblk + (b * 2) * 512);
-                const f16x8 vl = *reinterpret_cast<const f16x8*>(vblk + (b * 2 + 1) * 512);
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl[a], vh, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[a], vl, acc[a][b], 0, 0, 0);
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[a], vh, acc[a][b], 0, 0, 0);
-                }
+                vh[b] = *reinterpret_cast<const f16x8*>(vblk + (b * 2) * 512);
+                vl[b] = *reinterpret_cast<const f16x8*>(vblk + (b * 2 + 1) * 512);
             }
+            // three passes over the eight accumulator tiles: consecutive MFMAs never share an accumulator
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl[a], vh[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[a], vl[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int a = 0; a < 2; ++a)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[a], vh[b], acc[a][b], 0, 0, 0);
         }
-        __syncthreads();                                 // Ph/Pl/Sl/alpha are rewritten by the next tile
+        // no barrier here: the next tile's red_m writes happen after (B), its P / alpha writes after its own (A),
+        // which every wave reaches only after finishing the reads above
     }
     // partial results: un-normalised O, running max and sum
     const int dv0 = wave * 128;
-    float* po = p.part_o + ((int64_t)slot * hw) * DV;
+    float* po = p.part_o + ((int64_t)part * hw) * DV;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -250,10 +269,10 @@ __global__ __launch_bounds__(256) void memory_read_f16x3_kernel(const Mem3Args p
                 for (int b = 0; b < 4; ++b) po[(int64_t)qq * DV + dv0 + 32 * b + frow] = acc[a][b][e];
             }
         }
-    if (tid < BQ && q0 + tid < hw) {
-        float* ml = p.part_ml + ((int64_t)slot * hw + q0 + tid) * 2;
-        ml[0] = m_run[tid];
-        ml[1] = l_run[tid];
+    if (sa == 0 && fh == 0 && q0 + sb * 32 + frow < hw) {
+        float* ml = p.part_ml + ((int64_t)part * hw + q0 + sb * 32 + frow) * 2;
+        ml[0] = m_run;
+        ml[1] = l_run;
     }
 }
 
@@ -262,6 +281,20 @@ __global__ __launch_bounds__(256) void memory_read_f16x3_kernel(const Mem3Args p
 int otvm_memory_read_combine(const float* part_o, const float* part_ml, int T, int hw, float* out, int out_ld, void* stream);
 
 static inline int hw_pad64(int hw) { return (hw + 63) / 64 * 64; }
+
+// chunks of the memory axis for a launch over n slots: enough to fill 512 resident workgroups (2 per CU)
+static inline int mr_chunks(int n, int hw) {
+    const int qblocks = otvm_ceil_div(hw, BQ), total = n * (hw_pad64(hw) / BKV);
+    int s = otvm_ceil_div(512, qblocks);
+    return s < 1 ? 1 : (s > total ? total : s);
+}
+
+// partial results otvm_memory_read_f16x3 writes for a bank of T slots (sizes the workspace, memory_read.hip)
+int otvm_memory_read_f16x3_partials(int T, int hw) {
+    int np = 0;
+    for (int s0 = 0; s0 < T; s0 += 8) np += mr_chunks(T - s0 < 8 ? T - s0 : 8, hw);
+    return np;
+}
 
 extern "C" int64_t otvm_bank_slot_bytes_f16x3(int hw) {
     // keys: hw_pad x 128 x (hi,lo) fp16 ; values: hw_pad x 512 x (hi,lo) fp16
@@ -286,20 +319,29 @@ extern "C" int otvm_memory_read_f16x3(const float* q_key, int q_ld, const void* 
     OTVM_REQUIRE(q_ld % 4 == 0 && out_ld % 4 == 0, "otvm_memory_read_f16x3: views must be 16-byte aligned");
     const int hp = hw_pad64(hw);
     Mem3Args a;
-    a.q = q_key; a.q_ld = q_ld; a.T = T; a.hw = hw;
+    a.q = q_key; a.q_ld = q_ld; a.hw = hw;
+    const int np = otvm_memory_read_f16x3_partials(T, hw);
     a.part_o = (float*)ws;
-    a.part_ml = a.part_o + (int64_t)T * hw * DV;
+    a.part_ml = a.part_o + (int64_t)np * hw * DV;
+    a.tiles_per_slot = hp / BKV;
     // the reference's bank holds at most 5 slots (config.py:22); larger banks (the "unbounded bank" stress knob of
-    // BASELINE configs[4]) are handled 8 slots per launch, one partial per slot, one combine over all of them
+    // BASELINE configs[4]) are handled 8 slots per launch, one combine over all partials
+    int part0 = 0;
     for (int s0 = 0; s0 < T; s0 += 8) {
         const int n = T - s0 < 8 ? T - s0 : 8;
-        a.slot0 = s0;
         for (int t = 0; t < 8; ++t) {
             a.kf[t] = t < n ? (const _Float16*)slots[s0 + t] : nullptr;
             a.vf[t] = t < n ? (const _Float16*)slots[s0 + t] + (int64_t)hp * DK * 2 : nullptr;
         }
-        hipLaunchKernelGGL(memory_read_f16x3_kernel, dim3(otvm_ceil_div(hw, BQ), n), dim3(256), 0, (hipStream_t)stream, a);
+        const int chunks = mr_chunks(n, hw);
+        a.total_tiles = n * a.tiles_per_slot;
+        a.chunk_tiles = otvm_ceil_div(a.total_tiles, chunks);
+        a.part0 = part0;
+        // every chunk index < chunks owns at least one tile: chunks <= total_tiles and chunk_tiles = ceil(total/chunks)
+        const int used = otvm_ceil_div(a.total_tiles, a.chunk_tiles);
+        hipLaunchKernelGGL(memory_read_f16x3_kernel, dim3(otvm_ceil_div(hw, BQ), used), dim3(256), 0, (hipStream_t)stream, a);
+        part0 += used;
     }
     OTVM_CHECK_LAUNCH("otvm_memory_read_f16x3");
-    return otvm_memory_read_combine(a.part_o, a.part_ml, T, hw, out, out_ld, stream);
+    return otvm_memory_read_combine(a.part_o, a.part_ml, part0, hw, out, out_ld, stream);
 }
