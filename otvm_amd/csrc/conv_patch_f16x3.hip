@@ -164,17 +164,33 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
                     ah[a] = *reinterpret_cast<const f16x8*>(&Ph[o]);
                     al[a] = *reinterpret_cast<const f16x8*>(&Pl[o]);
                 }
-                // B fragments are read per channel tile right before use (keeps 8 instead of 8*TN operand registers live)
+                // B fragments are read for GB channel tiles at a time, then three passes over the GB x TM accumulators:
+                // consecutive MFMAs never share an accumulator (a wide tile has TM = 1: the per-tile order
+                // lo*hi, hi*lo, hi*hi was a chain of three dependent MFMAs)
+                constexpr int GB = TN < 4 ? TN : 4;
 #pragma unroll
-                for (int b = 0; b < TN; ++b) {
-                    const f16x8 bh = *reinterpret_cast<const f16x8*>(&Bs[((tl * TN + b) * 2) * 512 + lane * 8]);
-                    const f16x8 bl = *reinterpret_cast<const f16x8*>(&Bs[((tl * TN + b) * 2 + 1) * 512 + lane * 8]);
+                for (int b0 = 0; b0 < TN; b0 += GB) {
+                    f16x8 bh[GB], bl[GB];
 #pragma unroll
-                    for (int a = 0; a < TM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh, acc[a][b], 0, 0, 0);
+                    for (int j = 0; j < GB; ++j) {
+                        bh[j] = *reinterpret_cast<const f16x8*>(&Bs[((tl * TN + b0 + j) * 2) * 512 + lane * 8]);
+                        bl[j] = *reinterpret_cast<const f16x8*>(&Bs[((tl * TN + b0 + j) * 2 + 1) * 512 + lane * 8]);
+                    }
 #pragma unroll
-                    for (int a = 0; a < TM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl, acc[a][b], 0, 0, 0);
+                    for (int j = 0; j < GB; ++j)
 #pragma unroll
-                    for (int a = 0; a < TM; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh, acc[a][b], 0, 0, 0);
+                        for (int a = 0; a < TM; ++a)
+                            acc[a][b0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[j], acc[a][b0 + j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < GB; ++j)
+#pragma unroll
+                        for (int a = 0; a < TM; ++a)
+                            acc[a][b0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[j], acc[a][b0 + j], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < GB; ++j)
+#pragma unroll
+                        for (int a = 0; a < TM; ++a)
+                            acc[a][b0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[j], acc[a][b0 + j], 0, 0, 0);
                 }
             }
         }
