@@ -43,23 +43,48 @@ __global__ void classify_kernel(const float* __restrict__ probs, int64_t P, cons
     if (__any(has_fg) && (threadIdx.x & 63) == 0) atomicOr(&flags[1], 1);
 }
 
-// phase 1: one thread per (class, column)
-__global__ void edt_columns_kernel(const uint8_t* __restrict__ cls, int H, int W, int* __restrict__ g) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * W) return;
-    const int k = t / W, x = t - k * W;
+// phase 1: distance to the nearest class pixel within the column.  A column is cut into EDT_SEG segments, one thread
+// each (a workgroup = 64 columns x EDT_SEG segments, lanes along x: coalesced rows): every thread finds the first and
+// last seed of its segment, the carries (nearest seed above / below the segment) come from the other segments'
+// entries in LDS, then a down-scan and an up-scan over the segment write g.  (One thread per whole column -- 3840
+// threads at 1080p -- took 0.43 ms; integer arithmetic, same result.)
+constexpr int EDT_SEG = 16;
+
+__global__ __launch_bounds__(64 * EDT_SEG) void edt_columns_kernel(const uint8_t* __restrict__ cls, int H, int W,
+                                                                    int* __restrict__ g) {
+    __shared__ int first_s[EDT_SEG][64], last_s[EDT_SEG][64];
+    const int lx = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int cols_per_class = (W + 63) / 64;
+    const int k = blockIdx.x / cols_per_class, x = (blockIdx.x - k * cols_per_class) * 64 + lx;
     const uint8_t target = k == 0 ? 0 : 2;
+    const int len = (H + EDT_SEG - 1) / EDT_SEG;
+    const int y0 = seg * len, y1 = y0 + len < H ? y0 + len : H;
+    const bool live = x < W;
+    int first = -1, last = -1;
+    if (live) {
+        for (int y = y0; y < y1; ++y) {
+            if (cls[(int64_t)y * W + x] == target) {
+                if (first < 0) first = y;
+                last = y;
+            }
+        }
+    }
+    first_s[seg][lx] = first;
+    last_s[seg][lx] = last;
+    __syncthreads();
+    if (!live) return;
+    int above = -1, below = -1;                       // nearest seed rows outside the segment
+    for (int sgm = seg - 1; sgm >= 0 && above < 0; --sgm) above = last_s[sgm][lx];
+    for (int sgm = seg + 1; sgm < EDT_SEG && below < 0; ++sgm) below = first_s[sgm][lx];
     int* gk = g + (int64_t)k * H * W;
-    int d = EDT_INF;
-#pragma unroll 8
-    for (int y = 0; y < H; ++y) {
+    int d = above >= 0 ? y0 - 1 - above : EDT_INF;    // distance of row y0-1 to the seed above
+    for (int y = y0; y < y1; ++y) {
         const bool seed = cls[(int64_t)y * W + x] == target;
         d = seed ? 0 : (d + 1 > EDT_INF ? EDT_INF : d + 1);
         gk[(int64_t)y * W + x] = d;
     }
-    d = EDT_INF;
-#pragma unroll 8
-    for (int y = H - 1; y >= 0; --y) {
+    d = below >= 0 ? below - y1 : EDT_INF;            // distance of row y1 to the seed below
+    for (int y = y1 - 1; y >= y0; --y) {
         const int gv = gk[(int64_t)y * W + x];
         d = gv == 0 ? 0 : (d + 1 > EDT_INF ? EDT_INF : d + 1);
         gk[(int64_t)y * W + x] = gv < d ? gv : d;
@@ -86,19 +111,59 @@ __global__ __launch_bounds__(256) void edt_rows_encode_kernel(const int* __restr
         return;
     }
     const int* gr = g + ((int64_t)k * H + y) * W;
+    const int nb = (W + 31) >> 5;
+    int* bmin = g2 + W;                                // min of g2 over each 32-column block
     for (int x = threadIdx.x; x < W; x += blockDim.x) {
         const int v = gr[x];
         g2[x] = v * v;
     }
     __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+        int m = EDT_INF * EDT_INF;
+        const int e = b * 32 + 32 < W ? b * 32 + 32 : W;
+        for (int i = b * 32; i < e; ++i) m = min(m, g2[i]);
+        bmin[b] = m;
+    }
+    __syncthreads();
     for (int x = threadIdx.x; x < W; x += blockDim.x) {
         int best = g2[x];
-        for (int dx = 1; dx < W && dx * dx < best; ++dx) {
+        // near field: outward scan, stops at dx^2 >= best (the trip count is the pixel's own distance)
+        int dx = 1;
+        for (; dx < 32 && dx * dx < best; ++dx) {
             const int xl = x - dx, xr = x + dx;
             int c = EDT_INF * EDT_INF;
             if (xl >= 0) c = g2[xl];
             if (xr < W) c = min(c, g2[xr]);
             best = min(best, dx * dx + c);
+        }
+        if (dx == 32 && dx * dx < best) {
+            // far field: whole 32-column blocks, outwards; a block is skipped when even its best case
+            // (nearest column, smallest g2 of the block) cannot improve -- pixels far from every seed cross the
+            // empty columns in W/32 steps instead of W
+            const int bx = x >> 5;
+            for (int r = 1;; ++r) {
+                bool any = false;
+                const int bl = bx - r, br = bx + r;
+                if (bl >= 0) {
+                    const int dm = x - (bl * 32 + 31);
+                    if (dm * dm < best) {
+                        any = true;
+                        if (dm * dm + bmin[bl] < best)
+                            for (int i = bl * 32; i < bl * 32 + 32; ++i) best = min(best, (x - i) * (x - i) + g2[i]);
+                    }
+                }
+                if (br < nb) {
+                    const int dm = br * 32 - x;
+                    if (dm * dm < best) {
+                        any = true;
+                        if (dm * dm + bmin[br] < best) {
+                            const int e = br * 32 + 32 < W ? br * 32 + 32 : W;
+                            for (int i = br * 32; i < e; ++i) best = min(best, (i - x) * (i - x) + g2[i]);
+                        }
+                    }
+                }
+                if (!any) break;
+            }
         }
         const float d = sqrtf((float)best);
         const float v = -(d * d);                      // -dt(1 - tk)**2
@@ -128,8 +193,9 @@ extern "C" int otvm_trimap_encode(const float* probs, int Hp, int Wp, const uint
     const int grid = (int)(nb > 4096 ? 4096 : nb);
     hipLaunchKernelGGL(classify_kernel, dim3(grid), dim3(256), 0, s, probs, P, cls_override, cls_out, flags, x11, x11_ld, d80,
                        d80_ld);
-    hipLaunchKernelGGL(edt_columns_kernel, dim3(otvm_ceil_div(2 * Wp, 64)), dim3(64), 0, s, cls_out, Hp, Wp, g);
-    hipLaunchKernelGGL(edt_rows_encode_kernel, dim3(2 * Hp), dim3(256), Wp * sizeof(int), s, g, Hp, Wp, flags, x11, x11_ld);
+    hipLaunchKernelGGL(edt_columns_kernel, dim3(2 * otvm_ceil_div(Wp, 64)), dim3(64 * EDT_SEG), 0, s, cls_out, Hp, Wp, g);
+    hipLaunchKernelGGL(edt_rows_encode_kernel, dim3(2 * Hp), dim3(256), (Wp + (Wp + 31) / 32) * sizeof(int), s, g, Hp, Wp, flags,
+                       x11, x11_ld);
     OTVM_CHECK_LAUNCH("otvm_trimap_encode");
     return 0;
 }
