@@ -388,7 +388,8 @@ int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream) {
         // 390 vs 348 (512->256) against the implicit-GEMM kernel.  On smaller maps the implicit-GEMM tiles win
         // (a 4x32-tile variant of this kernel measured 160-230 TFLOP/s vs 290-315 and was dropped).
         const int64_t t8 = (int64_t)otvm_ceil_div(p->H, 8) * otvm_ceil_div(p->W, 32) * (p->Cout / 256);
-        if (t8 >= 400) {
+        static const int t_patch = getenv("OTVM_T_PATCH") ? atoi(getenv("OTVM_T_PATCH")) : 400;
+        if (t8 >= t_patch) {
             if (p->dil == 1) return launch_patch<8, 256, 8, 1, 3>(a, s);
             if (p->dil == 2) return launch_patch<8, 256, 8, 2, 3>(a, s);
             return launch_patch<8, 256, 8, 4, 3>(a, s);

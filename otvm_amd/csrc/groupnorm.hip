@@ -43,33 +43,40 @@ __global__ void gn_stats_kernel(const float* __restrict__ x, int64_t P, int C, i
     if (threadIdx.x < G * 2) atomicAdd(&stats[threadIdx.x], red[threadIdx.x]);
 }
 
-__global__ void gn_apply_kernel(const float* __restrict__ x, int64_t P, int C, int ld, const double* __restrict__ stats,
-                                const float* __restrict__ gamma, const float* __restrict__ beta,
-                                const float* __restrict__ residual, int res_ld, int act, float* __restrict__ out,
-                                int out_ld) {
-    extern __shared__ __attribute__((aligned(16))) float sc[];   // [C] scale, [C] shift
-    float* sh = sc + C;
+// y = act((x - mean_g) * rstd_g * gamma_c + beta_c [+ residual]).  The grid stride (gridDim.x * 256 float4 items) is a
+// multiple of the C/4 quads of a pixel (host side), so a thread keeps ONE channel quad for the whole launch: its
+// scale/shift live in registers and the pixel index advances by a constant.  mean / rstd are derived from the fp64
+// sums once per group per block (32 fp64 divisions and square roots, not C of them as in the first version).
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int64_t P, int C, int ld,
+                                                       const double* __restrict__ stats, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ residual,
+                                                       int res_ld, int act, float* __restrict__ out, int out_ld) {
+    __shared__ float mean_s[G], rstd_s[G];
     const int cg = C / G;
-    const double cnt = (double)P * cg;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        const int g = c / cg;
-        const double mean = stats[g * 2] / cnt;
-        double var = stats[g * 2 + 1] / cnt - mean * mean;
+    if (threadIdx.x < G) {
+        const double cnt = (double)P * cg;
+        const double mean = stats[threadIdx.x * 2] / cnt;
+        double var = stats[threadIdx.x * 2 + 1] / cnt - mean * mean;
         if (var < 0.0) var = 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
-        const float a = rstd * gamma[c];
-        sc[c] = a;
-        sh[c] = beta[c] - (float)mean * a;
+        mean_s[threadIdx.x] = (float)mean;
+        rstd_s[threadIdx.x] = (float)(1.0 / sqrt(var + 1e-5));
     }
     __syncthreads();
     const int Q = C >> 2;
-    const int64_t total = P * Q;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t pix = i / Q;
-        const int c = (int)(i - pix * Q) * 4;
+    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;            // multiple of Q
+    int64_t pix = i0 / Q;
+    const int c = (int)(i0 - pix * Q) * 4;
+    const int64_t dpix = stride / Q;
+    f32x4 a, b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int g = (c + j) / cg;
+        a[j] = rstd_s[g] * gamma[c + j];
+        b[j] = beta[c + j] - mean_s[g] * a[j];
+    }
+    for (; pix < P; pix += dpix) {
         f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * ld + c);
-        const f32x4 a = *reinterpret_cast<const f32x4*>(sc + c);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(sh + c);
         v = v * a + b;
         if (residual) v += *reinterpret_cast<const f32x4*>(residual + pix * res_ld + c);
         v.x = otvm_act(v.x, act); v.y = otvm_act(v.y, act); v.z = otvm_act(v.z, act); v.w = otvm_act(v.w, act);
@@ -97,11 +104,17 @@ extern "C" int otvm_gn_apply(const float* x, int64_t P, int C, int ld, const dou
                              void* stream) {
     OTVM_REQUIRE(C % 64 == 0 && C <= 2048, "otvm_gn_apply: C=%d unsupported", C);
     OTVM_REQUIRE(ld % 4 == 0 && out_ld % 4 == 0 && (!residual || res_ld % 4 == 0), "otvm_gn_apply: unaligned view");
-    const int64_t total = P * (C / 4);
+    const int Q = C / 4;
+    const int64_t total = P * Q;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((int)blocks), dim3(256), 2 * C * sizeof(float), (hipStream_t)stream, x, P, C,
-                       ld, stats, gamma, beta, residual, res_ld, act, out, out_ld);
+    // the grid stride must be a multiple of Q (the kernel keeps one channel quad per thread): Q | blocks * 256
+    int gcd = 256, r = Q;
+    while (r) { const int t = gcd % r; gcd = r; r = t; }
+    const int m = Q / gcd;                                   // smallest m with Q | 256 m
+    blocks = (blocks + m - 1) / m * m;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, P, C, ld, stats, gamma, beta,
+                       residual, res_ld, act, out, out_ld);
     OTVM_CHECK_LAUNCH("otvm_gn_apply");
     return 0;
 }
