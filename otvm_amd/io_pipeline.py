@@ -48,9 +48,10 @@ class FramePrefetcher:
             self._next += 1
 
     def _load(self, src):
-        arr = _decode(src)
-        t = torch.from_numpy(np.ascontiguousarray(arr))
-        return t.pin_memory()
+        arr = np.ascontiguousarray(_decode(src))
+        host = torch.empty(arr.shape, dtype=torch.from_numpy(np.empty(0, arr.dtype)).dtype, pin_memory=True)
+        host.numpy()[...] = arr                       # one copy, straight into the pinned staging buffer
+        return host
 
     def __iter__(self):
         self._submit()
