@@ -58,6 +58,13 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
     out_a, out_u8, out_t = [], [], []
     core = model.module if hasattr(model, "module") else model
     metrics = ClipMetrics(dev) if gt_alpha_u8 is not None else None
+    # loop invariants: the user trimap (25 MB as fp32 at 1080p) is uploaded once, not once per frame; the dummy alpha
+    # of the trimap flow is one tensor for the whole clip
+    tri_dev = None
+    if trimap is not None:
+        t = trimap if torch.is_tensor(trimap) else torch.from_numpy(np.ascontiguousarray(trimap))
+        tri_dev = t.to(dev).float()[None, None]
+    ones = None
     for i in range(T):
         fr = frames[i]
         f = fr if torch.is_tensor(fr) else torch.from_numpy(np.ascontiguousarray(fr))
@@ -73,9 +80,9 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
         else:
             bg = fg
         if trimap is not None:
-            a = torch.ones(1, 1, 1, H, W, device=dev)
-            t = trimap if torch.is_tensor(trimap) else torch.from_numpy(np.ascontiguousarray(trimap))
-            tri_gt = t.to(dev).float()[None, None]
+            if ones is None or ones.shape[-2:] != (H, W):
+                ones = torch.ones(1, 1, 1, H, W, device=dev)
+            a, tri_gt = ones, tri_dev
         else:
             al = alphas[i]
             al = al if torch.is_tensor(al) else torch.from_numpy(np.ascontiguousarray(al))
