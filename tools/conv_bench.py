@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--shape", action="append")
     ap.add_argument("--relu", type=int, default=0)
     ap.add_argument("--res", type=int, default=0)
+    ap.add_argument("--gn", type=int, default=0, help="fused GroupNorm statistics in the epilogue")
+    ap.add_argument("--bias", type=int, default=0)
     args = ap.parse_args()
     shapes = [tuple(int(v) for v in s.split(",")) for s in args.shape] if args.shape else DEFAULT
     lib = L.load()
@@ -47,7 +49,11 @@ def main():
         Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
         out = Act(torch.empty(Ho * Wo * max(4, Cout), device=dev), Ho, Wo, Cout)
         res = Act(torch.randn(Ho * Wo * Cout, device=dev), Ho, Wo, Cout) if args.res else None
-        p = conv_params(x, cw, out, None, stride, pad, dil, 0, args.relu, res, args.prec)
+        bias = torch.randn(Cout, device=dev) if args.bias else None
+        p = conv_params(x, cw, out, bias, stride, pad, dil, 0, args.relu, res, args.prec)
+        stats = torch.zeros(64, dtype=torch.float64, device=dev)
+        if args.gn:
+            p.gn_stats = stats.data_ptr()
         for _ in range(3):
             L.check(lib.otvm_conv2d(C.byref(p), st))
         torch.cuda.synchronize()
