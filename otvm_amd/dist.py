@@ -65,6 +65,21 @@ def run_sharded(sequences, matte_fn, rank=0, world=1, device="cpu", reference_fn
     if torch.cuda.is_available() and str(device).startswith("cuda"):
         torch.cuda.synchronize()
     secs = time.perf_counter() - t0
-    (sad_g, frames_g, secs_sum), (maxabs_g, wall_g) = reduce_metrics([sad, frames, secs], [maxabs, secs], device)
-    return dict(sad=sad_g, frames=frames_g, gpu_seconds=secs_sum, wall_seconds=wall_g, max_abs=maxabs_g,
-                fps=frames_g / wall_g if wall_g > 0 else 0.0, sequences=mine, outputs=outputs)
+    # ground-truth metrics accumulated on the device by video.ClipMetrics (sequences run with gt_alpha_u8)
+    keys = ("frames", "sad_sum", "mse_num", "mask_sum", "dt_err2_sum", "dt_mask_sum")
+    clip = [0.0] * len(keys)
+    for out in outputs.values():
+        m = out.get("metrics") if isinstance(out, dict) else None
+        if m:
+            clip = [c + float(m[k]) for c, k in zip(clip, keys)]
+    red, (maxabs_g, wall_g) = reduce_metrics([sad, frames, secs] + clip, [maxabs, secs], device)
+    sad_g, frames_g, secs_sum = red[:3]
+    summary = dict(sad=sad_g, frames=frames_g, gpu_seconds=secs_sum, wall_seconds=wall_g, max_abs=maxabs_g,
+                   fps=frames_g / wall_g if wall_g > 0 else 0.0, sequences=mine, outputs=outputs)
+    g = dict(zip(keys, red[3:]))
+    if g["frames"] > 0:
+        # per-frame means as utils/tmp/metric.py reports them (SAD /1000 per frame; MSE over evaluated pixels)
+        summary["gt_metrics"] = dict(frames=g["frames"], sad=g["sad_sum"] / g["frames"],
+                                     mse=g["mse_num"] / max(1.0, g["mask_sum"]),
+                                     dtssd_sum_err2=g["dt_err2_sum"], dtssd_mask_sum=g["dt_mask_sum"])
+    return summary

@@ -1,41 +1,30 @@
 """eval.py-shaped command line (reference eval.py:21-94, scripts/eval_s4_demo.sh) on the HIP path.
 
-    python -m otvm_amd.eval_cli --demo --data ./demo --weights weights/s4_OTVM.pth --out ./demo_results
+    python -m otvm_amd.eval_cli --demo --data ./demo --weights weights/s4_OTVM.pth --out ./demo_results [--viz]
+    python -m otvm_amd.eval_cli --data <root holding VideoMatting108/> --weights weights/s4_OTVM.pth   # val split
     python -m otvm_amd.eval_cli --demo --data ./demo --synthetic-weights            # plumbing check, no checkpoint
 
-Demo layout (reference dataset.py:1019-1070): <data>/<seq>/frames/*.jpg and <data>/<seq>/trimap/<first>.png.
-Images are read with PIL (RGB) and handed over as RGB; alpha PNGs are written as trunc(alpha*255)
-(eval.py:209-217).  With torch.distributed initialised (torchrun) sequences are sharded one-per-GPU.
+Dataset layouts: otvm_amd/datasets.py (Demo_Test / VideoMatting108_Test, reference dataset.py:959-1070).  Without
+--demo the VideoMatting108 validation split is evaluated as eval.py:86-89 does: the first-frame trimap is derived
+from the ground-truth alpha with the --trimap dilation, and SAD / MSE / dtSSD against the ground truth are
+accumulated on the device and reduced over ranks.  Alpha PNGs are written as trunc(alpha*255) (eval.py:209-217);
+--viz adds the six-panel composite frames (eval.py:96-115) and, when ffmpeg exists, the mp4 (eval.py:229-242).
+With torch.distributed initialised (torchrun) sequences are sharded one-per-GPU.
 """
 import argparse
 import os
 
-import numpy as np
 import torch
-
-
-def list_demo(data_root):
-    seqs = []
-    for v in sorted(os.listdir(data_root)):
-        fdir = os.path.join(data_root, v, "frames")
-        if not os.path.isdir(fdir):
-            continue
-        names = sorted(os.listdir(fdir))
-        tri = None
-        for n in names:
-            p = os.path.join(data_root, v, "trimap", os.path.splitext(n)[0] + ".png")
-            if os.path.isfile(p):
-                tri = p
-                break
-        seqs.append(dict(name=v, frames=[os.path.join(fdir, n) for n in names], trimap=tri))
-    return seqs
 
 
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--data", required=True)
     ap.add_argument("--out", default="./demo_results")
-    ap.add_argument("--demo", action="store_true", help="demo layout (the only dataset layout implemented)")
+    ap.add_argument("--demo", action="store_true", help="demo layout; default: VideoMatting108 validation split")
+    ap.add_argument("--subset", action="store_true", help="VideoMatting108: val_videos_subset.txt")
+    ap.add_argument("--viz", action="store_true", help="also write the six-panel composites (eval.py --viz)")
+    ap.add_argument("--max-frames", type=int, default=None, help="only the first N frames of every sequence")
     ap.add_argument("--weights", default=None)
     ap.add_argument("--synthetic-weights", action="store_true")
     ap.add_argument("--trimap", default="medium", choices=["narrow", "medium", "wide"])
@@ -46,7 +35,7 @@ def main(argv=None):
     from PIL import Image
     from . import helpers
     from .dist import run_sharded
-    from .video import run_video_matte, trimap_file_to_onehot
+    from .video import run_video_matte
 
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
@@ -64,22 +53,44 @@ def main(argv=None):
         model.load_state_dict(torch.load(args.weights, map_location="cpu"), strict=True)     # eval.py:77-79
     model.precision = args.precision
     model = torch.nn.DataParallel(model.to(dev)).eval()                                        # eval.py:80
-    seqs = list_demo(args.data)
+    from . import datasets, viz
+    ds = datasets.Demo_Test(args.data) if args.demo else datasets.VideoMatting108_Test(args.data, mode="val",
+                                                                                       use_subset=args.subset)
+    items = list(ds)
+    seqs = [dict(name=it[6], frames=it[2][:args.max_frames], item=it) for it in items]   # paths: sharding by length
+    root_out = os.path.join(args.out, "alpha", "test", helpers.get_model_name(cfg))
 
     def matte(seq):
-        frames = [np.asarray(Image.open(p).convert("RGB")) for p in seq["frames"]]
-        tri = trimap_file_to_onehot(np.asarray(Image.open(seq["trimap"])))
-        outdir = os.path.join(args.out, "alpha", "test", helpers.get_model_name(cfg), "pred", seq["name"])
+        data = datasets.load_sequence(seq["item"], max_frames=args.max_frames)
+        outdir = os.path.join(root_out, "pred", seq["name"])
         os.makedirs(outdir, exist_ok=True)
+        vizdir = os.path.join(args.out, "viz", "test", helpers.get_model_name(cfg), "viz", seq["name"])
+        if args.viz:
+            os.makedirs(vizdir, exist_ok=True)
 
         def save(i, alpha, u8, out):
-            name = os.path.splitext(os.path.basename(seq["frames"][i]))[0] + ".png"
-            Image.fromarray(u8.cpu().numpy()).save(os.path.join(outdir, name))
-        return run_video_matte(model, frames, trimap=tri, skip=args.skip, max_num=args.max_num, frames_are_rgb=True,
-                               on_frame=save, device=dev)
+            Image.fromarray(u8.cpu().numpy()).save(os.path.join(outdir, data["names"][i] + ".png"))
+            if args.viz:
+                viz.write_viz_frame(os.path.join(vizdir, "f%d.jpg" % i), out)
+        if data["data_name"] == "demo":
+            res = run_video_matte(model, data["frames"], trimap=data["trimap"], skip=args.skip, max_num=args.max_num,
+                                  on_frame=save, device=dev)
+        else:
+            res = run_video_matte(model, data["frames"], alphas=data["alphas"], backgrounds=data["backgrounds"],
+                                  skip=args.skip, max_num=args.max_num, on_frame=save, device=dev,
+                                  gt_alpha_u8=data["gt_alpha_u8"], gt_mask="unknown")
+        if args.viz:
+            viz.make_viz_video(os.path.join(vizdir, "f%d.jpg"),                          # eval.py:229-242
+                               os.path.join(args.out, "viz", "test", helpers.get_model_name(cfg), "viz",
+                                            seq["name"].replace("/", "_") + ".mp4"))
+        return res
     summary = run_sharded(seqs, matte, rank=rank, world=world, device=dev)
     if rank == 0:
         print("done | %d frames | %.2f frames/s over %d GPU(s)" % (summary["frames"], summary["fps"], world))
+        if "gt_metrics" in summary:
+            g = summary["gt_metrics"]
+            print("vs ground truth (unknown band) | SAD/frame %.4f | pooled MSE %.6f | frames %d" % (g["sad"], g["mse"], g["frames"]))
+    return summary
 
 
 if __name__ == "__main__":

@@ -37,9 +37,17 @@ def trimap_file_to_onehot(tri):
 
 
 @torch.no_grad()
+def _as_tensor(x):
+    """numpy / tensor -> tensor without the read-only-array warning (PIL hands out non-writable buffers)."""
+    if torch.is_tensor(x):
+        return x
+    a = np.ascontiguousarray(x)
+    return torch.from_numpy(a if a.flags.writeable else a.copy())
+
+
 def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, skip=10, max_num=5,
                     frames_are_rgb=False, on_frame=None, device=None, keep_on_device=False, gt_alpha_u8=None,
-                    gt_mask_u8=None):
+                    gt_mask_u8=None, gt_mask=None):
     """Matte one sequence.
 
     model       : EvalModel (optionally wrapped in nn.DataParallel), on the GPU
@@ -48,7 +56,8 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
     alphas      : per-frame GT alpha [H,W] in [0,1] (VideoMatting108 flow: first-frame trimap derived
                   from alpha with the model's dilate kernel) -- required when trimap is None
     gt_alpha_u8 : optional per-frame ground-truth alpha, uint8 [H,W]; with it SAD/MSE/dtSSD are accumulated on
-                  the device (ClipMetrics) and returned under "metrics"; gt_mask_u8 = optional {0,1} evaluation masks
+                  the device (ClipMetrics) and returned under "metrics"; gt_mask_u8 = optional {0,1} evaluation masks,
+                  gt_mask="unknown" = the reference metric's default mask (0 < gt < 255) instead
     backgrounds : optional per-frame BG images (V108 composites fg*a + bg*(1-a)); default bg = fg
     Returns dict(alpha=[T,H,W] float32, alpha_u8=[T,H,W] uint8 (truncated, eval.py:209), trimap=[T,3,H,W]).
     """
@@ -62,12 +71,12 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
     # of the trimap flow is one tensor for the whole clip
     tri_dev = None
     if trimap is not None:
-        t = trimap if torch.is_tensor(trimap) else torch.from_numpy(np.ascontiguousarray(trimap))
+        t = _as_tensor(trimap)
         tri_dev = t.to(dev).float()[None, None]
     ones = None
     for i in range(T):
         fr = frames[i]
-        f = fr if torch.is_tensor(fr) else torch.from_numpy(np.ascontiguousarray(fr))
+        f = _as_tensor(fr)
         f = f.to(dev).float()
         if frames_are_rgb:
             f = f.flip(-1)
@@ -75,7 +84,7 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
         H, W = fg.shape[-2:]
         if backgrounds is not None:
             b = backgrounds[i]
-            b = b if torch.is_tensor(b) else torch.from_numpy(np.ascontiguousarray(b))
+            b = _as_tensor(b)
             bg = b.to(dev).float().permute(2, 0, 1)[None, None].contiguous()
         else:
             bg = fg
@@ -85,7 +94,7 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
             a, tri_gt = ones, tri_dev
         else:
             al = alphas[i]
-            al = al if torch.is_tensor(al) else torch.from_numpy(np.ascontiguousarray(al))
+            al = _as_tensor(al)
             a = al.to(dev).float()[None, None, None]
             tri_gt = None
         memorize, max_memory_num, large = memory_schedule(i, H, W, skip, max_num)
@@ -95,11 +104,11 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
         u8 = core._engine.last_alpha_u8
         if metrics is not None:
             g = gt_alpha_u8[i]
-            g = g if torch.is_tensor(g) else torch.from_numpy(np.ascontiguousarray(g))
-            mk = None
+            g = _as_tensor(g)
+            mk = gt_mask
             if gt_mask_u8 is not None:
                 mk = gt_mask_u8[i]
-                mk = (mk if torch.is_tensor(mk) else torch.from_numpy(np.ascontiguousarray(mk))).to(dev)
+                mk = (_as_tensor(mk)).to(dev)
             metrics.add(u8, g.to(dev), mk)
         if on_frame is not None:
             on_frame(i, alpha, u8, out)
@@ -115,33 +124,50 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
 
 class ClipMetrics:
     """SAD / MSE / dtSSD of a clip accumulated on the device (otvm_matting_metrics), reference definitions
-    utils/tmp/metric.py:177-189,252-264 on the 8-bit alphas the path writes (eval.py:209)."""
+    utils/tmp/metric.py:177-189,252-264 on the 8-bit alphas the path writes (eval.py:209).  One row of partial sums
+    per frame stays on the device (no per-frame synchronisation); result() turns them into the reference's per-frame
+    values.  mask: None = all pixels, "unknown" = the reference's default (0 < target < 255, metric.py:113-115), or
+    explicit uint8 {0,1} masks."""
 
-    def __init__(self, device):
+    def __init__(self, device, capacity=256):
         from . import lib as L
         self.L, self.lib = L, L.load()
-        self.acc = torch.zeros(5, dtype=torch.float64, device=device)
+        self.device = device
+        self.acc = torch.zeros(capacity, 5, dtype=torch.float64, device=device)
         self.prev = None
         self.frames = 0
-        self.sad_per_frame = []
 
     def add(self, pred_u8, target_u8, mask_u8=None):
-        """pred/target: uint8 [H,W] device tensors (0..255); mask: uint8 {0,1} or None (all pixels)."""
+        """pred/target: uint8 [H,W] device tensors (0..255); mask: uint8 {0,1}, "unknown" or None (all pixels)."""
         st = torch.cuda.current_stream(pred_u8.device).cuda_stream
         pred_u8, target_u8 = pred_u8.contiguous(), target_u8.contiguous()
+        if isinstance(mask_u8, str):
+            if mask_u8 != "unknown":
+                raise ValueError("ClipMetrics: mask must be None, 'unknown' or a uint8 tensor")
+            mask_u8 = ((target_u8 > 0) & (target_u8 < 255)).to(torch.uint8)
         mask_u8 = None if mask_u8 is None else mask_u8.contiguous()
+        if self.frames == self.acc.shape[0]:
+            self.acc = torch.cat([self.acc, torch.zeros_like(self.acc)])
         pp, tp, mp = self.prev if self.prev is not None else (None, None, None)
         ptr = lambda x: 0 if x is None else x.data_ptr()
         self.L.check(self.lib.otvm_matting_metrics(ptr(pred_u8), ptr(target_u8), ptr(mask_u8), ptr(pp), ptr(tp), ptr(mp),
-                                                   pred_u8.numel(), self.acc.data_ptr(), st), "matting_metrics")
+                                                   pred_u8.numel(), self.acc[self.frames].data_ptr(), st), "matting_metrics")
         self.prev = (pred_u8, target_u8, mask_u8)
         self.frames += 1
 
     def result(self):
-        a = self.acc.tolist()
-        return dict(frames=self.frames, sad_sum=a[0] / 255.0 / 1000.0, mse_num=a[1] / 255.0 ** 2, mask_sum=a[2],
-                    dt_err2_sum=a[3] / 255.0 ** 2, dt_mask_sum=a[4],
-                    sad_mean=a[0] / 255.0 / 1000.0 / max(1, self.frames))
+        rows = self.acc[:self.frames].cpu()
+        tot = rows.sum(0).tolist()
+        sad_f = (rows[:, 0] / 255.0 / 1000.0).tolist()
+        mse_f = (rows[:, 1] / 255.0 ** 2 / (rows[:, 2] + 1.0)).tolist()
+        # row i > 0 holds the temporal term of the pair (i-1, i), masked by frame i-1's mask (metric.py:252-264)
+        dt_f = (rows[1:, 3] / 255.0 ** 2).sqrt().tolist()
+        dt_n = (rows[1:, 4] + 1.0).tolist()
+        return dict(frames=self.frames, sad_sum=tot[0] / 255.0 / 1000.0, mse_num=tot[1] / 255.0 ** 2, mask_sum=tot[2],
+                    dt_err2_sum=tot[3] / 255.0 ** 2, dt_mask_sum=tot[4],
+                    sad_mean=tot[0] / 255.0 / 1000.0 / max(1, self.frames),
+                    sad_per_frame=sad_f, mse_per_frame=mse_f, dtssd_per_pair=dt_f, dtssd_num_per_pair=dt_n,
+                    dtssd_sum=float(sum(dt_f)))
 
 
 def sad(pred, ref, mask=None):

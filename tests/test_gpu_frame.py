@@ -179,3 +179,63 @@ def test_io_pipeline_matches_direct_run(model, synth_sd):
     for t in range(T):
         back = np.asarray(Image.open(io.BytesIO(r_io["encoded"][t])))
         assert np.array_equal(back, r_dir["alpha_u8"][t].numpy())
+
+
+def test_eval_cli_demo_and_v108_layouts(tmp_path, model, synth_sd):
+    """eval.py-shaped command line over both dataset layouts of the reference (dataset.py:959-1070): the PNGs it writes
+    are the direct run_video_matte outputs, the V108 flow derives its trimap from the ground-truth alpha and reports the
+    ground-truth metrics, --viz writes the six-panel composites."""
+    import json
+    import os
+    from PIL import Image
+    from otvm_amd import eval_cli
+    from otvm_amd.datasets import Demo_Test, VideoMatting108_Test, load_sequence
+    from otvm_amd.synth_data import soft_alpha, synthetic_clip
+    from otvm_amd.video import run_video_matte
+    H, W, T = 64, 96, 3
+    frames_bgr, tri = synthetic_clip(H, W, T, seed=41)
+    # demo tree: frames as lossless PNG (RGB on disk), first-frame trimap as grayscale {0,128,255}
+    demo = os.path.join(str(tmp_path), "demo")
+    os.makedirs(os.path.join(demo, "clip", "frames")); os.makedirs(os.path.join(demo, "clip", "trimap"))
+    for t in range(T):
+        Image.fromarray(frames_bgr[t][..., ::-1].copy()).save(os.path.join(demo, "clip", "frames", "%04d.png" % t))
+    g = (np.asarray(tri)[1] * 128 + np.asarray(tri)[2] * 255).astype(np.uint8)
+    Image.fromarray(g).save(os.path.join(demo, "clip", "trimap", "0000.png"))
+    out_demo = os.path.join(str(tmp_path), "out_demo")
+    s = eval_cli.main(["--demo", "--data", demo, "--out", out_demo, "--synthetic-weights", "--skip", "2", "--viz"])
+    assert s["frames"] == T
+    m = model(12).module
+    d = load_sequence(next(iter(Demo_Test(demo))))
+    ref = run_video_matte(m, d["frames"], trimap=d["trimap"], skip=2, max_num=5)
+    pred = os.path.join(out_demo, "alpha", "test", "s4_OTVM", "pred", "clip")
+    for t in range(T):
+        assert np.array_equal(np.asarray(Image.open(os.path.join(pred, "%04d.png" % t))), ref["alpha_u8"][t].numpy())
+    vz = np.asarray(Image.open(os.path.join(out_demo, "viz", "test", "s4_OTVM", "viz", "clip", "f1.jpg")))
+    assert vz.shape == (3 * (H // 2 + 2) + 2, 2 * (W // 2 + 2) + 2, 3)
+    # V108 tree: RGBA foregrounds, separate backgrounds, frame_corr.json + val_videos.txt
+    root = os.path.join(str(tmp_path), "v108root")
+    v = os.path.join(root, "VideoMatting108")
+    os.makedirs(v)
+    corr = {}
+    bg_bgr, _ = synthetic_clip(H, W, T, seed=42)
+    for t in range(T):
+        a = np.rint(soft_alpha(H, W, t) * 255).astype(np.uint8)
+        rgba = np.concatenate([frames_bgr[t][..., ::-1], a[..., None]], -1)
+        k = "vid/clip_0/%05d.png" % t
+        corr[k] = "bgs/%05d.jpg" % t
+        os.makedirs(os.path.dirname(os.path.join(v, "FG_done", k)), exist_ok=True)
+        Image.fromarray(rgba).save(os.path.join(v, "FG_done", k))
+        os.makedirs(os.path.join(v, "BG_done2", "bgs"), exist_ok=True)
+        Image.fromarray(bg_bgr[t][..., ::-1].copy()).save(os.path.join(v, "BG_done2", "bgs", "%05d.png" % t))
+    json.dump(corr, open(os.path.join(v, "frame_corr.json"), "w"))
+    open(os.path.join(v, "val_videos.txt"), "w").write("vid/clip_0\n")
+    out_v = os.path.join(str(tmp_path), "out_v108")
+    s = eval_cli.main(["--data", root, "--out", out_v, "--synthetic-weights", "--skip", "2", "--trimap", "narrow"])
+    assert s["frames"] == T and s["gt_metrics"]["frames"] == T and s["gt_metrics"]["sad"] >= 0
+    dv = load_sequence(next(iter(VideoMatting108_Test(root))))
+    refv = run_video_matte(model(5).module, dv["frames"], alphas=dv["alphas"], backgrounds=dv["backgrounds"], skip=2,
+                           max_num=5, gt_alpha_u8=dv["gt_alpha_u8"], gt_mask="unknown")
+    predv = os.path.join(out_v, "alpha", "test", "s4_OTVM", "pred", "vid/clip_0")
+    for t in range(T):
+        assert np.array_equal(np.asarray(Image.open(os.path.join(predv, "%05d.png" % t))), refv["alpha_u8"][t].numpy())
+    assert abs(refv["metrics"]["sad_sum"] / T - s["gt_metrics"]["sad"]) < 1e-9

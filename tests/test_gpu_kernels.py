@@ -402,3 +402,14 @@ def test_matting_metrics(G):
     e, n = M.dtssd(p, t, m)
     assert abs(r["dt_err2_sum"] - float(e.double().pow(2).sum())) <= 1e-5 * r["dt_err2_sum"]
     assert r["dt_mask_sum"] == float(m[:-1].sum())
+    # per-frame values as the reference's BatchMetric methods return them (fixture: met_sad / met_mse / met_dtssd)
+    assert np.allclose(r["sad_per_frame"], ops["met_sad"], rtol=1e-5, atol=1e-9)
+    assert np.allclose(r["mse_per_frame"], ops["met_mse"], rtol=1e-5, atol=1e-12)
+    assert np.allclose(r["dtssd_per_pair"], ops["met_dt_err"], rtol=1e-5, atol=1e-9)
+    assert np.allclose(r["dtssd_num_per_pair"], ops["met_dt_num"], rtol=0, atol=0)
+    # the reference's default mask (no mask given): the unknown band of the ground truth
+    cm2 = ClipMetrics(G.DEV, capacity=2)                     # also exercises the row-buffer growth
+    for i in range(p.shape[0]):
+        cm2.add(p[i].to(torch.uint8).to(G.DEV), t[i].to(torch.uint8).to(G.DEV), "unknown")
+    unk = ((t > 0) & (t < 255)).float()
+    assert np.allclose(cm2.result()["sad_per_frame"], M.sad(p, t, unk).numpy(), rtol=1e-5, atol=1e-9)

@@ -144,3 +144,106 @@ def test_product_does_not_import_oracle():
                 src = open(os.path.join(dp, f)).read()
                 assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", ""), f
                 assert "/root/reference" not in src, f
+
+
+# ---- dataset enumeration / decoding / viz (SURVEY.md 8f ranks 2 and 3; reference dataset.py:959-1070, eval.py:96-115)
+
+def _write_rgb(path, arr):
+    from PIL import Image
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    Image.fromarray(arr).save(path)
+
+
+def test_demo_enumeration_follows_reference_layout(tmp_path):
+    from otvm_amd.datasets import Demo_Test, load_sequence
+    rng = np.random.default_rng(0)
+    img = lambda: rng.integers(0, 255, (12, 16, 3), dtype=np.uint8)
+    root = str(tmp_path)
+    for n in ("0001.png", "0002.png", "0003.png"):
+        _write_rgb(os.path.join(root, "seqA", "frames", n), img())
+    tri = np.zeros((12, 16), np.uint8); tri[3:9, 4:12] = 128; tri[5:7, 6:10] = 255
+    _write_rgb(os.path.join(root, "seqA", "trimap", "0001.png"), tri)
+    for n in ("a.png", "b.png"):
+        _write_rgb(os.path.join(root, "seqB", "frames", n), img())
+    _write_rgb(os.path.join(root, "seqB", "trimap", "b.png"), tri)        # trimap only for the 2nd frame
+    items = list(Demo_Test(root))
+    assert [it[6] for it in items] == ["seqA", "seqB"] and all(it[0] == "demo" and it[1] == root for it in items)
+    assert items[0][2] == [os.path.join("seqA", "frames", n) for n in ("0001.png", "0002.png", "0003.png")]
+    # the most recent existing trimap path is carried forward; '' before the first one (dataset.py:1041-1050)
+    assert items[0][5] == [os.path.join("seqA", "trimap", "0001.png")] * 3
+    assert items[1][5] == ["", os.path.join("seqB", "trimap", "b.png")]
+    assert items[0][3] is None and items[0][4] is None
+    d = load_sequence(items[0], max_frames=2)
+    assert d["names"] == ["0001", "0002"] and len(d["frames"]) == 2 and d["frames"][0].shape == (12, 16, 3)
+    # frames come back in cv2 channel order (BGR)
+    from PIL import Image
+    rgb = np.asarray(Image.open(os.path.join(root, "seqA", "frames", "0001.png")))
+    assert np.array_equal(d["frames"][0], rgb[..., ::-1])
+    assert tuple(d["trimap"].shape) == (3, 12, 16) and float(d["trimap"].sum()) == 12 * 16
+    assert float(d["trimap"][2].sum()) == 2 * 4 and float(d["trimap"][1].sum()) == 6 * 8 - 2 * 4
+
+
+def test_v108_enumeration_and_decoding(tmp_path):
+    import json
+    from otvm_amd.datasets import VideoMatting108_Test, load_sequence
+    rng = np.random.default_rng(1)
+    root = os.path.join(str(tmp_path), "VideoMatting108")
+    corr = {"vidB/clip0/00002.png": "bg1/0002.jpg", "vidB/clip0/00001.png": "bg1/0001.jpg",
+            "vidA/clip1/00001.png": "bg0/0001.jpg", "vidA/clip10/00001.png": "bg2/0001.jpg"}
+    os.makedirs(root)
+    json.dump(corr, open(os.path.join(root, "frame_corr.json"), "w"))
+    open(os.path.join(root, "val_videos.txt"), "w").write("vidB/clip0\nvidA/clip1\n")
+    open(os.path.join(root, "val_videos_subset.txt"), "w").write("vidA/clip1\n")
+    rgba = {}
+    for k in corr:
+        a = rng.integers(0, 255, (10, 14, 4), dtype=np.uint8)
+        rgba[k] = a
+        _write_rgb(os.path.join(root, "FG_done", k), a)
+    bgs = {}
+    for k, v in corr.items():
+        b = rng.integers(0, 255, (10, 14, 3), dtype=np.uint8)
+        bgs[v] = b
+        # the listed .jpg does not exist for bg1/0002: the loader falls back to .png (dataset.py:896-899)
+        _write_rgb(os.path.join(root, "BG_done2", os.path.splitext(v)[0] + ".png"), b)
+    ds = VideoMatting108_Test(str(tmp_path), mode="val")
+    items = list(ds)
+    assert len(ds) == 2 and [it[6] for it in items] == ["vidB/clip0", "vidA/clip1"]      # order of the set file
+    assert items[0][0] == "V108" and items[0][1] == root and items[0][4] is None and items[0][5] is None
+    # frames of a video: sorted frame_corr keys whose dirname is the video (clip10 must not leak into clip1)
+    assert items[0][2] == [os.path.join("FG_done", "vidB/clip0/00001.png"), os.path.join("FG_done", "vidB/clip0/00002.png")]
+    assert items[0][3] == [os.path.join("BG_done2", "bg1/0001.jpg"), os.path.join("BG_done2", "bg1/0002.jpg")]
+    assert items[1][2] == [os.path.join("FG_done", "vidA/clip1/00001.png")]
+    assert len(VideoMatting108_Test(str(tmp_path), use_subset=True)) == 1
+    d = load_sequence(items[0])
+    src = rgba["vidB/clip0/00001.png"]
+    assert np.array_equal(d["frames"][0], src[..., 2::-1]) and np.array_equal(d["gt_alpha_u8"][0], src[..., 3])
+    assert np.allclose(d["alphas"][0], src[..., 3].astype(np.float32) / 255.0)
+    assert np.array_equal(d["backgrounds"][1], bgs["bg1/0002.jpg"][..., ::-1])
+
+
+def test_viz_grid_layout_and_rounding():
+    """Six half-resolution panels, two per row, padding 2 (torchvision make_grid defaults), x*255+0.5 truncated."""
+    from otvm_amd.viz import make_grid_u8, viz_panels
+    h, w = 8, 12
+    img = torch.rand(1, 1, 3, h, w)
+    tri_pred = torch.softmax(torch.randn(1, 1, 3, h, w), 2)
+    tri_gt = torch.zeros(1, 1, 3, h, w); tri_gt[:, :, 1] = 1
+    alpha = torch.rand(1, 1, 1, h, w)
+    gt = torch.rand(1, 1, 1, h, w)
+    panels = viz_panels((img, tri_pred, tri_gt, alpha, gt))
+    assert tuple(panels.shape) == (6, 3, h // 2, w // 2)
+    down = lambda x: torch.nn.functional.interpolate(x.reshape(1, -1, h, w), size=(h // 2, w // 2), mode="bilinear",
+                                                     align_corners=False)[0]
+    green = torch.zeros(3, h, w); green[1] = 1
+    comp = img[0, 0] * alpha[0, 0] + green * (1 - alpha[0, 0])
+    want = [img[0, 0], comp, tri_gt[0, 0], gt[0, 0].expand(3, -1, -1), tri_pred[0, 0], alpha[0, 0].expand(3, -1, -1)]
+    for k in range(6):
+        assert torch.allclose(panels[k], down(want[k]), atol=1e-6)
+    g = make_grid_u8(panels, nrow=2)
+    ph, pw = h // 2, w // 2
+    assert g.shape == (3 * (ph + 2) + 2, 2 * (pw + 2) + 2, 3)
+    for k in range(6):
+        y, x = (k // 2) * (ph + 2) + 2, (k % 2) * (pw + 2) + 2
+        tile = (panels[k] * 255 + 0.5).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).numpy()
+        assert np.array_equal(g[y:y + ph, x:x + pw], tile)
+    assert g[:2].max() == 0 and g[:, :2].max() == 0 and g[ph + 2:ph + 4].max() == 0          # padding stays black
