@@ -35,6 +35,7 @@ extern "C" {
 #define OTVM_PREC_F16X3 1
 
 const char* otvm_last_error(void);
+#define OTVM_ABI_VERSION 2    /* 2: otvm_ppm_pool_ws_bytes(H, C) */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -108,8 +109,9 @@ int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, int in_ld, co
                            float* out, int Ho, int Wo, int out_ld, void* stream);
 /* nn.AdaptiveAvgPool2d(s) for s in {1,2,3,6} in one launch (FBA/models.py:300-306);
  * out = 50 bins x C, bins ordered scale-major then row-major.
- * ws >= otvm_ppm_pool_ws_bytes(C) (deterministic two-stage reduction).                             */
-int64_t otvm_ppm_pool_ws_bytes(int C);
+ * ws >= otvm_ppm_pool_ws_bytes(H, C): per-row sums of the 12 column bins (one pass over the map, then a
+ * fixed-order reduction over the rows of every bin).                                                */
+int64_t otvm_ppm_pool_ws_bytes(int H, int C);
 int otvm_ppm_pool(const float* in, int H, int W, int C, int ld, float* out, void* ws, void* stream);
 
 /* ---------------------------------------------------------------- memory read (STM.py:140-163) -

@@ -13,4 +13,4 @@ void otvm_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* otvm_last_error(void) { return g_err; }
-extern "C" int otvm_abi_version(void) { return 1; }
+extern "C" int otvm_abi_version(void) { return OTVM_ABI_VERSION; }

@@ -587,7 +587,7 @@ class FramePlan:
         de = "NET.decoder."
         conv5 = self.PPMCAT.ch(0, 2048)
         self.POOL = self.raw("ppm_pool", 50 * 2048)
-        self.POOL_WS = self.raw("ppm_ws", int(lib.otvm_ppm_pool_ws_bytes(2048)) // 4)
+        self.POOL_WS = self.raw("ppm_ws", int(lib.otvm_ppm_pool_ws_bytes(H8, 2048)) // 4)
         S.append((lib.otvm_ppm_pool, (conv5.ptr, H8, W8, 2048, conv5.ld, self.POOL.data_ptr(), self.POOL_WS.data_ptr()),
                   "ppm_pool"))
         base = 0

@@ -11,6 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3 = 0, 1
+ABI_VERSION = 2          # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -47,7 +48,7 @@ _PROTOS = {
     "otvm_gn_apply": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i32, i32, vp, i32, vp]),
     "otvm_maxpool3x3s2": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
     "otvm_upsample_bilinear": (i32, [vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, i32, vp]),
-    "otvm_ppm_pool_ws_bytes": (i64, [i32]),
+    "otvm_ppm_pool_ws_bytes": (i64, [i32, i32]),
     "otvm_ppm_pool": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "otvm_memory_read_ws_bytes": (i64, [i32, i32]),
     "otvm_memory_read": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp), i32, i32, vp, i32, vp, vp]),
@@ -88,6 +89,10 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
+    got = lib.otvm_abi_version()
+    if got != ABI_VERSION:
+        raise RuntimeError("otvm_amd: %s has ABI version %d, this binding expects %d -- rebuild it with "
+                           "`python otvm_amd/csrc/build.py`" % (LIB_PATH, got, ABI_VERSION))
     _lib = lib
     return lib
 

@@ -208,7 +208,7 @@ def test_maxpool_upsample_ppm(G):
     z = rnd(1, 512, 17, 30, seed=30)
     za = G.to_act(z)
     pool = torch.empty(50 * 512, device=G.DEV)
-    pws = torch.empty(int(lib.otvm_ppm_pool_ws_bytes(512)), dtype=torch.uint8, device=G.DEV)
+    pws = torch.empty(int(lib.otvm_ppm_pool_ws_bytes(17, 512)), dtype=torch.uint8, device=G.DEV)
     L.check(lib.otvm_ppm_pool(za.ptr, 17, 30, 512, za.ld, pool.data_ptr(), pws.data_ptr(), G.stream()))
     torch.cuda.synchronize()
     base = 0

@@ -28,7 +28,8 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     from otvm_amd import lib as L
     assert set(L.EXPORTED) == declared, (set(L.EXPORTED) ^ declared)
     lib.otvm_abi_version.restype = ctypes.c_int
-    assert lib.otvm_abi_version() == 1
+    raw = open(os.path.join(ROOT, "include", "otvm_hip.h")).read()
+    assert lib.otvm_abi_version() == L.ABI_VERSION == int(re.search(r"#define OTVM_ABI_VERSION (\d+)", raw).group(1))
 
 
 def test_ctypes_struct_matches_c_layout():
