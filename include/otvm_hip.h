@@ -35,7 +35,7 @@ extern "C" {
 #define OTVM_PREC_F16X3 1
 
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 2    /* 2: otvm_ppm_pool_ws_bytes(H, C) */
+#define OTVM_ABI_VERSION 3    /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -81,8 +81,17 @@ typedef struct {
     double* gn_stats;                               /* optional: fused GroupNorm(32) statistics of the OUTPUT
                                                        (sum, sum of squares per group, [32][2] fp64, accumulated
                                                        atomically; Cout % 32 == 0, act == NONE, no residual) or NULL */
+    const float* in_scale; const float* in_shift;   /* optional fused normalisation of the INPUT (the GroupNorm apply of
+                                                       the producing layer folded into this conv's staging):
+                                                       in' = in_act(in * in_scale[c] + in_shift[c]) inside the image, zero
+                                                       padding outside; tables of Cin floats from otvm_gn_table, or NULL.
+                                                       Only layers for which otvm_conv2d_accepts_input_norm() returns 1 */
+    int in_act;                                     /* OTVM_ACT_* applied after the input normalisation */
 } otvm_conv_params;
 int otvm_conv2d(const otvm_conv_params* p, void* stream);
+/* 1 when otvm_conv2d would run the layer on a kernel that implements in_scale / in_shift (f16x3 3x3 stride-1 patch
+ * kernel), else 0: the caller then applies otvm_gn_apply as a separate pass.                                       */
+int otvm_conv2d_accepts_input_norm(const otvm_conv_params* p);
 
 /* f16x3: derive the split weights from a packed fp32 weight (see otvm_pack_conv_weight):
  * row o is scaled by 2^-e (|w| <= 1), w_hi = fp16(w), w_lo = fp16(w - w_hi), w_scale[o] = 2^e.
@@ -96,6 +105,10 @@ int otvm_split_conv_weight_f16x3(const float* w_packed, int O, int O_pad, int K_
  * stats accumulates per-group sum / sum-of-squares in fp64 (stats[32][2], must be zeroed before);
  * apply computes y = act((x-mean)*rstd*gamma + beta + residual).                                  */
 int otvm_gn_stats(const float* x, int64_t P, int C, int ld, double* stats, void* stream);
+/* per-channel scale / shift of the same normalisation (scale = rstd*gamma, shift = beta - mean*scale), for
+ * otvm_conv_params.in_scale / in_shift: identical arithmetic to otvm_gn_apply's                                   */
+int otvm_gn_table(const double* stats, int64_t P, int C, const float* gamma, const float* beta, float* scale,
+                  float* shift, void* stream);
 int otvm_gn_apply(const float* x, int64_t P, int C, int ld, const double* stats, const float* gamma,
                   const float* beta, const float* residual, int res_ld, int act,
                   float* out, int out_ld, void* stream);

@@ -309,6 +309,9 @@ extern "C" int otvm_conv2d(const otvm_conv_params* p, void* stream) {
     const int Ho = (p->H + 2 * p->pad - p->dil * (p->kh - 1) - 1) / p->stride + 1;
     const int Wo = (p->W + 2 * p->pad - p->dil * (p->kw - 1) - 1) / p->stride + 1;
     OTVM_REQUIRE(Ho == p->Ho && Wo == p->Wo, "otvm_conv2d: output size mismatch (%dx%d expected %dx%d)", p->Ho, p->Wo, Ho, Wo);
+    OTVM_REQUIRE(!p->in_scale == !p->in_shift, "otvm_conv2d: in_scale and in_shift go together");
+    OTVM_REQUIRE(!p->in_scale || otvm_conv2d_accepts_input_norm(p),
+                 "otvm_conv2d: fused input normalisation requested for a layer otvm_conv2d_accepts_input_norm() rejects");
     if (p->precision == OTVM_PREC_F16X3) return otvm_conv2d_f16x3_impl(p, stream);
     ConvArgs a;
     a.in = p->in; a.w = p->w; a.bias = p->bias; a.residual = p->residual; a.out = p->out; a.gn_stats = p->gn_stats;

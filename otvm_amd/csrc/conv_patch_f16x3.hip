@@ -29,6 +29,9 @@ struct PatchArgs {
     double* gn_stats;
     int H, W, Cin, in_ld, res_ld, Cout, out_ld, n_pad32, in_relu, act;
     int tiles_x, tiles_y, tiles_n;
+    // fused input normalisation (GroupNorm apply of the producer folded into the staging): x' = in_act(x * in_scale[c]
+    // + in_shift[c]) for pixels inside the image, 0 for the conv's zero padding; nullptr = plain input
+    const float* in_scale; const float* in_shift; int in_act;
 };
 
 constexpr int CB = 16;           // channels per stage = one MFMA k-step
@@ -91,6 +94,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
     constexpr int NB = (B_PIECES + NT - 1) / NT;                       // B 16-byte pieces per thread
     f32x4 rp[NP];
     f16x8 rb[NB];
+    f32x4 rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};      // input-normalisation table of this thread's quad
     auto prefetch = [&](int cb, int g) __attribute__((always_inline)) {
         const int cb32 = cb >> 1, ks = cb & 1;
 #pragma unroll
@@ -104,6 +108,10 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
             }
         }
         if (g == 0) {
+            if (p.in_scale) {                                           // NT % 4 == 0: idx & 3 == tid & 3 for every k
+                rsc = *reinterpret_cast<const f32x4*>(p.in_scale + cb * CB + (tid & 3) * 4);
+                rsh = *reinterpret_cast<const f32x4*>(p.in_shift + cb * CB + (tid & 3) * 4);
+            }
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int idx = tid + k * NT;
@@ -131,6 +139,17 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
                 const int idx = tid + k * NT;
                 if (idx < NPIX * 4) {
                     f32x4 v = rp[k];
+                    if (p.in_scale) {
+                        const int pix = idx >> 2;
+                        const int py = pix / PW, px = pix - py * PW;
+                        const int iy = ty0 - DIL + py, ix = tx0 - DIL + px;
+                        const bool inb = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+                        v = v * rsc + rsh;
+                        v.x = otvm_act(v.x, p.in_act); v.y = otvm_act(v.y, p.in_act);
+                        v.z = otvm_act(v.z, p.in_act); v.w = otvm_act(v.w, p.in_act);
+                        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                        v = inb ? v : z;
+                    }
                     if (p.in_relu) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
@@ -371,30 +390,42 @@ extern "C" int otvm_pack_patch_weight_f16x3(const float* w_packed, int O, int K_
     return 0;
 }
 
+// 0: not eligible (the implicit-GEMM kernel takes the layer), 1: narrow tiles, 2: wide (256-channel) tiles
+static int patch_choice(const otvm_conv_params* p) {
+    if (!p->w_frag || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->Cin % 16 != 0) return 0;
+    if (p->dil != 1 && p->dil != 2 && p->dil != 4) return 0;
+    static const int wide = getenv("OTVM_PATCH_WIDE") ? atoi(getenv("OTVM_PATCH_WIDE")) : 1;
+    if (p->Cout <= 64) return 1;
+    if (!wide || p->Cout % 256 != 0) return 0;                     // wide path: 256-channel tiles, 8 waves, 3-tap weight stages
+    // needs enough 8x32 x 256-channel tiles to fill 256 CUs (OS4 maps at 1080p): 327 vs 285 TFLOP/s (256->256) and
+    // 390 vs 348 (512->256) against the implicit-GEMM kernel.  On smaller maps the implicit-GEMM tiles win
+    // (a 4x32-tile variant of this kernel measured 160-230 TFLOP/s vs 290-315 and was dropped).
+    static const int t_patch = getenv("OTVM_T_PATCH") ? atoi(getenv("OTVM_T_PATCH")) : 400;
+    const int64_t t8 = (int64_t)otvm_ceil_div(p->H, 8) * otvm_ceil_div(p->W, 32) * (p->Cout / 256);
+    return t8 >= t_patch ? 2 : 0;
+}
+
+// the fused input normalisation (otvm_conv_params.in_scale) exists on this path only
+extern "C" int otvm_conv2d_accepts_input_norm(const otvm_conv_params* p) {
+    return p && p->precision == OTVM_PREC_F16X3 && patch_choice(p) != 0 ? 1 : 0;
+}
+
 // returns -1 when the layer is not eligible (caller falls back to the implicit-GEMM kernel)
 int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream) {
-    if (!p->w_frag || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->Cin % 16 != 0) return -1;
-    static const int wide = getenv("OTVM_PATCH_WIDE") ? atoi(getenv("OTVM_PATCH_WIDE")) : 1;
-    const bool is_wide = p->Cout > 64;
-    if (is_wide && (!wide || p->Cout % 256 != 0)) return -1;       // wide path: 256-channel tiles, 8 waves, 3-tap weight stages
+    const int choice = patch_choice(p);
+    if (choice == 0) return -1;
+    const bool is_wide = choice == 2;
     PatchArgs a;
     a.in = p->in; a.wf = (const _Float16*)p->w_frag; a.wscale = p->w_scale; a.bias = p->bias; a.residual = p->residual;
     a.out = p->out; a.gn_stats = p->gn_stats;
     a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.in_ld = p->in_ld; a.res_ld = p->res_ld; a.Cout = p->Cout; a.out_ld = p->out_ld;
     a.n_pad32 = (p->Cout + 31) / 32 * 32; a.in_relu = p->in_relu; a.act = p->act;
     hipStream_t s = (hipStream_t)stream;
+    a.in_scale = p->in_scale; a.in_shift = p->in_shift; a.in_act = p->in_act;
     if (is_wide) {
-        // needs enough 8x32 x 256-channel tiles to fill 256 CUs (OS4 maps at 1080p): 327 vs 285 TFLOP/s (256->256) and
-        // 390 vs 348 (512->256) against the implicit-GEMM kernel.  On smaller maps the implicit-GEMM tiles win
-        // (a 4x32-tile variant of this kernel measured 160-230 TFLOP/s vs 290-315 and was dropped).
-        const int64_t t8 = (int64_t)otvm_ceil_div(p->H, 8) * otvm_ceil_div(p->W, 32) * (p->Cout / 256);
-        static const int t_patch = getenv("OTVM_T_PATCH") ? atoi(getenv("OTVM_T_PATCH")) : 400;
-        if (t8 >= t_patch) {
-            if (p->dil == 1) return launch_patch<8, 256, 8, 1, 3>(a, s);
-            if (p->dil == 2) return launch_patch<8, 256, 8, 2, 3>(a, s);
-            return launch_patch<8, 256, 8, 4, 3>(a, s);
-        }
-        return -1;
+        if (p->dil == 1) return launch_patch<8, 256, 8, 1, 3>(a, s);
+        if (p->dil == 2) return launch_patch<8, 256, 8, 2, 3>(a, s);
+        return launch_patch<8, 256, 8, 4, 3>(a, s);
     }
     if (p->dil == 1) return p->Cout <= 32 ? launch_patch<8, 32, 4, 1>(a, s) : launch_patch<8, 64, 4, 1>(a, s);
     if (p->dil == 2) return launch_patch<8, 64, 4, 2>(a, s);

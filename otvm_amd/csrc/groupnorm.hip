@@ -84,7 +84,36 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     }
 }
 
+__global__ void gn_table_kernel(const double* __restrict__ stats, int64_t P, int C, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift) {
+    __shared__ float mean_s[G], rstd_s[G];
+    const int cg = C / G;
+    if (threadIdx.x < G) {
+        const double cnt = (double)P * cg;
+        const double mean = stats[threadIdx.x * 2] / cnt;
+        double var = stats[threadIdx.x * 2 + 1] / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_s[threadIdx.x] = (float)mean;
+        rstd_s[threadIdx.x] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cg;
+        const float a = rstd_s[g] * gamma[c];
+        scale[c] = a;
+        shift[c] = beta[c] - mean_s[g] * a;
+    }
+}
+
 }  // namespace
+
+extern "C" int otvm_gn_table(const double* stats, int64_t P, int C, const float* gamma, const float* beta, float* scale,
+                             float* shift, void* stream) {
+    OTVM_REQUIRE(stats && gamma && beta && scale && shift && C % 32 == 0 && C <= 4096, "otvm_gn_table: bad arguments (C=%d)", C);
+    hipLaunchKernelGGL(gn_table_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, P, C, gamma, beta, scale, shift);
+    OTVM_CHECK_LAUNCH("otvm_gn_table");
+    return 0;
+}
 
 extern "C" int otvm_gn_stats(const float* x, int64_t P, int C, int ld, double* stats, void* stream) {
     OTVM_REQUIRE(C % 64 == 0 && C <= 2048, "otvm_gn_stats: C=%d unsupported (need multiple of 64, <= 2048)", C);

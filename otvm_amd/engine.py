@@ -14,6 +14,7 @@ What is decided at plan time (load time for weights):
   * the memory bank is a set of per-slot key/value buffers (``alpha/model.py:472-493`` policy kept).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -21,6 +22,9 @@ from . import lib as L
 
 NONE, RELU, LEAKY = 0, 1, 2
 FUSE_GN_STATS = True       # GroupNorm statistics accumulated in the producing conv's epilogue
+# GroupNorm apply folded into the staging of the ONLY consumer when that is a patch conv (the normalised tensor is never
+# written: refinement BasicBlocks at full resolution, FBA layer1); OTVM_FUSE_GN_APPLY=0 keeps the separate pass
+FUSE_GN_APPLY = os.environ.get("OTVM_FUSE_GN_APPLY", "1") != "0"
 
 
 def _rup(x, m):
@@ -121,7 +125,9 @@ def pack_conv_weight(lib, dev, w, ws=False, scale=None, i_pad=None, split=True, 
     return cw
 
 
-def conv_params(x, cw, out, bias=None, stride=1, pad=0, dil=1, act=NONE, in_relu=0, residual=None, precision=L.PREC_F32):
+def conv_params(x, cw, out, bias=None, stride=1, pad=0, dil=1, act=NONE, in_relu=0, residual=None, precision=L.PREC_F32,
+                in_norm=None):
+    """in_norm = (scale_ptr, shift_ptr, act): fused normalisation of the input (otvm_conv_params.in_scale)."""
     Ho = (x.H + 2 * pad - dil * (cw.kh - 1) - 1) // stride + 1
     Wo = (x.W + 2 * pad - dil * (cw.kw - 1) - 1) // stride + 1
     if precision == L.PREC_F16X3 and cw.w_hi is None:
@@ -132,7 +138,9 @@ def conv_params(x, cw, out, bias=None, stride=1, pad=0, dil=1, act=NONE, in_relu
                         out.ptr, Ho, Wo, cw.O, out.ld, cw.kh, cw.kw, stride, pad, dil, in_relu, act, precision,
                         0 if cw.w_hi is None else cw.w_hi.data_ptr(), 0 if cw.w_lo is None else cw.w_lo.data_ptr(),
                         0 if cw.w_scale is None else cw.w_scale.data_ptr(),
-                        0 if cw.w_frag is None else cw.w_frag.data_ptr(), 0)
+                        0 if cw.w_frag is None else cw.w_frag.data_ptr(), 0,
+                        0 if in_norm is None else in_norm[0], 0 if in_norm is None else in_norm[1],
+                        0 if in_norm is None else in_norm[2])
 
 
 class HipEngine:
@@ -398,13 +406,13 @@ class FramePlan:
         return self._bufs[key]
 
     # ---- step builders (S = list being filled)
-    def conv(self, S, x, wname, out, stride=1, pad=0, dil=1, act=NONE, in_relu=0, residual=None):
+    def conv(self, S, x, wname, out, stride=1, pad=0, dil=1, act=NONE, in_relu=0, residual=None, in_norm=None):
         w = self.e.W[wname]
         assert x.C == w.I_pad, (wname, x.C, w.I_pad)
         Ho = (x.H + 2 * pad - dil * (w.kh - 1) - 1) // stride + 1
         Wo = (x.W + 2 * pad - dil * (w.kw - 1) - 1) // stride + 1
         assert (out.H, out.W) == (Ho, Wo) and out.C >= w.O, (wname, out.H, out.W, Ho, Wo, out.C, w.O)
-        p = conv_params(x, w, out, w.bias, stride, pad, dil, act, in_relu, residual, self.e.precision)
+        p = conv_params(x, w, out, w.bias, stride, pad, dil, act, in_relu, residual, self.e.precision, in_norm)
         self._keep.append(p)
         flops = 2 * Ho * Wo * w.O * w.kh * w.kw * w.I           # algorithmic (un-padded) 2*MAC
         # algorithmic bytes: read the input once, the weights once, write the output once (+ residual read), fp32
@@ -428,6 +436,26 @@ class FramePlan:
                    0 if residual is None else residual.ptr, 0 if residual is None else residual.ld, act,
                    out.ptr, out.ld), "gn_apply " + name))
 
+    def gn_then_conv(self, S, x, gn_name, gn_act, producer_p, wname, out, **kw):
+        """GroupNorm(32) + activation of the raw conv output ``x`` whose ONLY consumer is the conv ``wname``.  When
+        that conv runs on the patch kernel the apply is folded into its input staging (x stays raw in memory, the
+        normalised tensor is never written); otherwise the usual in-place apply pass is emitted."""
+        w = self.e.W[wname]
+        sd = self.e.sd
+        if FUSE_GN_APPLY and FUSE_GN_STATS and producer_p is not None:
+            probe = conv_params(x, w, out, w.bias, kw.get("stride", 1), kw.get("pad", 0), kw.get("dil", 1), kw.get("act", NONE),
+                                0, kw.get("residual"), self.e.precision, (1, 1, gn_act))
+            if self.lib.otvm_conv2d_accepts_input_norm(C.byref(probe)):
+                idx = self.n_gn
+                self.n_gn += 1
+                self._fused_stats.append((producer_p, idx))
+                tab = self.raw("gntab_" + gn_name, 2 * x.C)
+                S.append(("gn_table", (x.P, x.C, sd[gn_name + ".weight"].data_ptr(), sd[gn_name + ".bias"].data_ptr(),
+                                       tab.data_ptr(), tab.data_ptr() + 4 * x.C), idx, "gn_table " + gn_name))
+                return self.conv(S, x, wname, out, in_norm=(tab.data_ptr(), tab.data_ptr() + 4 * x.C, gn_act), **kw)
+        self.gn(S, x, gn_name, gn_act, conv_p=producer_p)
+        return self.conv(S, x, wname, out, **kw)
+
     def _bind_stats(self):
         base = self.stats.data_ptr()
         for conv_p, idx in self._fused_stats:
@@ -437,6 +465,9 @@ class FramePlan:
                 if st[0] == "gn_stats":
                     _, a, idx, label = st
                     S[i] = (self.lib.otvm_gn_stats, a + (base + idx * 512,), label)
+                elif st[0] == "gn_table":
+                    _, a, idx, label = st
+                    S[i] = (self.lib.otvm_gn_table, (base + idx * 512,) + a, label)
                 elif st[0] == "gn_apply":
                     _, a, idx, b, label = st
                     S[i] = (self.lib.otvm_gn_apply, a + (base + idx * 512,) + b, label)
@@ -454,9 +485,8 @@ class FramePlan:
         Ho, Wo = x.H // stride, x.W // stride
         t1 = self.buf("bt1", x.H, x.W, planes)
         cp = self.conv(S, x, p + ".conv1", t1)
-        self.gn(S, t1, p + ".bn1", RELU, conv_p=cp)
         t2 = self.buf("bt2", Ho, Wo, planes)
-        cp = self.conv(S, t1, p + ".conv2", t2, stride=stride, pad=dil, dil=dil)
+        cp = self.gn_then_conv(S, t1, p + ".bn1", RELU, cp, p + ".conv2", t2, stride=stride, pad=dil, dil=dil)
         self.gn(S, t2, p + ".bn2", RELU, conv_p=cp)
         t3 = self.buf("bt3", Ho, Wo, planes * 4)
         cp3 = self.conv(S, t2, p + ".conv3", t3)
@@ -630,9 +660,8 @@ class FramePlan:
         for l in ("layer1", "layer2"):
             t1 = self.buf("rt1", Hp, Wp, 64)
             cp = self.conv(S, x, rf + l + ".conv1", t1, pad=1)
-            self.gn(S, t1, rf + l + ".bn1", RELU, conv_p=cp)
             t2 = self.buf("rt2", Hp, Wp, 64)
-            cp = self.conv(S, t1, rf + l + ".conv2", t2, pad=1)
+            cp = self.gn_then_conv(S, t1, rf + l + ".bn1", RELU, cp, rf + l + ".conv2", t2, pad=1)
             o = self.buf("r_" + l, Hp, Wp, 64)
             self.gn(S, t2, rf + l + ".bn2", RELU, out=o, residual=x, conv_p=cp)
             x = o

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3 = 0, 1
-ABI_VERSION = 2          # include/otvm_hip.h OTVM_ABI_VERSION
+ABI_VERSION = 3          # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -23,7 +23,8 @@ class ConvParams(C.Structure):
                 ("kh", i32), ("kw", i32), ("stride", i32), ("pad", i32), ("dil", i32),
                 ("in_relu", i32), ("act", i32),
                 ("precision", i32), ("w_hi", vp), ("w_lo", vp), ("w_scale", vp), ("w_frag", vp),
-                ("gn_stats", vp)]
+                ("gn_stats", vp),
+                ("in_scale", vp), ("in_shift", vp), ("in_act", i32)]
 
 
 class PreprocessParams(C.Structure):
@@ -45,6 +46,8 @@ _PROTOS = {
     "otvm_conv2d": (i32, [C.POINTER(ConvParams), vp]),
     "otvm_split_conv_weight_f16x3": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "otvm_gn_stats": (i32, [vp, i64, i32, i32, vp, vp]),
+    "otvm_gn_table": (i32, [vp, i64, i32, vp, vp, vp, vp, vp]),
+    "otvm_conv2d_accepts_input_norm": (i32, [C.POINTER(ConvParams)]),
     "otvm_gn_apply": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i32, i32, vp, i32, vp]),
     "otvm_maxpool3x3s2": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
     "otvm_upsample_bilinear": (i32, [vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, i32, vp]),

@@ -110,6 +110,47 @@ def test_conv_big_tile_fused_groupnorm_stats(G):
     assert float((stats.cpu() - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("Cin,Cout,dil,H,W,act", [(64, 64, 1, 37, 70, 1), (64, 32, 1, 20, 33, 2), (256, 256, 2, 320, 320, 1)])
+def test_conv_fused_input_groupnorm(G, Cin, Cout, dil, H, W, act):
+    """GroupNorm apply of the producer folded into the patch conv's staging (otvm_conv_params.in_scale): equals
+    otvm_gn_apply followed by the plain conv, including the zero padding of the NORMALISED tensor at the border."""
+    from otvm_amd import lib as L
+    lib = L.load()
+    x = rnd(1, Cin, H, W, seed=80) * 1.7 + 0.3
+    w = rnd(Cout, Cin, 3, 3, seed=81, scale=1.0 / math.sqrt(Cin * 9))
+    b = rnd(Cout, seed=82)
+    gamma, beta = rnd(Cin, seed=83).abs() + 0.5, rnd(Cin, seed=84) * 0.2
+    xn = F.group_norm(x, 32, gamma, beta, 1e-5)
+    xn = F.relu(xn) if act == 1 else F.leaky_relu(xn, 0.01)
+    ref = F.conv2d(xn, w, b, 1, dil, dil)
+    xa, cw = G.to_act(x), G.pack_weight(w)
+    g_d, b_d, bias_d = gamma.to(G.DEV), beta.to(G.DEV), b.to(G.DEV)           # kept alive: raw pointers go to the library
+    stats = torch.zeros(64, dtype=torch.float64, device=G.DEV)
+    L.check(lib.otvm_gn_stats(xa.ptr, H * W, Cin, xa.ld, stats.data_ptr(), G.stream()))
+    tab = torch.zeros(2 * Cin, device=G.DEV)
+    L.check(lib.otvm_gn_table(stats.data_ptr(), H * W, Cin, g_d.data_ptr(), b_d.data_ptr(),
+                              tab.data_ptr(), tab.data_ptr() + 4 * Cin, G.stream()))
+    out = G.empty_act(H, W, max(4, Cout))
+    from otvm_amd.engine import conv_params
+    probe = conv_params(xa, cw, out, None, 1, dil, dil, 0, 0, None, 1, (tab.data_ptr(), tab.data_ptr() + 4 * Cin, act))
+    assert lib.otvm_conv2d_accepts_input_norm(C.byref(probe)) == 1          # these shapes take the patch kernel
+    G.conv2d(xa, cw, out, bias_d, pad=dil, dil=dil, precision=1, in_norm=(tab.data_ptr(), tab.data_ptr() + 4 * Cin, act))
+    got = G.from_act(out, Cout)
+    assert G.maxdiff(got, ref) <= 3e-5 * max(1.0, float(ref.abs().max()))
+    # bit-identical to the two-pass route (same table arithmetic, same staging)
+    xa2 = G.to_act(x)
+    L.check(lib.otvm_gn_apply(xa2.ptr, H * W, Cin, xa2.ld, stats.data_ptr(), g_d.data_ptr(), b_d.data_ptr(), 0, 0, act,
+                              xa2.ptr, xa2.ld, G.stream()))
+    out2 = G.empty_act(H, W, max(4, Cout))
+    G.conv2d(xa2, cw, out2, bias_d, pad=dil, dil=dil, precision=1)
+    assert torch.equal(G.from_act(out2, Cout), got)
+    # layers the patch kernel does not take reject the request loudly
+    w1 = rnd(Cout, Cin, 1, 1, seed=85)
+    cw1 = G.pack_weight(w1)
+    with pytest.raises(RuntimeError):
+        G.conv2d(xa, cw1, out, None, precision=1, in_norm=(tab.data_ptr(), tab.data_ptr() + 4 * Cin, act))
+
+
 def test_f16x3_is_fp32_class(G):
     """Error of the split-fp16 path vs an fp64 reference, next to the exact-fp32 MFMA path, on operands
     spanning 1e-3 .. 30 (the dropped lo*lo term is 2^-22 relative)."""
