@@ -35,7 +35,8 @@ extern "C" {
 #define OTVM_PREC_F16X3 1
 
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 3    /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act */
+#define OTVM_ABI_VERSION 4    /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
+                                 4: otvm_conv_params.splitk_ws */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -87,6 +88,10 @@ typedef struct {
                                                        padding outside; tables of Cin floats from otvm_gn_table, or NULL.
                                                        Only layers for which otvm_conv2d_accepts_input_norm() returns 1 */
     int in_act;                                     /* OTVM_ACT_* applied after the input normalisation */
+    void* splitk_ws; int64_t splitk_ws_bytes;       /* optional workspace (f16x3): layers with too few output tiles to fill
+                                                       the chip split K over up to 8 workgroups per tile and reduce the
+                                                       partial tiles in a fixed order (deterministic); NULL = never split.
+                                                       One workspace per stream that runs convs concurrently.          */
 } otvm_conv_params;
 int otvm_conv2d(const otvm_conv_params* p, void* stream);
 /* 1 when otvm_conv2d would run the layer on a kernel that implements in_scale / in_shift (f16x3 3x3 stride-1 patch

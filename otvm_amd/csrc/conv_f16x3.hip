@@ -36,6 +36,10 @@ struct Conv3Args {
     int H, W, Cin, in_ld, K_pad, res_ld, Ho, Wo, Cout, out_ld;
     int kh, kw, stride, pad, dil, in_relu, act;
     int M, taps, nchunks, tiles_m, tiles_n;
+    // split-K (layers too small to fill the chip): gridDim.y workgroups share an output tile, each walks a contiguous
+    // range of the K chunks and writes its un-biased partial tile to out + blockIdx.y * split_stride (the host points
+    // `out` at the workspace and clears bias / residual / act / gn_stats); splitk_finish_kernel adds them up in order
+    int64_t split_stride;
 };
 
 constexpr int BK = 32;
@@ -106,8 +110,13 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
             tapmask[i] = mk;
         }
     }
-    // wave-uniform tap walk (FAST)
-    int u_cb = 0, u_tap = 0, u_ky = 0, u_kx = 0;
+    // K chunks of this workgroup: all of them, or the blockIdx.y-th share (split-K)
+    const int c_begin = (int)(((int64_t)blockIdx.y * p.nchunks) / gridDim.y);
+    const int c_end = (int)(((int64_t)(blockIdx.y + 1) * p.nchunks) / gridDim.y);
+    float* const outp = p.out + (int64_t)blockIdx.y * p.split_stride;
+    // wave-uniform tap walk (FAST), positioned on the first chunk
+    int u_cb = c_begin / p.taps, u_tap = c_begin - u_cb * p.taps;
+    int u_ky = u_tap / p.kw, u_kx = u_tap - u_ky * p.kw;
     const int64_t woff0 = (int64_t)(n0 + brow) * p.K_pad + bk;
     const int64_t wstep = (int64_t)B_ROWS * p.K_pad;
 
@@ -232,33 +241,32 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
     };
 
-    load_chunk(0);
+    load_chunk(c_begin);
     if (DBUF) {
         // one barrier per chunk: while the MFMAs of chunk c run out of stage c&1, the same wave converts chunk
         // c+1 into the other stage (VALU/LDS work issues in the shadow of the 32-cycle MFMAs) and then launches
         // the global loads of chunk c+2, which have a whole chunk of MFMA time to land.
         store_chunk(0);
-        if (p.nchunks > 1) load_chunk(1);
+        if (c_begin + 1 < c_end) load_chunk(c_begin + 1);
         __syncthreads();
         // the conversion of chunk c+1 sits between the two k-steps of chunk c in ONE basic block (no branch around
         // it: the last chunk is peeled), so the scheduler can interleave its VALU / LDS writes with the MFMAs
-        int c = 0;
-        for (; c + 1 < p.nchunks; ++c) {
-            const int buf = c & 1;
+        int c = c_begin, buf = 0;
+        for (; c + 1 < c_end; ++c, buf ^= 1) {
             compute_ks(buf, 0);
             store_chunk(buf ^ 1);
-            if (c + 2 < p.nchunks) load_chunk(c + 2);
+            if (c + 2 < c_end) load_chunk(c + 2);
             compute_ks(buf, 1);
             __syncthreads();
         }
-        compute_ks(c & 1, 0);
-        compute_ks(c & 1, 1);
+        compute_ks(buf, 0);
+        compute_ks(buf, 1);
     } else {
-        for (int c = 0; c < p.nchunks; ++c) {
+        for (int c = c_begin; c < c_end; ++c) {
             __syncthreads();
             store_chunk(0);
             __syncthreads();
-            if (c + 1 < p.nchunks) load_chunk(c + 1);
+            if (c + 1 < c_end) load_chunk(c + 1);
             compute_ks(0, 0);
             compute_ks(0, 1);
         }
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     {
         float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
         const int prow = lane >> 3, pc = (lane & 7) * 4;
-        const bool vec_ok = ((p.out_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
+        const bool vec_ok = ((p.out_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(outp) & 15) == 0) &&
                             (!p.residual || (((p.res_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0)));
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
@@ -313,14 +321,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
                             v += rres[r4];
                             v.x = otvm_act(v.x, p.act); v.y = otvm_act(v.y, p.act);
                             v.z = otvm_act(v.z, p.act); v.w = otvm_act(v.w, p.act);
-                            *reinterpret_cast<f32x4*>(p.out + (int64_t)m * p.out_ld + n4) = v;
+                            *reinterpret_cast<f32x4*>(outp + (int64_t)m * p.out_ld + n4) = v;
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 if (n4 + j < p.Cout) {
                                     float x = v[j];
                                     if (p.residual) x += p.residual[(int64_t)m * p.res_ld + n4 + j];
-                                    p.out[(int64_t)m * p.out_ld + n4 + j] = otvm_act(x, p.act);
+                                    outp[(int64_t)m * p.out_ld + n4 + j] = otvm_act(x, p.act);
                                 }
                             }
                         }
@@ -380,11 +388,34 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     }
 }
 
+// split-K epilogue: out = act(sum_z part[z] + bias + residual), partials added in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int S, int64_t stride, int64_t M,
+                                                            int Cout, int ldp, const float* __restrict__ bias,
+                                                            const float* __restrict__ residual, int res_ld, int act,
+                                                            float* __restrict__ out, int out_ld) {
+    const int Q = ldp >> 2;
+    const int64_t total = M * Q;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t m = i / Q;
+        const int c = (int)(i - m * Q) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(part + m * ldp + c);
+        for (int z = 1; z < S; ++z) v += *reinterpret_cast<const f32x4*>(part + z * stride + m * ldp + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (c + j < Cout) {
+                float x = v[j] + (bias ? bias[c + j] : 0.f);
+                if (residual) x += residual[m * res_ld + c + j];
+                out[m * out_ld + c + j] = otvm_act(x, act);
+            }
+        }
+    }
+}
+
 template <int BM, int BN, int WM, int WN>
-int launch3(Conv3Args& a, hipStream_t s) {
+int launch3(Conv3Args& a, hipStream_t s, int ksplit = 1) {
     a.tiles_m = otvm_ceil_div(a.M, BM);
     a.tiles_n = otvm_ceil_div(a.Cout, BN);
-    const dim3 grid(a.tiles_m * a.tiles_n), block(WM * WN * 64);
+    const dim3 grid(a.tiles_m * a.tiles_n, ksplit), block(WM * WN * 64);
     // int32 element offsets in the fast path: the whole input view must stay below 2^31 elements
     // (the split weights of such layers are stored channel-block major: the generic decode cannot read them)
     const bool fast = f16x3_fast_layout(a.taps, a.Cin);
@@ -464,8 +495,39 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     a.kh = p->kh; a.kw = p->kw; a.stride = p->stride; a.pad = p->pad; a.dil = p->dil;
     a.in_relu = p->in_relu; a.act = p->act;
     a.M = p->Ho * p->Wo; a.taps = p->kh * p->kw; a.nchunks = p->K_pad / 32;
+    a.split_stride = 0;
     hipStream_t s = (hipStream_t)stream;
     const int64_t M = a.M;
+    // ---- split-K for layers that cannot fill the chip with output tiles alone (OS16/OS32 maps, the whole 480p frame):
+    // 128-row tiles, the K chunks of a tile shared by up to 8 workgroups, partials through the caller's workspace
+    static const int splitk = getenv("OTVM_SPLITK") ? atoi(getenv("OTVM_SPLITK")) : 1;
+    if (splitk && p->splitk_ws && a.nchunks >= 64) {
+        const bool wide = p->Cout > 64;
+        const int64_t tiles = (int64_t)otvm_ceil_div(M, 128) * otvm_ceil_div(p->Cout, wide ? 128 : 64);
+        const int ldp = (p->Cout + 3) & ~3;
+        // at least 16 chunks per workgroup; the reduction pass (and, with fused GroupNorm sums, a statistics pass over
+        // the output) costs two small launches, so moderately deep layers keep the single-pass kernel (measured per
+        // layer at 480p / 1080p: 1024->128 3x3 at OS16 0.186 -> 0.058 ms, 1024->256 1x1 + GN 0.035 -> 0.074 ms)
+        int S = (int)(384 / (tiles > 0 ? tiles : 1));
+        if (S > 8) S = 8;
+        if (S > a.nchunks / 16) S = a.nchunks / 16;
+        if (p->gn_stats && a.nchunks < 256 && tiles > 8) S = 1;
+        while (S >= 2 && (int64_t)S * M * ldp * (int64_t)sizeof(float) > p->splitk_ws_bytes) --S;
+        if (tiles < 192 && S >= 2) {
+            Conv3Args b = a;
+            b.out = (float*)p->splitk_ws; b.out_ld = ldp; b.split_stride = M * ldp;
+            b.bias = nullptr; b.residual = nullptr; b.act = OTVM_ACT_NONE; b.gn_stats = nullptr;
+            const int rc = wide ? launch3<128, 128, 2, 2>(b, s, S) : launch3<128, 64, 2, 2>(b, s, S);
+            if (rc) return rc;
+            int64_t blocks = (M * (ldp / 4) + 255) / 256;
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)blocks), dim3(256), 0, s, (const float*)p->splitk_ws, S,
+                               (int64_t)M * ldp, M, p->Cout, ldp, p->bias, p->residual, p->res_ld, p->act, p->out, p->out_ld);
+            OTVM_CHECK_LAUNCH("otvm_conv2d(split-K finish)");
+            if (p->gn_stats) return otvm_gn_stats(p->out, M, p->Cout, p->out_ld, p->gn_stats, stream);
+            return 0;
+        }
+    }
     if (p->Cout <= 32) return launch3<256, 32, 4, 1>(a, s);
     if (p->Cout <= 64) return (M >= 256 * 128) ? launch3<256, 64, 4, 1>(a, s) : launch3<64, 64, 2, 2>(a, s);
     // Tile choice by workgroup count (thresholds tuned on the whole 1080p frame after the 256-row tiles got their

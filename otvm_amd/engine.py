@@ -126,8 +126,9 @@ def pack_conv_weight(lib, dev, w, ws=False, scale=None, i_pad=None, split=True, 
 
 
 def conv_params(x, cw, out, bias=None, stride=1, pad=0, dil=1, act=NONE, in_relu=0, residual=None, precision=L.PREC_F32,
-                in_norm=None):
-    """in_norm = (scale_ptr, shift_ptr, act): fused normalisation of the input (otvm_conv_params.in_scale)."""
+                in_norm=None, splitk_ws=None):
+    """in_norm = (scale_ptr, shift_ptr, act): fused normalisation of the input (otvm_conv_params.in_scale);
+    splitk_ws = float tensor the library may use for split-K partial tiles (one per concurrently used stream)."""
     Ho = (x.H + 2 * pad - dil * (cw.kh - 1) - 1) // stride + 1
     Wo = (x.W + 2 * pad - dil * (cw.kw - 1) - 1) // stride + 1
     if precision == L.PREC_F16X3 and cw.w_hi is None:
@@ -140,7 +141,9 @@ def conv_params(x, cw, out, bias=None, stride=1, pad=0, dil=1, act=NONE, in_relu
                         0 if cw.w_scale is None else cw.w_scale.data_ptr(),
                         0 if cw.w_frag is None else cw.w_frag.data_ptr(), 0,
                         0 if in_norm is None else in_norm[0], 0 if in_norm is None else in_norm[1],
-                        0 if in_norm is None else in_norm[2])
+                        0 if in_norm is None else in_norm[2],
+                        0 if splitk_ws is None else splitk_ws.data_ptr(),
+                        0 if splitk_ws is None else splitk_ws.numel() * splitk_ws.element_size())
 
 
 class HipEngine:
@@ -412,7 +415,7 @@ class FramePlan:
         Ho = (x.H + 2 * pad - dil * (w.kh - 1) - 1) // stride + 1
         Wo = (x.W + 2 * pad - dil * (w.kw - 1) - 1) // stride + 1
         assert (out.H, out.W) == (Ho, Wo) and out.C >= w.O, (wname, out.H, out.W, Ho, Wo, out.C, w.O)
-        p = conv_params(x, w, out, w.bias, stride, pad, dil, act, in_relu, residual, self.e.precision, in_norm)
+        p = conv_params(x, w, out, w.bias, stride, pad, dil, act, in_relu, residual, self.e.precision, in_norm, self._ws)
         self._keep.append(p)
         flops = 2 * Ho * Wo * w.O * w.kh * w.kw * w.I           # algorithmic (un-padded) 2*MAC
         # algorithmic bytes: read the input once, the weights once, write the output once (+ residual read), fp32
@@ -538,6 +541,10 @@ class FramePlan:
         H2, W2, H4, W4, H8, W8, H16, W16 = Hp // 2, Wp // 2, Hp // 4, Wp // 4, Hp // 8, Wp // 8, Hp // 16, Wp // 16
         self.hw = H16 * W16
 
+        # split-K workspaces: one for the launch stream, one for the memorize steps (they run on the side stream
+        # concurrently with the next frame's segment steps)
+        self.SPLITK_WS = [self.raw("splitk_ws0", 16 << 20), self.raw("splitk_ws1", 16 << 20)]
+        self._ws = self.SPLITK_WS[0]
         # ---------------- frame-level buffers
         self.X11 = self.buf("X11", Hp, Wp, 12)          # 0-2 normalised RGB, 3-8 distance encoding, 9-10 soft, 11 zero
         self.SQ = self.buf("SQ", Hp, Wp, 4)             # Encoder_Q input (normalised RGB)
@@ -679,6 +686,7 @@ class FramePlan:
             self.steps["fba_tail%d" % par] = S
 
         # ---------------- STM memorize (STM.py:201-228); key/value convs are bound to a slot at run time
+        self._ws = self.SPLITK_WS[1]
         m_ = "trimap.model.Encoder_M."
         stem = self.buf("m_stem", H2, W2, 64)
         for par in (0, 1):

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3 = 0, 1
-ABI_VERSION = 3          # include/otvm_hip.h OTVM_ABI_VERSION
+ABI_VERSION = 4          # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -24,7 +24,8 @@ class ConvParams(C.Structure):
                 ("in_relu", i32), ("act", i32),
                 ("precision", i32), ("w_hi", vp), ("w_lo", vp), ("w_scale", vp), ("w_frag", vp),
                 ("gn_stats", vp),
-                ("in_scale", vp), ("in_shift", vp), ("in_act", i32)]
+                ("in_scale", vp), ("in_shift", vp), ("in_act", i32),
+                ("splitk_ws", vp), ("splitk_ws_bytes", i64)]
 
 
 class PreprocessParams(C.Structure):

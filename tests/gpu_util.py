@@ -46,8 +46,8 @@ def pack_weight(w, ws=False, scale=None, i_pad=None):
 
 
 def conv2d(x, cw, out, bias=None, stride=1, pad=0, dil=1, act=0, in_relu=0, residual=None, precision=0, gn_stats=None,
-           in_norm=None):
-    p = conv_params(x, cw, out, bias, stride, pad, dil, act, in_relu, residual, precision, in_norm)
+           in_norm=None, splitk_ws=None):
+    p = conv_params(x, cw, out, bias, stride, pad, dil, act, in_relu, residual, precision, in_norm, splitk_ws)
     if gn_stats is not None:
         p.gn_stats = gn_stats.data_ptr()
     L.check(L.load().otvm_conv2d(C.byref(p), stream()), "conv2d")

@@ -94,6 +94,47 @@ def test_conv_fused_groupnorm_stats(G, prec, Cin, Cout, H, W):
     assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("Cin,Cout,k,stride,H,W,use_res,act,gn", [
+    (2048, 256, 1, 1, 30, 52, True, 1, False),      # 480p OS16, 64 chunks: 26 tiles of 128x128 -> 4-way split
+    (512, 64, 3, 1, 17, 23, False, 2, False),       # narrow output (128x64 tiles), 3x3 with the fragment weights withheld (see below)
+    (256, 256, 3, 2, 24, 32, False, 0, True),       # strided 3x3 + fused GroupNorm sums (reduced after the finish pass)
+    (2048, 128, 1, 1, 15, 26, True, 0, False),      # ragged M, K = 64 chunks
+])
+def test_conv_split_k(G, Cin, Cout, k, stride, H, W, use_res, act, gn):
+    """Split-K route (otvm_conv_params.splitk_ws): same result as the single-pass kernel up to fp32 summation order,
+    deterministic, bias / residual / activation / GroupNorm sums applied after the reduction."""
+    pad = k // 2
+    x = rnd(1, Cin, H, W, seed=90)
+    w = rnd(Cout, Cin, k, k, seed=91, scale=1.0 / math.sqrt(Cin * k * k))
+    b = rnd(Cout, seed=92)
+    ref = F.conv2d(x, w, b, stride, pad)
+    res = rnd(*ref.shape, seed=93) if use_res else None
+    if use_res:
+        ref = ref + res
+    ref = F.relu(ref) if act == 1 else (F.leaky_relu(ref, 0.01) if act == 2 else ref)
+    # the patch kernel would take 3x3 stride-1 layers before the split is considered: pack without fragment weights
+    cw = G.pack_weight(w)
+    cw.w_frag = None
+    xa = G.to_act(x)
+    ra = G.to_act(res) if use_res else None
+    bd = b.to(G.DEV)
+    ws = torch.empty(16 << 20, device=G.DEV)
+    outs = []
+    for use_ws in (ws, None, ws):
+        out = G.empty_act(ref.shape[2], ref.shape[3], Cout)
+        stats = torch.zeros(64, dtype=torch.float64, device=G.DEV) if gn else None
+        G.conv2d(xa, cw, out, bd, stride, pad, 1, act, 0, ra, precision=1, gn_stats=stats, splitk_ws=use_ws)
+        outs.append((G.from_act(out, Cout), None if stats is None else stats.cpu()))
+    got, plain, again = outs
+    assert G.maxdiff(got[0], ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    assert G.maxdiff(got[0], plain[0]) <= 1e-5 * max(1.0, float(ref.abs().max())) and not torch.equal(got[0], plain[0])
+    assert torch.equal(got[0], again[0])                                   # fixed reduction order
+    if gn:
+        g = ref.double().reshape(32, Cout // 32, -1)
+        want = torch.stack([g.sum((1, 2)), (g * g).sum((1, 2))], 1).flatten()
+        assert float((got[1] - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
 def test_conv_big_tile_fused_groupnorm_stats(G):
     """GroupNorm sums out of the two-stage 256-row tiles (the group sums live behind the epilogue patches in LDS)."""
     Cin, Cout, H, W = 64, 256, 352, 353
