@@ -35,8 +35,8 @@ extern "C" {
 #define OTVM_PREC_F16X3 1
 
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 4    /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
-                                 4: otvm_conv_params.splitk_ws */
+#define OTVM_ABI_VERSION 5    /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
+                                 4: otvm_conv_params.splitk_ws; 5: otvm_preprocess_params.fg_u8/bg_u8/u8_rgb */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -168,6 +168,9 @@ typedef struct {
     float* sq;  int sq_ld;        /* ch0-2 <- Encoder_Q normalised         */
     float* sm;  int sm_ld;        /* ch0-2 <- Encoder_M normalised         */
     float* d80; int d80_ld;       /* ch64-66 <- normalised, ch67-69 <- 0..1 */
+    const unsigned char* fg_u8;   /* optional: decoded frames as uint8 [H,W,3] (interleaved, what an image decoder  */
+    const unsigned char* bg_u8;   /* hands out); when set, fg / bg are ignored.  float(uint8) == the reference's     */
+    int u8_rgb;                   /* .float() of the same pixels; u8_rgb != 0: channels are R,G,B instead of B,G,R   */
 } otvm_preprocess_params;
 int otvm_preprocess(const otvm_preprocess_params* p, void* stream);
 

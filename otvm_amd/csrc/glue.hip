@@ -20,8 +20,15 @@ __global__ void preprocess_kernel(const otvm_preprocess_params p) {
             const float a = p.a[o];
 #pragma unroll
             for (int c = 0; c < 3; ++c) {                     // BGR -> RGB flip (alpha/model.py:384-385)
-                const float sf = p.fg[(2 - c) * plane + o] * s;
-                const float sb = p.bg[(2 - c) * plane + o] * s;
+                float sf, sb;
+                if (p.fg_u8) {                                // decoded uint8 [H,W,3]: float(u8) == the caller's .float()
+                    const int ch = p.u8_rgb ? c : 2 - c;
+                    sf = (float)p.fg_u8[o * 3 + ch] * s;
+                    sb = (float)p.bg_u8[o * 3 + ch] * s;
+                } else {
+                    sf = p.fg[(2 - c) * plane + o] * s;
+                    sb = p.bg[(2 - c) * plane + o] * s;
+                }
                 img[c] = sf * a + sb * (1.f - a);             // alpha/model.py:386
                 p.scaled_imgs[c * plane + o] = img[c];
             }
@@ -217,8 +224,8 @@ int grid_for(int64_t total) {
 }  // namespace
 
 extern "C" int otvm_preprocess(const otvm_preprocess_params* p, void* stream) {
-    OTVM_REQUIRE(p && p->fg && p->bg && p->a && p->x11 && p->sq && p->sm && p->d80 && p->scaled_imgs,
-                 "otvm_preprocess: null pointer");
+    OTVM_REQUIRE(p && ((p->fg && p->bg) || (p->fg_u8 && p->bg_u8)) && p->a && p->x11 && p->sq && p->sm && p->d80 &&
+                     p->scaled_imgs, "otvm_preprocess: null pointer");
     hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for((int64_t)p->Hp * p->Wp)), dim3(256), 0, (hipStream_t)stream, *p);
     OTVM_CHECK_LAUNCH("otvm_preprocess");
     return 0;

@@ -239,19 +239,32 @@ class HipEngine:
         return [float(x) for x in self.sd[key].flatten().tolist()]
 
     def frame(self, a, fg, bg, tri_gt=None, first_frame=False, last_frame=False, memorize=False, max_memory_num=2,
-              dilate_kernel=None, frame_id=None, cls_override=None):
+              dilate_kernel=None, frame_id=None, cls_override=None, frames_rgb=False):
         """One call of EvalModel.forward (reference models/alpha/model.py:391-512) on the HIP path.
 
         a [1,1,1,H,W] in [0,1]; fg, bg [1,1,3,H,W] BGR 0..255; tri_gt [1,1,3,H,W] or None.
+        Extension: fg / bg may be the decoded uint8 images themselves, [H,W,3] interleaved (BGR, or RGB with
+        ``frames_rgb``): the preprocess kernel reads them directly (same arithmetic as ``.float()`` + permute).
         Returns the reference's 5-tuple (scaled_imgs, preds_trimap, tri_gt, preds_alpha, scaled_gts)."""
         dev, lib = self.dev, self.lib
         f32 = torch.float32
         a = a.to(dev, f32).contiguous()
-        fg = fg.to(dev, f32).contiguous()
-        bg = bg.to(dev, f32).contiguous()
-        if a.dim() != 5 or a.shape[0] != 1 or a.shape[1] != 1:
-            raise ValueError("otvm_amd: inputs must be [1,1,C,H,W] (batch 1, one frame), got %s" % (tuple(a.shape),))
-        H, W = int(fg.shape[-2]), int(fg.shape[-1])
+        u8 = fg.dtype == torch.uint8
+        if u8:
+            if bg.dtype != torch.uint8 or fg.dim() != 3 or fg.shape[-1] != 3 or bg.shape != fg.shape:
+                raise ValueError("otvm_amd: uint8 frames must be [H,W,3] for both fg and bg, got %s / %s"
+                                 % (tuple(fg.shape), tuple(bg.shape)))
+            fg, bg = fg.to(dev).contiguous(), bg.to(dev).contiguous()
+            H, W = int(fg.shape[0]), int(fg.shape[1])
+        else:
+            if frames_rgb:
+                raise ValueError("otvm_amd: frames_rgb applies to uint8 [H,W,3] frames only (fp32 input is BGR planar)")
+            fg = fg.to(dev, f32).contiguous()
+            bg = bg.to(dev, f32).contiguous()
+            H, W = int(fg.shape[-2]), int(fg.shape[-1])
+        if a.dim() != 5 or a.shape[0] != 1 or a.shape[1] != 1 or tuple(a.shape[-2:]) != (H, W):
+            raise ValueError("otvm_amd: inputs must be [1,1,C,H,W] (batch 1, one frame), got a %s for %dx%d frames"
+                             % (tuple(a.shape), H, W))
         pl = self.plan(H, W)
         stream = self._stream()
         scaled_imgs = torch.empty((1, 1, 3, H, W), dtype=f32, device=dev)
@@ -291,7 +304,11 @@ class HipEngine:
                 self._memorize(pend, stream)
         pl.stats.zero_()
         pp = L.PreprocessParams()
-        pp.fg, pp.bg, pp.a = fg.data_ptr(), bg.data_ptr(), a.data_ptr()
+        pp.a = a.data_ptr()
+        if u8:
+            pp.fg_u8, pp.bg_u8, pp.u8_rgb = fg.data_ptr(), bg.data_ptr(), 1 if frames_rgb else 0
+        else:
+            pp.fg, pp.bg = fg.data_ptr(), bg.data_ptr()
         pp.H, pp.W, pp.Hp, pp.Wp, pp.lh, pp.lw = H, W, pl.Hp, pl.Wp, pl.lh, pl.lw
         for name, key in (("mean", "IMG_MEAN"), ("std", "IMG_STD"), ("mean_q", "trimap.model.Encoder_Q.mean"),
                           ("std_q", "trimap.model.Encoder_Q.std"), ("mean_m", "trimap.model.Encoder_M.mean"),

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3 = 0, 1
-ABI_VERSION = 4          # include/otvm_hip.h OTVM_ABI_VERSION
+ABI_VERSION = 5          # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -35,7 +35,8 @@ class PreprocessParams(C.Structure):
                 ("mean_m", f32 * 3), ("std_m", f32 * 3),
                 ("scaled_imgs", vp),
                 ("x11", vp), ("x11_ld", i32), ("sq", vp), ("sq_ld", i32), ("sm", vp), ("sm_ld", i32),
-                ("d80", vp), ("d80_ld", i32)]
+                ("d80", vp), ("d80_ld", i32),
+                ("fg_u8", vp), ("bg_u8", vp), ("u8_rgb", i32)]
 
 
 _PROTOS = {

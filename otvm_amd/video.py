@@ -58,7 +58,8 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
     gt_alpha_u8 : optional per-frame ground-truth alpha, uint8 [H,W]; with it SAD/MSE/dtSSD are accumulated on
                   the device (ClipMetrics) and returned under "metrics"; gt_mask_u8 = optional {0,1} evaluation masks,
                   gt_mask="unknown" = the reference metric's default mask (0 < gt < 255) instead
-    backgrounds : optional per-frame BG images (V108 composites fg*a + bg*(1-a)); default bg = fg
+    backgrounds : optional per-frame BG images (V108 composites fg*a + bg*(1-a)), same dtype / channel order as the
+                  frames; default bg = fg
     Returns dict(alpha=[T,H,W] float32, alpha_u8=[T,H,W] uint8 (truncated, eval.py:209), trimap=[T,3,H,W]).
     """
     frames = list(frames) if not (hasattr(frames, "shape") or hasattr(frames, "__getitem__")) else frames
@@ -75,19 +76,29 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
         tri_dev = t.to(dev).float()[None, None]
     ones = None
     for i in range(T):
-        fr = frames[i]
-        f = _as_tensor(fr)
-        f = f.to(dev).float()
-        if frames_are_rgb:
-            f = f.flip(-1)
-        fg = f.permute(2, 0, 1)[None, None].contiguous()
-        H, W = fg.shape[-2:]
-        if backgrounds is not None:
-            b = backgrounds[i]
-            b = _as_tensor(b)
-            bg = b.to(dev).float().permute(2, 0, 1)[None, None].contiguous()
+        f = _as_tensor(frames[i])
+        b = _as_tensor(backgrounds[i]) if backgrounds is not None else None
+        extra = {}
+        if f.dtype == torch.uint8 and (b is None or b.dtype == torch.uint8):
+            # decoded images go to the device as they are ([H,W,3] uint8): the preprocess kernel converts, flips the
+            # channel order and composites -- no per-frame torch conversion / transposition kernels
+            fg = f.to(dev, non_blocking=True)
+            bg = fg if b is None else b.to(dev, non_blocking=True)
+            H, W = fg.shape[:2]
+            extra["_frames_rgb"] = bool(frames_are_rgb)
         else:
-            bg = fg
+            f = f.to(dev).float()
+            if frames_are_rgb:
+                f = f.flip(-1)
+            fg = f.permute(2, 0, 1)[None, None].contiguous()
+            H, W = fg.shape[-2:]
+            if b is not None:                                 # backgrounds come in the same channel order as the frames
+                b = b.to(dev).float()
+                if frames_are_rgb:
+                    b = b.flip(-1)
+                bg = b.permute(2, 0, 1)[None, None].contiguous()
+            else:
+                bg = fg
         if trimap is not None:
             if ones is None or ones.shape[-2:] != (H, W):
                 ones = torch.ones(1, 1, 1, H, W, device=dev)
@@ -99,7 +110,7 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
             tri_gt = None
         memorize, max_memory_num, large = memory_schedule(i, H, W, skip, max_num)
         out = model(a, fg, bg, tri=None, tri_gt=tri_gt, first_frame=(i == 0), last_frame=(i == T - 1),
-                    memorize=memorize, max_memory_num=max_memory_num, large_input=large)
+                    memorize=memorize, max_memory_num=max_memory_num, large_input=large, **extra)
         alpha = out[3][0, 0, 0]
         u8 = core._engine.last_alpha_u8
         if metrics is not None:

@@ -239,3 +239,26 @@ def test_eval_cli_demo_and_v108_layouts(tmp_path, model, synth_sd):
     for t in range(T):
         assert np.array_equal(np.asarray(Image.open(os.path.join(predv, "%05d.png" % t))), refv["alpha_u8"][t].numpy())
     assert abs(refv["metrics"]["sad_sum"] / T - s["gt_metrics"]["sad"]) < 1e-9
+
+
+@pytest.mark.parametrize("rgb", [False, True])
+def test_uint8_frames_equal_float_frames(model, synth_sd, rgb):
+    """Decoded uint8 [H,W,3] frames handed over as they are (otvm_preprocess_params.fg_u8) give bit-identical results
+    to the reference-style fp32 [1,1,3,H,W] BGR tensors, with and without separate backgrounds, for both channel orders."""
+    from otvm_amd.synth_data import soft_alpha, synthetic_clip
+    from otvm_amd.video import run_video_matte
+    H, W, T = 72, 104, 4
+    frames_bgr, tri = synthetic_clip(H, W, T, seed=51)
+    bgs_bgr, _ = synthetic_clip(H, W, T, seed=52)
+    m = model(12).module
+    fr = [f[..., ::-1].copy() if rgb else f for f in frames_bgr]
+    bg = [f[..., ::-1].copy() if rgb else f for f in bgs_bgr]
+    as_f32 = lambda lst: [torch.from_numpy(x.astype(np.float32)) for x in lst]
+    r_u8 = run_video_matte(m, fr, trimap=tri, skip=2, max_num=3, frames_are_rgb=rgb)
+    r_f32 = run_video_matte(m, as_f32(fr), trimap=tri, skip=2, max_num=3, frames_are_rgb=rgb)
+    assert torch.equal(r_u8["alpha"], r_f32["alpha"]) and torch.equal(r_u8["trimap"], r_f32["trimap"])
+    al = [soft_alpha(H, W, t) for t in range(T)]
+    v_u8 = run_video_matte(m, fr, alphas=al, backgrounds=bg, skip=2, max_num=3, frames_are_rgb=rgb)
+    v_f32 = run_video_matte(m, as_f32(fr), alphas=al, backgrounds=as_f32(bg), skip=2, max_num=3, frames_are_rgb=rgb)
+    assert torch.equal(v_u8["alpha"], v_f32["alpha"])
+    assert not torch.equal(v_u8["alpha"], r_u8["alpha"])
