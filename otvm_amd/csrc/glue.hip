@@ -5,6 +5,7 @@
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -33,15 +34,21 @@ __global__ void preprocess_kernel(const otvm_preprocess_params p) {
                 p.scaled_imgs[c * plane + o] = img[c];
             }
         }
+        float n[3], q[3], m[3];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float n = (img[c] - p.mean[c]) / p.std[c];  // alpha/model.py:414
-            p.x11[i * p.x11_ld + c] = n;
-            p.d80[i * p.d80_ld + 64 + c] = n;                 // conv_out[-6][:, :3] (FBA/models.py:377)
-            p.d80[i * p.d80_ld + 67 + c] = img[c];            // img (FBA/models.py:377)
-            p.sq[i * p.sq_ld + c] = (img[c] - p.mean_q[c]) / p.std_q[c];   // STM.py:90
-            p.sm[i * p.sm_ld + c] = (img[c] - p.mean_m[c]) / p.std_m[c];   // STM.py:54
+            n[c] = (img[c] - p.mean[c]) / p.std[c];           // alpha/model.py:414
+            q[c] = (img[c] - p.mean_q[c]) / p.std_q[c];       // STM.py:90
+            m[c] = (img[c] - p.mean_m[c]) / p.std_m[c];       // STM.py:54
         }
+        // 16-byte stores into the interleaved buffers (a pixel's three scalars 48 / 320 bytes apart from the next
+        // pixel's were three uncoalesced store instructions each).  The fourth lane of every vector is a channel a
+        // LATER kernel of the frame owns and overwrites: x11[3] (distance encoding), sq[3] / sm[+3] (zero pad / p_un).
+        *reinterpret_cast<f32x4*>(p.x11 + i * p.x11_ld) = f32x4{n[0], n[1], n[2], 0.f};
+        *reinterpret_cast<f32x4*>(p.d80 + i * p.d80_ld + 64) = f32x4{n[0], n[1], n[2], img[0]};   // FBA/models.py:377
+        *reinterpret_cast<f32x2*>(p.d80 + i * p.d80_ld + 68) = f32x2{img[1], img[2]};
+        *reinterpret_cast<f32x4*>(p.sq + i * p.sq_ld) = f32x4{q[0], q[1], q[2], 0.f};
+        *reinterpret_cast<f32x4*>(p.sm + i * p.sm_ld) = f32x4{m[0], m[1], m[2], 0.f};
     }
 }
 
@@ -226,6 +233,9 @@ int grid_for(int64_t total) {
 extern "C" int otvm_preprocess(const otvm_preprocess_params* p, void* stream) {
     OTVM_REQUIRE(p && ((p->fg && p->bg) || (p->fg_u8 && p->bg_u8)) && p->a && p->x11 && p->sq && p->sm && p->d80 &&
                      p->scaled_imgs, "otvm_preprocess: null pointer");
+    OTVM_REQUIRE(p->x11_ld % 4 == 0 && p->d80_ld % 4 == 0 && p->sq_ld % 4 == 0 && p->sm_ld % 4 == 0 &&
+                     (((uintptr_t)p->x11 | (uintptr_t)p->d80 | (uintptr_t)p->sq | (uintptr_t)p->sm) & 15) == 0,
+                 "otvm_preprocess: x11 / d80 / sq / sm views must be 16-byte aligned with strides that are multiples of 4");
     hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for((int64_t)p->Hp * p->Wp)), dim3(256), 0, (hipStream_t)stream, *p);
     OTVM_CHECK_LAUNCH("otvm_preprocess");
     return 0;
