@@ -81,7 +81,8 @@ typedef struct {
                                                        (otvm_pack_patch_weight_f16x3) or NULL                    */
     double* gn_stats;                               /* optional: fused GroupNorm(32) statistics of the OUTPUT
                                                        (sum, sum of squares per group, [32][2] fp64, accumulated
-                                                       atomically; Cout % 32 == 0, act == NONE, no residual) or NULL */
+                                                       atomically; Cout = 64, 128, 256, ... (32 groups of a power-of-two
+                                                       number of channels), act == NONE, no residual) or NULL        */
     const float* in_scale; const float* in_shift;   /* optional fused normalisation of the INPUT (the GroupNorm apply of
                                                        the producing layer folded into this conv's staging):
                                                        in' = in_act(in * in_scale[c] + in_shift[c]) inside the image, zero

@@ -303,8 +303,11 @@ extern "C" int otvm_conv2d(const otvm_conv_params* p, void* stream) {
     OTVM_REQUIRE(((uintptr_t)p->in & 15) == 0 && ((uintptr_t)p->w & 15) == 0, "otvm_conv2d: in/w must be 16-byte aligned");
     OTVM_REQUIRE(p->precision == OTVM_PREC_F32 || p->precision == OTVM_PREC_F16X3, "otvm_conv2d: unknown precision %d",
                  p->precision);
-    OTVM_REQUIRE(!p->gn_stats || (p->Cout % 64 == 0 && p->act == OTVM_ACT_NONE && !p->residual),
-                 "otvm_conv2d: fused GroupNorm statistics need Cout %% 64 == 0, no activation, no residual");
+    // the in-tile group reduction works on power-of-two runs of channels: 32 groups of 2, 4, 8, ... channels
+    OTVM_REQUIRE(!p->gn_stats || (p->Cout % 64 == 0 && ((p->Cout / 32) & (p->Cout / 32 - 1)) == 0 &&
+                                  p->act == OTVM_ACT_NONE && !p->residual),
+                 "otvm_conv2d: fused GroupNorm statistics need Cout = 64, 128, 256, ... (got %d), no activation, no residual",
+                 p->Cout);
     OTVM_REQUIRE(p->K_pad % 32 == 0 && p->K_pad >= p->kh * p->kw * p->Cin, "otvm_conv2d: K_pad %d too small", p->K_pad);
     const int Ho = (p->H + 2 * p->pad - p->dil * (p->kh - 1) - 1) / p->stride + 1;
     const int Wo = (p->W + 2 * p->pad - p->dil * (p->kw - 1) - 1) / p->stride + 1;

@@ -2,6 +2,7 @@
 (torch fp32 ops / the oracle's functions), through the C ABI."""
 import ctypes as C
 import math
+import os
 
 import numpy as np
 import pytest
@@ -133,6 +134,26 @@ def test_conv_split_k(G, Cin, Cout, k, stride, H, W, use_res, act, gn):
         g = ref.double().reshape(32, Cout // 32, -1)
         want = torch.stack([g.sum((1, 2)), (g * g).sum((1, 2))], 1).flatten()
         assert float((got[1] - want).abs().max()) <= 1e-5 * float(want.abs().max())
+
+
+def test_conv_fuzz_all_routes(G):
+    """tools/conv_fuzz.py: randomised shapes / views / epilogues over every dispatch route (implicit-GEMM tiles, patch
+    kernels, split-K, both precisions) against torch on the CPU."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_fuzz.py"), "--n", "80", "--seed", "3"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "conv_fuzz: 80 cases" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_fused_groupnorm_stats_reject_odd_group_width(G):
+    """The in-tile group reduction needs 32 groups of a power-of-two number of channels: anything else fails loudly."""
+    x, w = rnd(1, 32, 12, 16, seed=95), rnd(192, 32, 1, 1, seed=96)
+    out = G.empty_act(12, 16, 192)
+    stats = torch.zeros(64, dtype=torch.float64, device=G.DEV)
+    with pytest.raises(RuntimeError):
+        G.conv2d(G.to_act(x), G.pack_weight(w), out, precision=1, gn_stats=stats)
 
 
 def test_conv_big_tile_fused_groupnorm_stats(G):
