@@ -28,16 +28,19 @@ __global__ void gn_stats_kernel(const float* __restrict__ x, int64_t P, int C, i
         }
     }
     const int cg = C / G;                         // channels per group (>= 2)
-    if (cg >= 4) {
-        const int g = (q * 4) / cg;
-        atomicAdd(&red[g * 2], (double)s.x + (double)s.y + (double)s.z + (double)s.w);
-        atomicAdd(&red[g * 2 + 1], (double)ss.x + (double)ss.y + (double)ss.z + (double)ss.w);
-    } else {                                      // cg == 2: a float4 straddles two groups
-        const int g = (q * 4) / 2;
-        atomicAdd(&red[g * 2], (double)s.x + (double)s.y);
-        atomicAdd(&red[g * 2 + 1], (double)ss.x + (double)ss.y);
-        atomicAdd(&red[g * 2 + 2], (double)s.z + (double)s.w);
-        atomicAdd(&red[g * 2 + 3], (double)ss.z + (double)ss.w);
+    if (r < rows) {
+        if ((cg & 3) == 0) {                      // a float4 lies inside one group
+            const int g = (q * 4) / cg;
+            atomicAdd(&red[g * 2], (double)s.x + (double)s.y + (double)s.z + (double)s.w);
+            atomicAdd(&red[g * 2 + 1], (double)ss.x + (double)ss.y + (double)ss.z + (double)ss.w);
+        } else {                                  // cg = 2, 6, 10, ...: a float4 straddles groups -> per channel
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int g = (q * 4 + j) / cg;
+                atomicAdd(&red[g * 2], (double)s[j]);
+                atomicAdd(&red[g * 2 + 1], (double)ss[j]);
+            }
+        }
     }
     __syncthreads();
     if (threadIdx.x < G * 2) atomicAdd(&stats[threadIdx.x], red[threadIdx.x]);

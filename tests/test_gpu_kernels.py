@@ -147,6 +147,17 @@ def test_conv_fuzz_all_routes(G):
     assert r.returncode == 0 and "conv_fuzz: 80 cases" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_kernel_fuzz_non_conv(G):
+    """tools/kernel_fuzz.py: GroupNorm (incl. group widths that are not multiples of 4), upsampling, pooling, PPM pooling,
+    memory read and the distance encoding on randomised shapes against torch / the oracle."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "kernel_fuzz.py"), "--n", "24", "--seed", "7"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "kernel_fuzz: 24 rounds" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_fused_groupnorm_stats_reject_odd_group_width(G):
     """The in-tile group reduction needs 32 groups of a power-of-two number of channels: anything else fails loudly."""
     x, w = rnd(1, 32, 12, 16, seed=95), rnd(192, 32, 1, 1, seed=96)
