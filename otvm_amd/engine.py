@@ -739,11 +739,13 @@ class FramePlan:
 
     def new_slot(self):
         e = self.e
+        # a slot carries launch parameters bound to THIS plan's buffers (kv_steps read self.r4m): it may only be recycled
+        # by the plan that made it -- two input sizes with the same padded size have different plans and buffers
         for i, s in enumerate(e.free_slots):
-            if s["hw"] == self.hw:
+            if s["plan"] is self:
                 return e.free_slots.pop(i)
         H16, W16 = self.Hp // 16, self.Wp // 16
-        slot = dict(hw=self.hw, k=Act(torch.zeros(self.hw * 128, dtype=torch.float32, device=self.dev), H16, W16, 128),
+        slot = dict(hw=self.hw, plan=self, k=Act(torch.zeros(self.hw * 128, dtype=torch.float32, device=self.dev), H16, W16, 128),
                     v=Act(torch.zeros(self.hw * 512, dtype=torch.float32, device=self.dev), H16, W16, 512), frame=-1)
         if e.precision == L.PREC_F16X3:        # packed (split fp16, MFMA fragment order) copy read by the f16x3 kernel
             slot["packed"] = torch.zeros(int(self.lib.otvm_bank_slot_bytes_f16x3(self.hw)), dtype=torch.uint8, device=self.dev)

@@ -262,3 +262,35 @@ def test_uint8_frames_equal_float_frames(model, synth_sd, rgb):
     v_f32 = run_video_matte(m, as_f32(fr), alphas=al, backgrounds=as_f32(bg), skip=2, max_num=3, frames_are_rgb=rgb)
     assert torch.equal(v_u8["alpha"], v_f32["alpha"])
     assert not torch.equal(v_u8["alpha"], r_u8["alpha"])
+
+
+def test_same_padded_size_different_input_size_does_not_share_slots(model, synth_sd):
+    """Two clips whose frames pad to the same size (208x88 and 203x77 -> 224x96) matted back to back by ONE module: the
+    second must equal what a fresh module gives (bank slots carry launch parameters bound to a plan's buffers and may not
+    be recycled by another plan; found by tools/frame_fuzz.py)."""
+    from otvm_amd import helpers
+    from otvm_amd.synth_data import synthetic_clip
+    from otvm_amd.video import run_video_matte
+    m = model(12).module
+    fa, ta = synthetic_clip(208, 88, 4, seed=61)
+    fb, tb = synthetic_clip(203, 77, 4, seed=62)
+    run_video_matte(m, fa, trimap=ta, skip=3, max_num=5)
+    second = run_video_matte(m, fb, trimap=tb, skip=3, max_num=5)
+    cfg = helpers.default_cfg()
+    fresh = helpers.get_model_alpha(cfg, helpers.get_model_trimap(cfg, "Test", 12), "Test", 12)
+    fresh.load_state_dict(synth_sd, strict=True)
+    want = run_video_matte(fresh.cuda().eval(), fb, trimap=tb, skip=3, max_num=5)
+    assert torch.equal(second["alpha"], want["alpha"]) and torch.equal(second["trimap"], want["trimap"])
+
+
+def test_frame_fuzz_short():
+    """tools/frame_fuzz.py: random resolutions, schedules, flows and frame dtypes end to end against the oracle."""
+    import os
+    import subprocess
+    import sys
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "frame_fuzz.py"), "--n", "5", "--seed", "4", "--max-side", "150"],
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0 and "frame_fuzz: 5 clips" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
