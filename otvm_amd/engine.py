@@ -276,6 +276,8 @@ class HipEngine:
         # here it opens frame t+1 so that Encoder_M(t) and Encoder_Q(t+1), two chains of small launches that cannot fill
         # 256 CUs on their own, run concurrently on two HIP streams; they meet before the memory read)
         if first_frame:
+            if self.pending is not None:                      # previous clip ended without last_frame=True: its deferred
+                self.free_slots.append(self.pending["slot"])  # memorize is dropped, the slot goes back to the pool
             self.pending = None
             self.reset()
             self.frame_counter = 0

@@ -42,6 +42,7 @@ def main():
         skip, max_num = rng.choice([3, 4, 10]), rng.choice([1, 2, 5])
         v108 = rng.random() < 0.4
         u8 = rng.random() < 0.5
+        abandoned = rng.random() < 0.3
         if dk not in models:
             m = helpers.get_model_alpha(cfg, helpers.get_model_trimap(cfg, "Test", dk), "Test", dk)
             m.load_state_dict(sd, strict=True)
@@ -50,7 +51,8 @@ def main():
         orc = OtvmOracle(sd, dilate_kernel=dk)
         frames, tri = synthetic_clip(H, W, T, seed=7000 + it)
         bgs, _ = synthetic_clip(H, W, T, seed=8000 + it)
-        desc = "%dx%d T%d dk%d skip%d max%d %s %s" % (H, W, T, dk, skip, max_num, "v108" if v108 else "demo", "u8" if u8 else "f32")
+        desc = "%dx%d T%d dk%d skip%d max%d %s %s%s" % (H, W, T, dk, skip, max_num, "v108" if v108 else "demo",
+                                                          "u8" if u8 else "f32", " abandoned" if abandoned else "")
         for t in range(T):
             f32 = lambda x: torch.from_numpy(x.astype(np.float32)).permute(2, 0, 1)[None, None].contiguous()
             fg_ref, bg_ref = f32(frames[t]), (f32(bgs[t]) if v108 else f32(frames[t]))
@@ -65,7 +67,8 @@ def main():
                 a = torch.ones(1, 1, 1, H, W)
                 tg = torch.from_numpy(np.asarray(tri))[None, None]
             memorize, mx, _ = memory_schedule(t, H, W, skip, max_num)
-            kw = dict(first_frame=(t == 0), last_frame=(t == T - 1), memorize=memorize, max_memory_num=mx)
+            # some clips are abandoned without ever passing last_frame=True (the next clip must still start clean)
+            kw = dict(first_frame=(t == 0), last_frame=(t == T - 1) and not abandoned, memorize=memorize, max_memory_num=mx)
             out = m(a, fg_in, bg_in, tri_gt=tg, **kw)
             torch.cuda.synchronize()
             pl = m._engine.last_plan
