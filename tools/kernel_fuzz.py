@@ -145,6 +145,24 @@ def main():
             got8 = x11.reshape(Hp, Wp, 12)[..., 3:11].permute(2, 0, 1).cpu()
             ref8 = make_trimap8(probs)
             worst["edt"] = max(worst.get("edt", 0), check("trimap_encode", got8, ref8, 2e-6, "%dx%d %s" % (Hp, Wp, kind)))
+        # ---- matting metrics (SAD / MSE / dtSSD partial sums per frame) on random sizes and masks
+        if it % 2 == 1:
+            from oracle import metrics_oracle as M
+            from otvm_amd.video import ClipMetrics
+            B, hm2, wm2 = rng.randint(2, 5), rng.randint(1, 70), rng.randint(1, 90)
+            pr = torch.randint(0, 256, (B, hm2, wm2), generator=g).float()
+            tg2 = torch.randint(0, 256, (B, hm2, wm2), generator=g).float()
+            mk = (torch.rand(B, hm2, wm2, generator=g) < rng.uniform(0.05, 0.9)).float()
+            cm = ClipMetrics(G.DEV, capacity=2)
+            for i in range(B):
+                cm.add(pr[i].to(torch.uint8).to(G.DEV), tg2[i].to(torch.uint8).to(G.DEV), mk[i].to(torch.uint8).to(G.DEV))
+            torch.cuda.synchronize()
+            r = cm.result()
+            e, n = M.dtssd(pr, tg2, mk)
+            for name, got_v, ref_v in (("sad", r["sad_per_frame"], M.sad(pr, tg2, mk)), ("mse", r["mse_per_frame"], M.mse(pr, tg2, mk)),
+                                       ("dtssd", r["dtssd_per_pair"], e), ("dtssd_n", r["dtssd_num_per_pair"], n)):
+                worst["met"] = max(worst.get("met", 0), check("metrics." + name, torch.tensor(got_v, dtype=torch.float64),
+                                                                ref_v.double(), 1e-5, "%dx%dx%d" % (B, hm2, wm2)))
     print("kernel_fuzz: %d rounds, worst relative errors %s" % (args.n, {k: "%.2e" % v for k, v in worst.items()}))
 
 
