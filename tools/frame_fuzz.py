@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--n", type=int, default=12)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--max-side", type=int, default=220)
+    ap.add_argument("--precision", default=None, choices=["f32", "f16x3"])
     args = ap.parse_args()
     from oracle.otvm_oracle import OtvmOracle
     from otvm_amd import helpers
@@ -46,6 +47,7 @@ def main():
         if dk not in models:
             m = helpers.get_model_alpha(cfg, helpers.get_model_trimap(cfg, "Test", dk), "Test", dk)
             m.load_state_dict(sd, strict=True)
+            m.precision = args.precision
             models[dk] = m.cuda().eval()
         m = models[dk]
         orc = OtvmOracle(sd, dilate_kernel=dk)
