@@ -393,11 +393,11 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
                                                             int Cout, int ldp, const float* __restrict__ bias,
                                                             const float* __restrict__ residual, int res_ld, int act,
                                                             float* __restrict__ out, int out_ld) {
-    const int Q = ldp >> 2;
-    const int64_t total = M * Q;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const unsigned Q = (unsigned)ldp >> 2;
+    const unsigned total = (unsigned)M * Q;                     // split layers are small: M * ldp / 4 < 2^32 (host check)
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int64_t m = i / Q;
-        const int c = (int)(i - m * Q) * 4;
+        const int c = (int)(i - (unsigned)m * Q) * 4;
         f32x4 v = *reinterpret_cast<const f32x4*>(part + m * ldp + c);
         for (int z = 1; z < S; ++z) v += *reinterpret_cast<const f32x4*>(part + z * stride + m * ldp + c);
 #pragma unroll
@@ -513,7 +513,7 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
         if (S > a.nchunks / 16) S = a.nchunks / 16;
         if (p->gn_stats && a.nchunks < 256 && tiles > 8) S = 1;
         while (S >= 2 && (int64_t)S * M * ldp * (int64_t)sizeof(float) > p->splitk_ws_bytes) --S;
-        if (tiles < 192 && S >= 2) {
+        if (tiles < 192 && S >= 2 && M * (ldp / 4) < (1ll << 32)) {
             Conv3Args b = a;
             b.out = (float*)p->splitk_ws; b.out_ld = ldp; b.split_stride = M * ldp;
             b.bias = nullptr; b.residual = nullptr; b.act = OTVM_ACT_NONE; b.gn_stats = nullptr;

@@ -38,28 +38,36 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, int H, int W, 
 
 // F.interpolate(bilinear, align_corners=False): src = (dst + 0.5) * (in/out) - 0.5, clamped at 0;
 // the upper neighbour index is clamped to the last row/col (PyTorch area_pixel_compute_source_index).
-__global__ void upsample_bilinear_kernel(const float* __restrict__ in, int Hi, int Wi, int C, int in_ld,
-                                         const float* __restrict__ add, int add_ld, float* __restrict__ out, int Ho,
-                                         int Wo, int out_ld, float sy, float sx) {
+// One output row per blockIdx.y: the row terms (y0, y1, ly) are uniform, the column index is a 32-bit division by
+// the channel-quad count (the flat 64-bit index of the first version cost two int64 divisions per float4).
+__global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ in, int Hi, int Wi, int C, int in_ld,
+                                                                const float* __restrict__ add, int add_ld,
+                                                                float* __restrict__ out, int Ho, int Wo, int out_ld, float sy,
+                                                                float sx) {
     const int Q = C >> 2;
-    const int64_t total = (int64_t)Ho * Wo * Q;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t pix = i / Q;
-        const int c = (int)(i - pix * Q) * 4;
-        const int oy = (int)(pix / Wo), ox = (int)(pix - (int64_t)oy * Wo);
-        float fy = ((float)oy + 0.5f) * sy - 0.5f;
+    const int oy = blockIdx.y;
+    float fy = ((float)oy + 0.5f) * sy - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    const int y0 = (int)fy;
+    const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, hy = 1.f - ly;
+    const float* r0 = in + (int64_t)y0 * Wi * in_ld;
+    const float* r1 = in + (int64_t)y1 * Wi * in_ld;
+    const unsigned total = (unsigned)Wo * (unsigned)Q;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned ox = i / (unsigned)Q;
+        const int c = (int)(i - ox * (unsigned)Q) * 4;
         float fx = ((float)ox + 0.5f) * sx - 0.5f;
-        fy = fy < 0.f ? 0.f : fy;
         fx = fx < 0.f ? 0.f : fx;
-        const int y0 = (int)fy, x0 = (int)fx;
-        const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0), x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
-        const float ly = fy - (float)y0, lx = fx - (float)x0;
-        const float hy = 1.f - ly, hx = 1.f - lx;
-        const f32x4 v00 = *reinterpret_cast<const f32x4*>(in + ((int64_t)y0 * Wi + x0) * in_ld + c);
-        const f32x4 v01 = *reinterpret_cast<const f32x4*>(in + ((int64_t)y0 * Wi + x1) * in_ld + c);
-        const f32x4 v10 = *reinterpret_cast<const f32x4*>(in + ((int64_t)y1 * Wi + x0) * in_ld + c);
-        const f32x4 v11 = *reinterpret_cast<const f32x4*>(in + ((int64_t)y1 * Wi + x1) * in_ld + c);
+        const int x0 = (int)fx;
+        const int x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
+        const float lx = fx - (float)x0, hx = 1.f - lx;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(r0 + (int64_t)x0 * in_ld + c);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(r0 + (int64_t)x1 * in_ld + c);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(r1 + (int64_t)x0 * in_ld + c);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(r1 + (int64_t)x1 * in_ld + c);
         f32x4 v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+        const int64_t pix = (int64_t)oy * Wo + ox;
         if (add) v += *reinterpret_cast<const f32x4*>(add + pix * add_ld + c);
         *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = v;
     }
@@ -153,8 +161,11 @@ extern "C" int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, in
     OTVM_REQUIRE(C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0 && (!add || add_ld % 4 == 0),
                  "otvm_upsample_bilinear: channels must be multiples of 4");
     const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
-    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(grid_for((int64_t)Ho * Wo * (C / 4))), dim3(256), 0,
-                       (hipStream_t)stream, in, Hi, Wi, C, in_ld, add, add_ld, out, Ho, Wo, out_ld, sy, sx);
+    OTVM_REQUIRE(Ho <= 65535 && (int64_t)Wo * (C / 4) < (1ll << 31), "otvm_upsample_bilinear: output %dx%d too large", Ho, Wo);
+    int bx = otvm_ceil_div(Wo * (C / 4), 256);
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(bx, Ho), dim3(256), 0, (hipStream_t)stream, in, Hi, Wi, C, in_ld, add,
+                       add_ld, out, Ho, Wo, out_ld, sy, sx);
     OTVM_CHECK_LAUNCH("otvm_upsample_bilinear");
     return 0;
 }
