@@ -294,3 +294,24 @@ def test_frame_fuzz_short():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "frame_fuzz.py"), "--n", "5", "--seed", "4", "--max-side", "150"],
                        capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "frame_fuzz: 5 clips" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_graph_replay_equals_direct_launches(synth_sd):
+    """Opt-in hipGraph replay of the static launch lists (engine.use_graphs) gives bit-identical frames."""
+    from otvm_amd import helpers
+    from otvm_amd.synth_data import synthetic_clip
+    from otvm_amd.video import run_video_matte
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cfg = helpers.default_cfg()
+    frames, tri = synthetic_clip(90, 130, 6, seed=71)
+    outs = []
+    for graphs in (False, True):
+        m = helpers.get_model_alpha(cfg, helpers.get_model_trimap(cfg, "Test", 12), "Test", 12)
+        m.load_state_dict(synth_sd, strict=True)
+        m = m.cuda().eval()
+        m._get_engine().use_graphs = graphs
+        outs.append(run_video_matte(m, frames, trimap=tri, skip=2, max_num=3))
+        if graphs:
+            assert len(m._engine.last_plan.graphs) >= 4          # the lists really were captured and replayed
+    assert torch.equal(outs[0]["alpha"], outs[1]["alpha"]) and torch.equal(outs[0]["trimap"], outs[1]["trimap"])
