@@ -501,16 +501,18 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     // ---- split-K for layers that cannot fill the chip with output tiles alone (OS16/OS32 maps, the whole 480p frame):
     // 128-row tiles, the K chunks of a tile shared by up to 8 workgroups, partials through the caller's workspace
     static const int splitk = getenv("OTVM_SPLITK") ? atoi(getenv("OTVM_SPLITK")) : 1;
-    if (splitk && p->splitk_ws && a.nchunks >= 64) {
+    static const int min_total = getenv("OTVM_SPLITK_MINTOTAL") ? atoi(getenv("OTVM_SPLITK_MINTOTAL")) : 32;
+    if (splitk && p->splitk_ws && a.nchunks >= min_total) {
         const bool wide = p->Cout > 64;
         const int64_t tiles = (int64_t)otvm_ceil_div(M, 128) * otvm_ceil_div(p->Cout, wide ? 128 : 64);
         const int ldp = (p->Cout + 3) & ~3;
-        // at least 16 chunks per workgroup; the reduction pass (and, with fused GroupNorm sums, a statistics pass over
+        // at least 8 chunks per workgroup (16 -> 8 and 64 -> 32 total: 480p 124.9 -> 126.3 fps, 1080p unchanged); the reduction pass (and, with fused GroupNorm sums, a statistics pass over
         // the output) costs two small launches, so moderately deep layers keep the single-pass kernel (measured per
         // layer at 480p / 1080p: 1024->128 3x3 at OS16 0.186 -> 0.058 ms, 1024->256 1x1 + GN 0.035 -> 0.074 ms)
         int S = (int)(384 / (tiles > 0 ? tiles : 1));
         if (S > 8) S = 8;
-        if (S > a.nchunks / 16) S = a.nchunks / 16;
+        static const int min_chunks = getenv("OTVM_SPLITK_MINCHUNKS") ? atoi(getenv("OTVM_SPLITK_MINCHUNKS")) : 8;
+        if (S > a.nchunks / min_chunks) S = a.nchunks / min_chunks;
         if (p->gn_stats && a.nchunks < 256 && tiles > 8) S = 1;
         while (S >= 2 && (int64_t)S * M * ldp * (int64_t)sizeof(float) > p->splitk_ws_bytes) --S;
         if (tiles < 192 && S >= 2 && M * (ldp / 4) < (1ll << 32)) {
