@@ -30,8 +30,9 @@ if ROOT not in sys.path:
 # MI355X_MICROARCH.md, dense peaks.  f16x3 issues three f16 MFMAs per fp32-equivalent product, so its
 # roofline for ALGORITHMIC (fp32-equivalent) FLOPs is the f16 peak / 3.
 PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0 / 3.0}
-KERNEL_NAME = {"f32": "conv_igemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
-               "f16x3": "conv_igemm_f16x3_kernel (3x v_mfma_f32_32x32x16_f16 per fp32-equivalent MAC)"}
+KERNEL_NAME = {"f32": "all otvm_conv2d launches: conv_igemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
+               "f16x3": "all otvm_conv2d launches: conv_igemm_f16x3_kernel + conv_patch_f16x3_kernel (+ split-K finish); "
+                        "3x v_mfma_f32_32x32x16_f16 per fp32-equivalent MAC"}
 
 
 def device_clip(H, W, T, seed, dev):
@@ -85,11 +86,20 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
 
+    # --gpus N > 1 outside a torch.distributed launch: start the N ranks ourselves (one process per GPU, RCCL)
+    from otvm_amd.dist import self_launch_command
+    cmd = self_launch_command(args.gpus, os.environ, torch.cuda.device_count(), os.path.abspath(__file__), sys.argv[1:])
+    if cmd is not None:
+        import subprocess
+        raise SystemExit(subprocess.call(cmd))
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -107,10 +117,13 @@ def main():
     tri = torch.from_numpy(disc_trimap(H, W))[None, None].to(dev)
     a = torch.ones(1, 1, 1, H, W, device=dev)
 
+    t_read = {}                                             # frame -> memory slots its segment step read
+
     def run_frames(t0, t1, sink=None):
         for t in range(t0, t1):
             out = model(a, frames[t], frames[t], tri=None, tri_gt=tri, large_input=False,
                         **frame_kwargs(t, T, args.skip, args.max_num))
+            t_read[t] = model._engine.last_T_read
             if sink is not None:
                 sink.append(out[3])
         return out
@@ -134,20 +147,27 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
-        frames_total = torch.tensor([float(K)], dtype=torch.float64, device=dev)
+        frames_total = torch.tensor([float(K), 1.0], dtype=torch.float64, device=dev)
         dist.all_reduce(frames_total, op=dist.ReduceOp.SUM)
-        total_frames = float(frames_total[0])
+        total_frames, ranks_seen = float(frames_total[0]), int(frames_total[1])
     else:
-        total_frames = float(K)
+        total_frames, ranks_seen = float(K), 1
+    if ranks_seen != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but %d rank(s) took part in the run" % (args.gpus, ranks_seen))
 
     eng = model._engine
     pl = eng.last_plan
     Hp, Wp, hw = pl.Hp, pl.Wp, pl.hw
     peak = PEAK_TFLOPS[eng.precision_name]
-    T_read = min(args.max_num, 5)
-    flops_frame = 2.6195e6 * Hp * Wp + 1280.0 * T_read * hw * hw         # SURVEY.md 8d, steady state
+    # algorithmic FLOPs of the timed frames: convs 2.6195 MFLOP per padded pixel + the memory read
+    # with the number of slots each frame ACTUALLY read (short clips spend their first 16 frames below 5 slots)
+    timed_T = [t_read[t] for t in range(Wm, T)]
+    flops_frame = 2.6195e6 * Hp * Wp + 1280.0 * (sum(timed_T) / float(K)) * hw * hw
+    hist = {}
+    for n_ in timed_T:
+        hist[str(n_)] = hist.get(str(n_), 0) + 1
     result = {
-        "metric": "frames_per_sec", "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world,
+        "metric": "frames_per_sec", "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": ranks_seen,
         "steps": K, "warmup": Wm, "ms_per_step": 1000.0 * elapsed / K, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if eng.precision_name == "f32" else "f16x3 (fp32 operands split into fp16 hi+lo, fp32 accumulate)",
         "data": "synthetic",
@@ -155,7 +175,9 @@ def main():
                                "trimap propagation + alpha + memorize per frame, one sequence per GPU" %
                                (W, H, T, Wm, K, args.skip, args.max_num),
                    "padded": [Hp, Wp], "weights": "synthetic (otvm_amd.synth_weights seed 0)",
-                   "parallelism": "sequence-per-gpu x%d" % world},
+                   "parallelism": "sequence-per-gpu x%d" % world,
+                   "T_read_timed_frames": {"mean": sum(timed_T) / float(K), "histogram": hist}},
+        "ranks_seen": ranks_seen,
         "algorithmic_tflop_per_frame": flops_frame / 1e12,
         "achieved_tflops_whole_frame": flops_frame / 1e12 / (elapsed / K),
         "alpha_checksum": float(alpha_last.double().mean()),
@@ -167,7 +189,9 @@ def main():
         eng.prof = []
         run_frames(T - nrep, T)
         torch.cuda.synchronize(dev)
-        prof, eng.prof = eng.prof, None
+        prof_all, eng.prof = eng.prof, None
+        prof = [p_ for p_ in prof_all if p_[0].startswith("conv ")]
+        mr = [p_ for p_ in prof_all if p_[0] == "memory_read"]
         tot_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1, _ in prof)
         tot_fl = float(sum(f for _, f, _, _, _ in prof))
         tot_by = float(sum(b for _, _, _, _, b in prof))
@@ -185,9 +209,10 @@ def main():
         # HBM bytes per conv launch from the committed PMC passes of this same command (profiles/, tools/pmc_traffic.py);
         # only quoted when that run matches this configuration
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "r01_conv_traffic_%s_%dx%d.json" % (eng.precision_name, W, H))
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("traffic_bytes_per_launch")
+        import glob
+        tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_conv_traffic_%s_%dx%d.json" % (eng.precision_name, W, H))))
+        if tpaths:                                          # the most recent round's passes
+            traffic = json.load(open(tpaths[-1])).get("traffic_bytes_per_launch")
         result["roofline"] = {
             "bound": "mfma", "kernel": KERNEL_NAME[eng.precision_name],
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -199,6 +224,17 @@ def main():
             "method": "torch.cuda.Event pairs on the launch stream around every otvm_conv2d launch, replay of the last "
                       "%d timed frames; FLOPs = 2*Ho*Wo*Cout*kh*kw*Cin (un-padded)" % nrep,
         }
+        if mr:
+            # the memory-read contraction (north_star: >= 40 % MFMA utilisation): algorithmic FLOPs 1280*T*hw^2 over the
+            # HIP-event time of otvm_memory_read_f16x3 (kernel + combine), same replay
+            mr_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1, _ in mr)
+            mr_fl = float(sum(f for _, f, _, _, _ in mr))
+            mr_t = mr_fl / (mr_ms * 1e-3) / 1e12
+            result["memory_read"] = {"ms_per_launch": mr_ms / len(mr), "launches": len(mr), "achieved": mr_t, "peak": peak,
+                                     "unit": "TFLOP/s", "frac": mr_t / peak,
+                                     "T_read": [int(b) for _, _, _, _, b in mr],
+                                     "note": "frac = share of the MFMA peak spent on ALGORITHMIC flops; the kernel also "
+                                             "issues the softmax rescale and padded tiles, see profiles/ for MFMA-busy"}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle (port of the reference algorithm) on the host cores, ONE steady-state frame of the

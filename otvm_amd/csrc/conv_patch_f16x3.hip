@@ -427,6 +427,9 @@ int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream) {
         if (p->dil == 2) return launch_patch<8, 256, 8, 2, 3>(a, s);
         return launch_patch<8, 256, 8, 4, 3>(a, s);
     }
+    static const int th16 = getenv("OTVM_PATCH_TH16") ? atoi(getenv("OTVM_PATCH_TH16")) : 0;
+    if (p->dil == 1 && th16 && (int64_t)p->H * p->W >= (1 << 18))      // 16x32 pixel blocks, 8 waves: half the weight stream per pixel
+        return p->Cout <= 32 ? launch_patch<16, 32, 8, 1>(a, s) : launch_patch<16, 64, 8, 1>(a, s);
     if (p->dil == 1) return p->Cout <= 32 ? launch_patch<8, 32, 4, 1>(a, s) : launch_patch<8, 64, 4, 1>(a, s);
     if (p->dil == 2) return launch_patch<8, 64, 4, 2>(a, s);
     return launch_patch<8, 64, 4, 4>(a, s);

@@ -122,12 +122,28 @@ def read_fg_with_alpha(path):
     return np.ascontiguousarray(im[..., 2::-1]), np.ascontiguousarray(im[..., 3])
 
 
+def read_trimap_unchanged(path):
+    """cv2.imread(path, IMREAD_UNCHANGED) for a trimap file (dataset.py:879): grayscale stays 2-D (8 or 16 bit),
+    colour comes back in cv2's BGR(A) order (trimap_file_to_onehot reads unknown from channel 2 = R and foreground from
+    channel 1 = G), palette images are expanded to colour as OpenCV does."""
+    from PIL import Image
+    im = Image.open(path)
+    if im.mode in ("L", "I;16", "I;16B", "I"):
+        return np.asarray(im)
+    if im.mode == "1":
+        return np.asarray(im.convert("L"))
+    if im.mode in ("RGBA", "LA", "PA") or (im.mode == "P" and "transparency" in im.info):
+        a = np.asarray(im.convert("RGBA"))
+        return np.ascontiguousarray(np.concatenate([a[..., 2::-1], a[..., 3:]], -1))
+    return np.ascontiguousarray(np.asarray(im.convert("RGB"))[..., ::-1])
+
+
 def resolve_bg(path):
     """dataset.py:896-899: a listed background that does not exist is looked up with a .png extension."""
     return path if os.path.exists(path) else os.path.splitext(path)[0] + ".png"
 
 
-def load_sequence(item, max_frames=None):
+def load_sequence(item, max_frames=None, decode_frames=True):
     """Decode one item of either iterator into what run_video_matte takes.
 
     Returns dict(name, names=[file stems], frames=[uint8 BGR], and either trimap=one-hot [3,H,W] (demo) or
@@ -139,11 +155,16 @@ def load_sequence(item, max_frames=None):
     names = [os.path.splitext(os.path.basename(p))[0] for p in FG[:n]]
     out = dict(name=seq_name, names=names, data_name=data_name)
     if data_name == "demo":
-        out["frames"] = [read_bgr(os.path.join(root, p)) for p in FG[:n]]
-        tri = next((t for t in TRI if t), "")
+        if decode_frames:                          # False: the caller decodes ahead itself from "frame_paths"
+            out["frames"] = [read_bgr(os.path.join(root, p)) for p in FG[:n]]
+        # the reference reads the trimap listed for each frame (dataset.py:879) and the model consumes the first
+        # frame's: a clip whose FIRST frame has no trimap file cannot be evaluated (cv2.imread('') -> None there)
+        tri = TRI[0] if TRI else ""
         if not tri:
-            raise FileNotFoundError("sequence %s has no trimap under %s/%s/trimap" % (seq_name, root, seq_name))
-        out["trimap"] = trimap_file_to_onehot(_imread(os.path.join(root, tri)))
+            raise FileNotFoundError("sequence %s: no trimap for its first frame (%s/%s/trimap/%s.png)"
+                                    % (seq_name, root, seq_name, names[0] if names else "?"))
+        out["trimap"] = trimap_file_to_onehot(read_trimap_unchanged(os.path.join(root, tri)))
+        out["frame_paths"] = [os.path.join(root, p) for p in FG[:n]]
         return out
     frames, gts = [], []
     for p in FG[:n]:

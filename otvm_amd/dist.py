@@ -13,6 +13,27 @@ import time
 import torch
 
 
+def self_launch_command(n_gpus, env, device_count, script, argv, python=None, port=None):
+    """``bench.py --gpus N`` (or eval_cli) started as a plain process: the command that launches its N ranks, one
+    process per GPU (the reference runs one device per process, eval.py:42,80), or None when the caller should run
+    in-process (N == 1, or already inside a torch.distributed launch: RANK set).  Raises when the node has fewer than
+    N GPUs -- a run must never report n_gpus it did not use."""
+    import socket
+    import sys
+    if n_gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" in env or n_gpus == 1:
+        return None
+    if device_count < n_gpus:
+        raise SystemExit("--gpus %d requested but only %d GPU(s) are visible on this node" % (n_gpus, device_count))
+    if port is None:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [python or sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+
+
 def shard_sequences(n_sequences, rank, world, lengths=None):
     """Indices of the sequences rank ``rank`` processes.  With ``lengths`` (frames per sequence) the split is
     longest-first greedy (balanced frame counts); otherwise round-robin."""
@@ -66,11 +87,21 @@ def run_sharded(sequences, matte_fn, rank=0, world=1, device="cpu", reference_fn
         torch.cuda.synchronize()
     secs = time.perf_counter() - t0
     # ground-truth metrics accumulated on the device by video.ClipMetrics (sequences run with gt_alpha_u8)
-    keys = ("frames", "sad_sum", "mse_num", "mask_sum", "dt_err2_sum", "dt_mask_sum")
+    # plus the sums of the reference's per-frame values (utils/tmp/metric.py:184-189: MSE = mean over frames of
+    # err^2 / (mask_sum + 1); :252-264: dtSSD = per-pair sqrt(err^2) with its own normaliser), so the reduced report
+    # carries the numbers the reference's BatchMetric would print, not only pooled ratios
+    keys = ("frames", "sad_sum", "mse_num", "mask_sum", "dt_err2_sum", "dt_mask_sum", "mse_frame_sum", "dtssd_pair_sum", "dtssd_norm_sum",
+            "pairs")
     clip = [0.0] * len(keys)
     for out in outputs.values():
         m = out.get("metrics") if isinstance(out, dict) else None
         if m:
+            m = dict(m)
+            m["mse_frame_sum"] = float(sum(m.get("mse_per_frame", [])))
+            dt, dn = m.get("dtssd_per_pair", []), m.get("dtssd_num_per_pair", [])
+            m["dtssd_pair_sum"] = float(sum(dt))                             # the (error, num) pairs dtSSD returns
+            m["dtssd_norm_sum"] = float(sum(e / n for e, n in zip(dt, dn)))
+            m["pairs"] = float(len(dt))
             clip = [c + float(m[k]) for c, k in zip(clip, keys)]
     red, (maxabs_g, wall_g) = reduce_metrics([sad, frames, secs] + clip, [maxabs, secs], device)
     sad_g, frames_g, secs_sum = red[:3]
@@ -80,6 +111,9 @@ def run_sharded(sequences, matte_fn, rank=0, world=1, device="cpu", reference_fn
     if g["frames"] > 0:
         # per-frame means as utils/tmp/metric.py reports them (SAD /1000 per frame; MSE over evaluated pixels)
         summary["gt_metrics"] = dict(frames=g["frames"], sad=g["sad_sum"] / g["frames"],
-                                     mse=g["mse_num"] / max(1.0, g["mask_sum"]),
+                                     mse=g["mse_num"] / max(1.0, g["mask_sum"]),                # pooled over all pixels
+                                     mse_mean=g["mse_frame_sum"] / g["frames"],                  # reference: per-frame mean
+                                     dtssd_mean=g["dtssd_pair_sum"] / max(1.0, g["pairs"]),       # mean of the per-pair errors
+                                     dtssd_norm_mean=g["dtssd_norm_sum"] / max(1.0, g["pairs"]),  # ... of error / num
                                      dtssd_sum_err2=g["dt_err2_sum"], dtssd_mask_sum=g["dt_mask_sum"])
     return summary

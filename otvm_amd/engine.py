@@ -171,6 +171,7 @@ class HipEngine:
         self.prof = None
         self.pending = None          # deferred memorize of the previous frame
         self.frame_counter = 0
+        self.last_T_read = 0
         self.parity = 0
         self.side = None
         import os
@@ -200,6 +201,10 @@ class HipEngine:
         return scale, bias
 
     def _pack_all(self):
+        with torch.cuda.device(self.dev):
+            self._pack_all_on_device()
+
+    def _pack_all_on_device(self):
         sd = self.sd
         for k, v in sd.items():
             if not (k.endswith(".weight") and v.dim() == 4):
@@ -243,8 +248,14 @@ class HipEngine:
     def _vec3(self, key):
         return [float(x) for x in self.sd[key].flatten().tolist()]
 
-    def frame(self, a, fg, bg, tri_gt=None, first_frame=False, last_frame=False, memorize=False, max_memory_num=2,
-              dilate_kernel=None, frame_id=None, cls_override=None, frames_rgb=False):
+    def frame(self, *args, **kw):
+        # the raw launches below go to torch's current stream of self.dev: make that device current for the call (a model
+        # on cuda:N called without torch.cuda.set_device(N) would otherwise launch into another device's context)
+        with torch.cuda.device(self.dev):
+            return self._frame(*args, **kw)
+
+    def _frame(self, a, fg, bg, tri_gt=None, first_frame=False, last_frame=False, memorize=False, max_memory_num=2,
+               dilate_kernel=None, frame_id=None, cls_override=None, frames_rgb=False):
         """One call of EvalModel.forward (reference models/alpha/model.py:391-512) on the HIP path.
 
         a [1,1,1,H,W] in [0,1]; fg, bg [1,1,3,H,W] BGR 0..255; tri_gt [1,1,3,H,W] or None.
@@ -340,6 +351,7 @@ class HipEngine:
                                                ws.data_ptr(), stream), "trimap_from_alpha")
             tri_src = tri_gt_out
 
+        self.last_T_read = 0
         if first_frame:
             L.check(lib.otvm_pad_trimap(tri_src.data_ptr(), H, W, pl.PROBS.data_ptr(), pl.Hp, pl.Wp, pl.lh, pl.lw, stream),
                     "pad_trimap")
@@ -349,7 +361,14 @@ class HipEngine:
                 main.wait_event(ev_side)
             if not self.bank:
                 raise RuntimeError("otvm_amd: non-first frame with an empty memory bank (call with first_frame=True first)")
+            self.last_T_read = len(self.bank)
+            if self.prof is not None:                         # bench.py roofline leg: HIP events around the memory read
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             pl.memory_read(self.bank, stream)
+            if self.prof is not None:
+                e1.record()
+                self.prof.append(("memory_read", 1280.0 * len(self.bank) * pl.hw * pl.hw, e0, e1, len(self.bank)))
             pl.run("segment_b", stream)
         if first_frame and ev_side is not None:
             main.wait_event(ev_side)
@@ -388,7 +407,8 @@ class HipEngine:
         """Run a deferred memorize now (bank introspection, end of stream)."""
         pend, self.pending = self.pending, None
         if pend is not None:
-            self._memorize(pend, self._stream())
+            with torch.cuda.device(self.dev):
+                self._memorize(pend, self._stream())
 
     def _consts(self, key):
         c = getattr(self, "_const_cache", None)

@@ -9,7 +9,11 @@ Dataset layouts: otvm_amd/datasets.py (Demo_Test / VideoMatting108_Test, referen
 from the ground-truth alpha with the --trimap dilation, and SAD / MSE / dtSSD against the ground truth are
 accumulated on the device and reduced over ranks.  Alpha PNGs are written as trunc(alpha*255) (eval.py:209-217);
 --viz adds the six-panel composite frames (eval.py:96-115) and, when ffmpeg exists, the mp4 (eval.py:229-242).
-With torch.distributed initialised (torchrun) sequences are sharded one-per-GPU.
+Frame IO runs through otvm_amd/io_pipeline.py: the demo flow decodes ahead in a thread pool and uploads on a copy
+stream, both flows download the 8-bit alphas asynchronously and PNG-encode them in a pool (the reference's loop blocks
+on .cpu() + cv2.imwrite per frame, eval.py:209-217).
+Multi-GPU: `--gpus N` starts N ranks (one process per GPU) itself, or launch with torchrun; sequences are sharded
+one-per-GPU and the metric sums meet in one all-reduce.
 """
 import argparse
 import os
@@ -31,11 +35,21 @@ def main(argv=None):
     ap.add_argument("--skip", type=int, default=10)          # cfg.TEST.MEMORY_SKIP_FRAME (config.py:23)
     ap.add_argument("--max-num", type=int, default=5)        # cfg.TEST.MEMORY_MAX_NUM   (config.py:22)
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3"])
+    ap.add_argument("--gpus", type=int, default=None, help="start this many ranks, one per GPU (default: the launcher's)")
+    ap.add_argument("--sync-io", action="store_true", help="write PNGs synchronously in the frame loop (as eval.py does)")
     args = ap.parse_args(argv)
     from PIL import Image
     from . import helpers
-    from .dist import run_sharded
+    from .dist import run_sharded, self_launch_command
+    from .io_pipeline import AlphaWriter, FramePrefetcher, _Listish
     from .video import run_video_matte
+
+    if args.gpus is not None and args.gpus > 1 and "RANK" not in os.environ:
+        import subprocess
+        import sys
+        cmd = self_launch_command(args.gpus, os.environ, torch.cuda.device_count(), "-m",
+                                  ["otvm_amd.eval_cli"] + list(sys.argv[1:] if argv is None else argv))
+        raise SystemExit(subprocess.call(cmd))
 
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
@@ -52,7 +66,10 @@ def main(argv=None):
     else:
         model.load_state_dict(torch.load(args.weights, map_location="cpu"), strict=True)     # eval.py:77-79
     model.precision = args.precision
-    model = torch.nn.DataParallel(model.to(dev)).eval()                                        # eval.py:80
+    # eval.py:80 wraps the model in nn.DataParallel with ONE visible device (CUDA_VISIBLE_DEVICES, eval.py:42).  Under a
+    # launcher every GPU is visible to every rank, so the wrapper is pinned to this rank's device: with the default
+    # device_ids it would scatter the frames over all GPUs and its per-call replicas would lose the memory bank.
+    model = torch.nn.DataParallel(model.to(dev), device_ids=[dev.index], output_device=dev.index).eval()
     from . import datasets, viz
     ds = datasets.Demo_Test(args.data) if args.demo else datasets.VideoMatting108_Test(args.data, mode="val",
                                                                                        use_subset=args.subset)
@@ -61,24 +78,38 @@ def main(argv=None):
     root_out = os.path.join(args.out, "alpha", "test", helpers.get_model_name(cfg))
 
     def matte(seq):
-        data = datasets.load_sequence(seq["item"], max_frames=args.max_frames)
+        demo = seq["item"][0] == "demo"
+        data = datasets.load_sequence(seq["item"], max_frames=args.max_frames, decode_frames=not demo or args.sync_io)
         outdir = os.path.join(root_out, "pred", seq["name"])
         os.makedirs(outdir, exist_ok=True)
         vizdir = os.path.join(args.out, "viz", "test", helpers.get_model_name(cfg), "viz", seq["name"])
         if args.viz:
             os.makedirs(vizdir, exist_ok=True)
+        writer = None if args.sync_io else AlphaWriter(dev, outdir, [n + ".png" for n in data["names"]])
 
         def save(i, alpha, u8, out):
-            Image.fromarray(u8.cpu().numpy()).save(os.path.join(outdir, data["names"][i] + ".png"))
+            if writer is None:
+                Image.fromarray(u8.cpu().numpy()).save(os.path.join(outdir, data["names"][i] + ".png"))
+            else:
+                writer.put(i, u8)
             if args.viz:
                 viz.write_viz_frame(os.path.join(vizdir, "f%d.jpg" % i), out)
-        if data["data_name"] == "demo":
-            res = run_video_matte(model, data["frames"], trimap=data["trimap"], skip=args.skip, max_num=args.max_num,
-                                  on_frame=save, device=dev)
+        if demo:
+            if args.sync_io:
+                frames, rgb, pre = data["frames"], False, None
+            else:                                  # decode ahead + pinned upload on a copy stream (RGB order)
+                pre = FramePrefetcher(data["frame_paths"], dev)
+                frames, rgb = _Listish(pre), True
+            res = run_video_matte(model, frames, trimap=data["trimap"], skip=args.skip, max_num=args.max_num,
+                                  on_frame=save, device=dev, frames_are_rgb=rgb, keep_on_device=True)
+            if pre is not None:
+                pre.close()
         else:
             res = run_video_matte(model, data["frames"], alphas=data["alphas"], backgrounds=data["backgrounds"],
                                   skip=args.skip, max_num=args.max_num, on_frame=save, device=dev,
-                                  gt_alpha_u8=data["gt_alpha_u8"], gt_mask="unknown")
+                                  gt_alpha_u8=data["gt_alpha_u8"], gt_mask="unknown", keep_on_device=True)
+        if writer is not None:
+            writer.close()
         if args.viz:
             viz.make_viz_video(os.path.join(vizdir, "f%d.jpg"),                          # eval.py:229-242
                                os.path.join(args.out, "viz", "test", helpers.get_model_name(cfg), "viz",
@@ -89,7 +120,8 @@ def main(argv=None):
         print("done | %d frames | %.2f frames/s over %d GPU(s)" % (summary["frames"], summary["fps"], world))
         if "gt_metrics" in summary:
             g = summary["gt_metrics"]
-            print("vs ground truth (unknown band) | SAD/frame %.4f | pooled MSE %.6f | frames %d" % (g["sad"], g["mse"], g["frames"]))
+            print("vs ground truth (unknown band) | SAD/frame %.4f | MSE/frame %.6f (pooled %.6f) | dtSSD/pair %.6f | frames %d"
+                  % (g["sad"], g["mse_mean"], g["mse"], g["dtssd_mean"], g["frames"]))
     return summary
 
 

@@ -21,7 +21,7 @@ def trimap_file_to_onehot(tri):
     """Grayscale / 3-channel trimap image -> one-hot float32 [3,H,W] (bg, unknown, fg): dataset.py:880-893."""
     tri = np.asarray(tri)
     if tri.ndim == 3:
-        t = tri > 1                                    # BGR order as read by cv2
+        t = tri[..., :3] > 1                           # BGR order as read by cv2 (an alpha plane carries no class)
         out = np.zeros(t.shape, np.float32)
         out[..., 0][np.logical_not(t[..., 1] + t[..., 2])] = 1
         out[..., 1][t[..., 2]] = 1
@@ -60,12 +60,13 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
                   gt_mask="unknown" = the reference metric's default mask (0 < gt < 255) instead
     backgrounds : optional per-frame BG images (V108 composites fg*a + bg*(1-a)), same dtype / channel order as the
                   frames; default bg = fg
-    Returns dict(alpha=[T,H,W] float32, alpha_u8=[T,H,W] uint8 (truncated, eval.py:209), trimap=[T,3,H,W]).
+    Returns dict(alpha=[T,H,W] float32, alpha_u8=[T,H,W] uint8 (truncated, eval.py:209), trimap=[T,3,H,W],
+    bank_frames=[per frame: ids of the frames resident in the memory bank after that frame's update]).
     """
     frames = list(frames) if not (hasattr(frames, "shape") or hasattr(frames, "__getitem__")) else frames
     T = len(frames)
     dev = device or next(model.parameters()).device
-    out_a, out_u8, out_t = [], [], []
+    out_a, out_u8, out_t, bank_log = [], [], [], []
     core = model.module if hasattr(model, "module") else model
     metrics = ClipMetrics(dev) if gt_alpha_u8 is not None else None
     # loop invariants: the user trimap (25 MB as fp32 at 1080p) is uploaded once, not once per frame; the dummy alpha
@@ -113,6 +114,7 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
                     memorize=memorize, max_memory_num=max_memory_num, large_input=large, **extra)
         alpha = out[3][0, 0, 0]
         u8 = core._engine.last_alpha_u8
+        bank_log.append(list(core.memories["frames"]))          # frame ids resident after this frame's update (host list)
         if metrics is not None:
             g = gt_alpha_u8[i]
             g = _as_tensor(g)
@@ -127,7 +129,7 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
             out_a.append(alpha), out_u8.append(u8), out_t.append(out[1][0, 0])
         else:
             out_a.append(alpha.cpu()), out_u8.append(u8.cpu()), out_t.append(out[1][0, 0].cpu())
-    res = dict(alpha=torch.stack(out_a), alpha_u8=torch.stack(out_u8), trimap=torch.stack(out_t))
+    res = dict(alpha=torch.stack(out_a), alpha_u8=torch.stack(out_u8), trimap=torch.stack(out_t), bank_frames=bank_log)
     if metrics is not None:
         res["metrics"] = metrics.result()
     return res

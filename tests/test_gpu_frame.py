@@ -241,6 +241,32 @@ def test_eval_cli_demo_and_v108_layouts(tmp_path, model, synth_sd):
     assert abs(refv["metrics"]["sad_sum"] / T - s["gt_metrics"]["sad"]) < 1e-9
 
 
+def test_viz_composite_pixels_on_device(model, synth_sd, tmp_path):
+    """--viz (eval.py:96-115): the six-panel grid computed from the device outputs equals the same composite computed
+    from their CPU copies (the panel arithmetic itself is pinned to the reference's write_image by
+    tests/test_host_logic.py::test_viz_panels_match_reference_write_image), and the JPEG that lands on disk decodes to it."""
+    from PIL import Image
+    from otvm_amd.viz import make_grid_u8, viz_panels, write_viz_frame
+    meta = META["demo_64x96_s3m3"]
+    m = model(meta["dilate_kernel"])
+    a, fg, bg, tri_gt = clip_inputs(meta)[0]
+    out = m(a, fg, bg, tri=None, tri_gt=tri_gt, **frame_flags(meta, 0))
+    grid_dev = make_grid_u8(viz_panels(out), nrow=2)
+    grid_cpu = make_grid_u8(viz_panels(tuple(o.cpu() for o in out)), nrow=2)
+    H, W = meta["H"], meta["W"]
+    assert grid_dev.shape == (3 * (H // 2 + 2) + 2, 2 * (W // 2 + 2) + 2, 3)
+    assert int(np.abs(grid_dev.astype(np.int32) - grid_cpu.astype(np.int32)).max()) <= 1
+    # panel 5 (bottom right) is the predicted alpha, panel 2 (middle left) the first-frame trimap
+    ph, pw = H // 2, W // 2
+    al = torch.nn.functional.interpolate(out[3][0].cpu(), size=(ph, pw), mode="bilinear", align_corners=False)[0, 0]
+    tile = grid_dev[2 * (ph + 2) + 2:2 * (ph + 2) + 2 + ph, (pw + 2) + 2:(pw + 2) + 2 + pw, 0]
+    assert int(np.abs(tile.astype(np.int32) - (al * 255 + 0.5).clamp(0, 255).to(torch.uint8).numpy().astype(np.int32)).max()) <= 1
+    path = str(tmp_path / "f0.jpg")
+    write_viz_frame(path, out)
+    back = np.asarray(Image.open(path)).astype(np.int32)
+    assert back.shape == grid_dev.shape and float(np.abs(back - grid_dev.astype(np.int32)).mean()) < 6.0     # JPEG is lossy
+
+
 @pytest.mark.parametrize("rgb", [False, True])
 def test_uint8_frames_equal_float_frames(model, synth_sd, rgb):
     """Decoded uint8 [H,W,3] frames handed over as they are (otvm_preprocess_params.fg_u8) give bit-identical results

@@ -456,9 +456,10 @@ def test_glue_kernels(G):
     from otvm_amd.synth_data import soft_alpha
     lib = L.load()
     H, W = 50, 70
-    # first-frame trimap from GT alpha, narrow / medium kernels (alpha/model.py:342-362)
+    # first-frame trimap from GT alpha, narrow / medium / wide kernels (eval.py:67-72: 5 / 12 / 20 -> 11, 25 and 41
+    # pixel windows; alpha/model.py:342-362)
     a = torch.from_numpy(soft_alpha(H, W, 0))
-    for r in (5, 12):
+    for r in (5, 12, 20):
         trimask = ((a > 0) & (a < 1)).float()[None, None]
         tm = F.max_pool2d(trimask, 2 * r + 1, 1, r)[0, 0]
         t1 = torch.where(tm > 0.5, torch.ones_like(a), 2 * a).long()
@@ -527,3 +528,107 @@ def test_matting_metrics(G):
         cm2.add(p[i].to(torch.uint8).to(G.DEV), t[i].to(torch.uint8).to(G.DEV), "unknown")
     unk = ((t > 0) & (t < 255)).float()
     assert np.allclose(cm2.result()["sad_per_frame"], M.sad(p, t, unk).numpy(), rtol=1e-5, atol=1e-9)
+
+
+# ---- the reference-held vectors of tests/golden/ops.npz (outputs of the imported reference's own functions,
+# tests/golden/make_golden.py) fed straight to the HIP kernels through the C ABI
+def _ops():
+    import os
+    from tests.common import GOLDEN
+    return np.load(os.path.join(GOLDEN, "ops.npz"))
+
+
+@pytest.mark.parametrize("T", [1, 2, 5])
+def test_reference_vectors_memory_read(G, T):
+    """Memory.forward (STM.py:144-163) vectors mem{1,2,5}_* -> otvm_memory_read / otvm_memory_read_f16x3."""
+    from otvm_amd import lib as L
+    lib = L.load()
+    ops = _ops()
+    mk, mv = torch.from_numpy(ops["mem%d_mk" % T][0]), torch.from_numpy(ops["mem%d_mv" % T][0])      # [C,T,h,w]
+    qk = torch.from_numpy(ops["mem%d_qk" % T][0])
+    want = torch.from_numpy(ops["mem%d_out" % T][0])                                                   # [1024,h,w]
+    h, w = qk.shape[-2:]
+    hw = h * w
+    ref = want[:512].reshape(512, hw).t()
+    keys = [mk[:, t].reshape(128, hw).t().contiguous().to(G.DEV) for t in range(T)]
+    vals = [mv[:, t].reshape(512, hw).t().contiguous().to(G.DEV) for t in range(T)]
+    q = qk.reshape(128, hw).t().contiguous().to(G.DEV)
+    ws = torch.empty(int(lib.otvm_memory_read_ws_bytes(hw, T)), dtype=torch.uint8, device=G.DEV)
+    out = torch.full((hw, 512), float("nan"), device=G.DEV)
+    kp = (C.c_void_p * T)(*[k.data_ptr() for k in keys])
+    vp = (C.c_void_p * T)(*[v.data_ptr() for v in vals])
+    L.check(lib.otvm_memory_read(q.data_ptr(), 128, kp, vp, T, hw, out.data_ptr(), 512, ws.data_ptr(), G.stream()))
+    torch.cuda.synchronize()
+    tol = 2e-5 * max(1.0, float(ref.abs().max()))
+    assert G.maxdiff(out.cpu(), ref) <= tol
+    slots = []
+    for t in range(T):
+        sl = torch.zeros(int(lib.otvm_bank_slot_bytes_f16x3(hw)), dtype=torch.uint8, device=G.DEV)
+        L.check(lib.otvm_bank_pack_f16x3(keys[t].data_ptr(), vals[t].data_ptr(), hw, sl.data_ptr(), G.stream()))
+        slots.append(sl)
+    out.fill_(float("nan"))
+    sp = (C.c_void_p * T)(*[s_.data_ptr() for s_ in slots])
+    L.check(lib.otvm_memory_read_f16x3(q.data_ptr(), 128, sp, T, hw, out.data_ptr(), 512, ws.data_ptr(), G.stream()))
+    torch.cuda.synchronize()
+    assert G.maxdiff(out.cpu(), ref) <= tol
+    # the second half of the reference output is the query value passed through (STM.py:161)
+    assert torch.equal(want[512:], torch.from_numpy(ops["mem%d_qv" % T][0]))
+
+
+def test_reference_vectors_trimap_transform(G):
+    """trimap_transform (utils/utils.py:25-39) vectors tt_masks -> tt_out through otvm_trimap_encode: the hard
+    (bg, fg) masks become one-hot probabilities (unknown = neither), whose argmax is the same class map."""
+    ops = _ops()
+    for m, ref in zip(ops["tt_masks"], ops["tt_out"]):
+        m = torch.from_numpy(m)
+        probs = torch.stack([m[0], 1.0 - m[0] - m[1], m[1]])
+        got, cls, _ = _encode(G, probs)
+        assert G.maxdiff(got[:6], torch.from_numpy(ref)) <= 2e-6
+    assert float(np.abs(ops["tt_out"][0][3:]).max()) == 0.0            # empty class -> zero triple on both sides
+
+
+def test_reference_vectors_ws_conv_groupnorm(G):
+    """layers_WS.Conv2d + GroupNorm(32) vector (layers_WS.py:6-27): weight standardisation at pack time, dilated 3x3
+    on both precisions, fused statistics + apply."""
+    from otvm_amd import lib as L
+    lib = L.load()
+    ops = _ops()
+    x, w = torch.from_numpy(ops["ws_x"]), torch.from_numpy(ops["ws_w"])
+    ref = torch.from_numpy(ops["ws_out"])
+    _, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    for prec in (0, 1):
+        cw = G.pack_weight(w, ws=True)
+        xa = G.to_act(x)
+        raw = G.empty_act(H, W, Cout)
+        stats = torch.zeros(64, dtype=torch.float64, device=G.DEV)
+        G.conv2d(xa, cw, raw, bias=torch.from_numpy(ops["ws_b"]).to(G.DEV), pad=2, dil=2, precision=prec, gn_stats=stats)
+        gam, bet = torch.from_numpy(ops["ws_g"]).to(G.DEV), torch.from_numpy(ops["ws_be"]).to(G.DEV)
+        out = G.empty_act(H, W, Cout)
+        L.check(lib.otvm_gn_apply(raw.ptr, H * W, Cout, raw.ld, stats.data_ptr(), gam.data_ptr(), bet.data_ptr(), 0, 0, 0,
+                                  out.ptr, out.ld, G.stream()))
+        torch.cuda.synchronize()
+        assert G.maxdiff(G.from_act(out), ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+
+
+def test_reference_vectors_fba_fusion(G):
+    """fba_fusion (FBA/models.py:279-288) vector ff_* through otvm_fba_head: an identity 1x1 head hands the kernel
+    alpha and the logits of F, B, so what is compared is the fusion itself (incl. the F-then-B update order)."""
+    from otvm_amd import lib as L
+    lib = L.load()
+    ops = _ops()
+    a, img, Fg, Bg = (torch.from_numpy(ops[k]) for k in ("ff_a", "ff_img", "ff_F", "ff_B"))
+    want = torch.from_numpy(ops["ff_out"])
+    _, _, H, W = a.shape
+    P = H * W
+    logit = lambda p: torch.log(p.double() / (1 - p.double())).float()
+    hid = torch.zeros(1, 16, H, W)
+    hid[:, 0:1], hid[:, 1:4], hid[:, 4:7] = a, logit(Fg), logit(Bg)
+    wd = torch.eye(16)[:7].contiguous().to(G.DEV)
+    bd = torch.zeros(7, device=G.DEV)
+    ha, ia = G.to_act(hid, c_pad=16), G.to_act(img, c_pad=4)
+    alpha = torch.full((P,), float("nan"), device=G.DEV)
+    L.check(lib.otvm_fba_head(ha.ptr, ha.ld, wd.data_ptr(), bd.data_ptr(), 7, ia.ptr, ia.ld, P, alpha.data_ptr(), 1, 0, 0, 0,
+                              G.stream()))
+    torch.cuda.synchronize()
+    assert G.maxdiff(alpha.cpu(), want[0, 0].flatten()) <= 5e-6

@@ -109,12 +109,15 @@ def _worker(rank, world, port, q):
     seqs = [dict(frames=list(range(3 + i)), id=i) for i in range(5)]
 
     def matte(seq):                         # stand-in for the GPU path: the sharding/reduction logic is what is tested
-        return dict(alpha=torch.full((len(seq["frames"]), 4, 4), float(seq["id"])))
+        n = len(seq["frames"])
+        met = dict(frames=n, sad_sum=1.0 * n, mse_num=2.0 * n, mask_sum=10.0 * n, dt_err2_sum=0.5, dt_mask_sum=10.0 * (n - 1),
+                   mse_per_frame=[0.25 * (seq["id"] + 1)] * n, dtssd_per_pair=[0.125] * (n - 1), dtssd_num_per_pair=[2.0] * (n - 1))
+        return dict(alpha=torch.full((n, 4, 4), float(seq["id"])), metrics=met)
 
     def ref(seq):
         return torch.full((len(seq["frames"]), 4, 4), float(seq["id"]) + 0.5)
     out = run_sharded(seqs, matte, rank=rank, world=world, reference_fn=ref)
-    q.put((rank, out["frames"], out["sad"], out["max_abs"], out["sequences"]))
+    q.put((rank, out["frames"], out["sad"], out["max_abs"], out["sequences"], out["gt_metrics"]))
     dist.destroy_process_group()
 
 
@@ -130,10 +133,16 @@ def test_sharded_runner_two_ranks_gloo():
     for p in procs:
         p.join(60)
     total_frames = sum(3 + i for i in range(5))
-    for rank, frames, sad, max_abs, mine in res:
+    for rank, frames, sad, max_abs, mine, gm in res:
         assert frames == total_frames                               # SUM all-reduce
         assert abs(sad - 0.5 * 16 * total_frames / 1000.0) < 1e-9
         assert abs(max_abs - 0.5) < 1e-12                           # MAX all-reduce
+        # ground-truth metrics: pooled ratios AND the reference's per-frame / per-pair means (utils/tmp/metric.py:184-189,
+        # 252-264), reduced over both ranks
+        assert gm["frames"] == total_frames and abs(gm["sad"] - 1.0) < 1e-12 and abs(gm["mse"] - 0.2) < 1e-12
+        want_mse = sum(0.25 * (i + 1) * (3 + i) for i in range(5)) / total_frames
+        assert abs(gm["mse_mean"] - want_mse) < 1e-12
+        assert abs(gm["dtssd_mean"] - 0.125) < 1e-12 and abs(gm["dtssd_norm_mean"] - 0.0625) < 1e-12
     assert sorted(res[0][4] + res[1][4]) == [0, 1, 2, 3, 4]
 
 
@@ -182,6 +191,37 @@ def test_demo_enumeration_follows_reference_layout(tmp_path):
     assert np.array_equal(d["frames"][0], rgb[..., ::-1])
     assert tuple(d["trimap"].shape) == (3, 12, 16) and float(d["trimap"].sum()) == 12 * 16
     assert float(d["trimap"][2].sum()) == 2 * 4 and float(d["trimap"][1].sum()) == 6 * 8 - 2 * 4
+    assert d["frame_paths"] == [os.path.join(root, "seqA", "frames", n) for n in ("0001.png", "0002.png")]
+    assert "frames" not in load_sequence(items[0], decode_frames=False)
+    # a clip whose FIRST frame has no trimap cannot be evaluated (the reference would hand cv2.imread('') -> None to the
+    # model, dataset.py:879); a later frame's trimap is not silently promoted to frame 0
+    with pytest.raises(FileNotFoundError):
+        load_sequence(items[1])
+
+
+def test_trimap_files_decode_like_cv2(tmp_path):
+    """dataset.py:879-893 reads the trimap with cv2.IMREAD_UNCHANGED: grayscale {0, mid, max} levels (the shipped
+    demo/dove file is {0,128,254}), or a colour-coded file whose R channel (BGR index 2) marks unknown and G marks
+    foreground; palette PNGs are expanded to colour by OpenCV."""
+    from PIL import Image
+    from otvm_amd.datasets import read_trimap_unchanged
+    from otvm_amd.video import trimap_file_to_onehot
+    un = np.zeros((6, 8), bool); un[1:5, 1:7] = True
+    fg = np.zeros((6, 8), bool); fg[2:4, 3:5] = True
+    un &= ~fg
+    want = np.stack([~(un | fg), un, fg]).astype(np.float32)
+    p = str(tmp_path)
+    g = np.zeros((6, 8), np.uint8); g[un] = 128; g[fg] = 254                       # the dove levels
+    Image.fromarray(g).save(os.path.join(p, "gray.png"))
+    rgb = np.zeros((6, 8, 3), np.uint8); rgb[un, 0] = 255; rgb[fg, 1] = 255         # R = unknown, G = foreground
+    Image.fromarray(rgb).save(os.path.join(p, "rgb.png"))
+    Image.fromarray(rgb).convert("P", palette=Image.ADAPTIVE, colors=4).save(os.path.join(p, "pal.png"))
+    Image.fromarray(np.concatenate([rgb, np.full((6, 8, 1), 255, np.uint8)], -1)).save(os.path.join(p, "rgba.png"))
+    for name in ("gray.png", "rgb.png", "pal.png", "rgba.png"):
+        got = trimap_file_to_onehot(read_trimap_unchanged(os.path.join(p, name)))
+        assert np.array_equal(got, want), name
+    assert read_trimap_unchanged(os.path.join(p, "gray.png")).ndim == 2
+    assert read_trimap_unchanged(os.path.join(p, "rgb.png"))[..., 2].max() == 255      # BGR: R is channel 2
 
 
 def test_v108_enumeration_and_decoding(tmp_path):
@@ -248,3 +288,53 @@ def test_viz_grid_layout_and_rounding():
         tile = (panels[k] * 255 + 0.5).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).numpy()
         assert np.array_equal(g[y:y + ph, x:x + pw], tile)
     assert g[:2].max() == 0 and g[:, :2].max() == 0 and g[ph + 2:ph + 4].max() == 0          # padding stays black
+
+
+def test_bench_self_launch_plumbing():
+    """bench.py --gpus N started as a plain process launches its N ranks itself (one process per GPU), runs in-process
+    when N == 1 or when a launcher already set RANK, and refuses a node with fewer GPUs instead of reporting n_gpus it
+    did not use (`--gpus 8` silently ran one rank)."""
+    from otvm_amd.dist import self_launch_command
+    assert self_launch_command(1, {}, 1, "bench.py", ["--gpus", "1"]) is None
+    assert self_launch_command(8, {"RANK": "3", "WORLD_SIZE": "8"}, 8, "bench.py", []) is None
+    cmd = self_launch_command(4, {}, 8, "/x/bench.py", ["--gpus", "4", "--steps", "5"], python="py", port=29999)
+    assert cmd == ["py", "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                   "--master-port", "29999", "/x/bench.py", "--gpus", "4", "--steps", "5"]
+    auto = self_launch_command(2, {}, 2, "bench.py", [])
+    assert 1024 < int(auto[auto.index("--master-port") + 1]) < 65536
+    with pytest.raises(SystemExit):
+        self_launch_command(8, {}, 1, "bench.py", [])
+    with pytest.raises(SystemExit):
+        self_launch_command(0, {}, 1, "bench.py", [])
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """End to end on this (GPU-less) container: `python bench.py --gpus 2` exits non-zero with a message, it does not
+    fall back to one rank."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a node with fewer than 2 GPUs")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "GPU" in (r.stdout + r.stderr)
+
+
+def test_viz_panels_match_reference_write_image():
+    """SURVEY.md 8f-3 pixel parity: the tensor (and nrow) the reference's write_image (eval.py:96-115) hands to
+    torchvision's save_image, captured by tests/golden/make_viz_golden.py from the imported reference, against
+    viz.viz_panels on the same inputs; the uint8 grid is then the documented make_grid / save_image arithmetic."""
+    from otvm_amd.viz import make_grid_u8, viz_panels
+    g = np.load(os.path.join(ROOT, "tests", "golden", "viz.npz"))
+    for i in (0, 1):
+        out5 = tuple(torch.from_numpy(g["in%d_%s" % (i, k)]) for k in ("imgs", "tri_pred", "tri_gt", "alpha", "gt"))
+        panels = viz_panels(out5)
+        ref = torch.from_numpy(g["out%d_imgs" % i])
+        assert int(g["out%d_nrow" % i]) == 2
+        assert panels.shape == ref.shape and float((panels - ref).abs().max()) <= 1e-6
+        grid = make_grid_u8(panels, nrow=int(g["out%d_nrow" % i]))
+        grid_ref = make_grid_u8(ref, nrow=2)
+        assert int(np.abs(grid.astype(np.int32) - grid_ref.astype(np.int32)).max()) <= 1     # 1e-6 around a rounding edge
+        assert (grid != grid_ref).mean() < 1e-3
