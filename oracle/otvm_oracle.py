@@ -81,7 +81,7 @@ def make_trimap8(tri3, cls=None):
     scaled = cls.float() * 0.5
     t2 = torch.stack([(scaled == 0).float(), (scaled == 1).float()])
     enc6 = trimap_transform(t2)
-    return torch.cat([enc6, tri3[0:1], tri3[2:3]], dim=0).float()
+    return torch.cat([enc6.to(tri3.dtype), tri3[0:1], tri3[2:3]], dim=0)
 
 
 def fba_fusion(alpha, img, Fg, Bg):
@@ -141,10 +141,15 @@ def bank_update(bank, new, first_frame, memorize, max_memory_num):
 
 # --------------------------------------------------------------------------- the model
 class OtvmOracle:
-    def __init__(self, state_dict, dilate_kernel=None, threads=None):
+    def __init__(self, state_dict, dilate_kernel=None, threads=None, dtype=torch.float32):
+        """dtype=torch.float64 evaluates the SAME operations in double precision (the distance encoding keeps the
+        reference's float32 arithmetic, it is part of the definition): the tests use it to measure how far the
+        reference's own fp32 forward is from the exact value of its algorithm on a given frame -- the summation-order
+        noise any two fp32 implementations differ by."""
         if threads:
             torch.set_num_threads(threads)
-        self.p = {k: v.detach().float() if v.is_floating_point() else v.detach() for k, v in state_dict.items()}
+        self.dtype = dtype
+        self.p = {k: v.detach().to(dtype) if v.is_floating_point() else v.detach() for k, v in state_dict.items()}
         self.dilate_kernel = dilate_kernel
         self.ws = {}
         for k, v in self.p.items():
@@ -322,11 +327,11 @@ class OtvmOracle:
 
     # ---- first-frame trimap from GT alpha (alpha/model.py:342-362), V108-style flow
     def trimap_from_alpha(self, a):
-        trimask = ((a > 0) & (a < 1.0)).float()
+        trimask = ((a > 0) & (a < 1.0)).to(a.dtype)
         r = self.dilate_kernel
         tm = F.max_pool2d(trimask, kernel_size=r * 2 + 1, stride=1, padding=r)
         t1 = torch.where(tm > 0.5, torch.ones_like(a), 2 * a).long()
-        return F.one_hot(t1[:, 0], num_classes=3).permute(0, 3, 1, 2).float()
+        return F.one_hot(t1[:, 0], num_classes=3).permute(0, 3, 1, 2).to(a.dtype)
 
     # ---- one frame (alpha/model.py:391-512)
     def reset(self):
@@ -335,12 +340,13 @@ class OtvmOracle:
     def frame(self, a, fg, bg, tri_gt=None, first_frame=False, last_frame=False, memorize=False,
               max_memory_num=2, frame_id=0, class_override=None, capture=None):
         """a [1,1,1,H,W] in [0,1]; fg,bg [1,1,3,H,W] BGR 0..255; tri_gt [1,1,3,H,W] one-hot or None."""
-        a4, fg4, bg4 = a[0].float().contiguous(), fg[0].float().contiguous(), bg[0].float().contiguous()
+        dt = self.dtype
+        a4, fg4, bg4 = a[0].to(dt).contiguous(), fg[0].to(dt).contiguous(), bg[0].to(dt).contiguous()
         s = 1.0 / 255
         img = (fg4.flip([1]) * s) * a4 + (bg4.flip([1]) * s) * (1.0 - a4)        # :384-386
         if tri_gt is not None:
-            tri = tri_gt[0].float()
-            tri_gt_out = F.one_hot(tri.max(dim=1)[1], 3).permute(0, 3, 1, 2).float()   # :356-362
+            tri = tri_gt[0].to(dt)
+            tri_gt_out = F.one_hot(tri.max(dim=1)[1], 3).permute(0, 3, 1, 2).to(dt)   # :356-362
         else:
             tri = self.trimap_from_alpha(a4)
             tri_gt_out = tri

@@ -35,11 +35,18 @@ def _model(synth_sd, precision="f16x3", dk=12):
     return m.cuda().eval()
 
 
-def _frame_vs_oracle(m, orc, a, fg, tg, t, kw, label):
+def _frame_vs_oracle(m, orc, a, fg, tg, t, kw, label, orc64=None):
     """One frame on the HIP path and on the oracle, with the tie-break protocol of tests/test_gpu_frame.py: when the
     HIP class map (the 3-class argmax feeding the distance transform, alpha/model.py:42) differs from the oracle's,
     every differing pixel must be a near-tie in the oracle (top-2 probability gap < 2e-3) and the oracle frame is re-run
-    with the HIP tie-breaks -- so the 1e-3 alpha bound is ALWAYS asserted.  Returns (hip out, oracle out, alpha diff, ties)."""
+    with the HIP tie-breaks -- so the 1e-3 alpha bound is ALWAYS asserted.  Returns (hip out, oracle out, alpha diff, ties).
+
+    orc64 (optional): the same oracle evaluated in float64 with the same bank.  Then the frame is also compared with
+    the EXACT value of the reference algorithm (bound 1e-3), and the bound against the fp32 oracle is widened by the
+    fp32 oracle's own measured distance from that exact value on this frame -- two fp32 evaluations of the same
+    algorithm differ by their summation orders, and with five memory slots the softmax over 40 800 memory positions
+    amplifies a 1e-5 difference in the query key to ~1e-3 in the readout (tools/steady_diag.py: the exact-fp32 MFMA
+    path and the f16x3 path are both ~1.0e-3 from the oneDNN oracle and 1.7e-4 from each other)."""
     out = m(a, fg, fg.clone(), tri_gt=tg, _frame_id=t, **kw)
     torch.cuda.synchronize()
     pl = m._engine.last_plan
@@ -60,7 +67,14 @@ def _frame_vs_oracle(m, orc, a, fg, tg, t, kw, label):
     d = float((out[3].cpu() - ref[3]).abs().max())
     dt = float((out[1].cpu() - ref[1]).abs().max())
     print("%s frame %d: alpha max-abs %.3e, trimap max-abs %.3e, tie-breaks %d of %d" % (label, t, d, dt, ties, cls_h.numel()))
-    assert d <= 1e-3, "%s frame %d: alpha max-abs %.3e" % (label, t, d)
+    slack = 0.0
+    if orc64 is not None:
+        ref64 = orc64.frame(a, fg, fg.clone(), tri_gt=tg, frame_id=t, class_override=cls_h if ties else None, **kw)
+        d64 = float((out[3].cpu().double() - ref64[3]).abs().max())
+        slack = float((ref[3].double() - ref64[3]).abs().max())
+        print("%s frame %d: vs the float64 evaluation %.3e; the fp32 oracle's own distance from it %.3e" % (label, t, d64, slack))
+        assert d64 <= 1e-3, "%s frame %d: alpha max-abs vs the exact (float64) evaluation %.3e" % (label, t, d64)
+    assert d <= 1e-3 + slack, "%s frame %d: alpha max-abs %.3e (allowed 1e-3 + %.3e)" % (label, t, d, slack)
     assert dt <= 5e-3, "%s frame %d: trimap max-abs %.3e" % (label, t, dt)
     if "tri_in" in cap and not kw["first_frame"]:
         dp = float((pl.PROBS.reshape(1, 3, pl.Hp, pl.Wp).cpu() - cap["tri_in"]).abs().max())
@@ -94,8 +108,9 @@ def test_1080p_steady_state_frame_vs_oracle(synth_sd):
     """BASELINE configs[2] in its steady state (memory every 5, max 5 slots): the HIP path free-runs frames 0..20 -- all
     five slots filled, one eviction done (bank read by frame 21 = [0, 9, 14, 19, 20]) -- then frame 21 is
     compared with the oracle, whose bank is seeded from the device slots (a CPU frame is ~30 s at this size, so the
-    oracle cannot free-run 21 of them).  Checks alpha <= 1e-3, the propagated trimap, T_read = 5 and the bank after the
-    frame's own update."""
+    oracle cannot free-run 21 of them).  Checks alpha (<= 1e-3 against the float64 evaluation of the reference algorithm,
+    <= 1e-3 + the fp32 oracle's own rounding distance against the fp32 oracle), the propagated trimap, T_read = 5 and the
+    bank after the frame's own update."""
     from oracle.otvm_oracle import OtvmOracle
     from otvm_amd.synth_data import synthetic_clip
     H, W, T, t_s = 1080, 1920, 24, 21
@@ -114,8 +129,11 @@ def test_1080p_steady_state_frame_vs_oracle(synth_sd):
     orc = OtvmOracle(synth_sd, dilate_kernel=12)
     orc.bank = [(s["k"].t.reshape(hw, 128).t().reshape(128, h16, w16).cpu().contiguous(),
                  s["v"].t.reshape(hw, 512).t().reshape(512, h16, w16).cpu().contiguous(), s["frame"]) for s in eng.bank]
+    import torch as _t
+    orc64 = OtvmOracle(synth_sd, dilate_kernel=12, dtype=_t.float64)
+    orc64.bank = [(k.double(), v.double(), f) for k, v, f in orc.bank]
     a, fg, tg = _clip_tensors(frames, tri, t_s, H, W)
-    out, ref, d, ties = _frame_vs_oracle(m, orc, a, fg, tg, t_s, flags(t_s), "1080p steady state (T_read=5)")
+    out, ref, d, ties = _frame_vs_oracle(m, orc, a, fg, tg, t_s, flags(t_s), "1080p steady state (T_read=5)", orc64=orc64)
     assert m.memories["frames"] == [b[2] for b in orc.bank] == [0, 9, 14, 19, 21]
 
 
@@ -255,7 +273,7 @@ def test_memory_read_slot_order_invariance_1080p(G):
     for perm in ([0, 1, 2, 3, 4], [4, 2, 0, 3, 1]):
         out = torch.empty(hw, 512, device=G.DEV)
         sp = (C.c_void_p * T)(*[slots[i].data_ptr() for i in perm])
-        L.check(lib.otvm_memory_read_f16x3(q.data_ptr(), 128, sp, T, hw, out.data_ptr(), 512, ws.data_ptr(), G.stream()))
+        L.check(lib.otvm_memory_read_f16x3(q.data_ptr(), 128, sp, T, hw, out.data_ptr(), 512, 0, ws.data_ptr(), G.stream()))
         torch.cuda.synchronize()
         outs.append(out)
     assert torch.isfinite(outs[0]).all()
