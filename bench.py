@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3"],
                     help="conv arithmetic: f16x3 = split-fp16 MFMA with fp32-class accuracy (default), f32 = exact-fp32 MFMA")
     ap.add_argument("--layer-report", default=None, help="write the per-layer conv timing table (JSON) to this path")
+    ap.add_argument("--tune-report", default=None, help="write the plan-time autotuner's choices (JSON) to this path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -264,6 +265,11 @@ def main():
             "alpha_maxabs_hip_vs_cpu_same_frame": float((hip[3].cpu() - ref[3]).abs().max()),
         }
 
+    if rank == 0 and args.tune_report:
+        from otvm_amd.engine import TUNE_LOG
+        json.dump([dict(layer=n, shape=dict(H=sg[0], W=sg[1], Cin=sg[2], Cout=sg[4], k=sg[6], stride=sg[8], dil=sg[10]),
+                        chosen=best, ms={str(k): round(v, 4) for k, v in ms.items()}) for n, sg, best, ms in TUNE_LOG],
+                  open(args.tune_report, "w"), indent=0)
     if rank == 0:
         print(json.dumps(result))
     if dist is not None:

@@ -47,9 +47,10 @@ extern "C" {
 #define OTVM_FMT_HL8 1
 
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 6    /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
+#define OTVM_ABI_VERSION 7    /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
                                  4: otvm_conv_params.splitk_ws; 5: otvm_preprocess_params.fg_u8/bg_u8/u8_rgb;
-                                 6: OTVM_FMT_HL8 -- *_fmt fields / arguments on every activation view */
+                                 6: OTVM_FMT_HL8 -- *_fmt fields / arguments on every activation view;
+                                 7: otvm_conv_params.tune + otvm_conv2d_candidates */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -102,6 +103,8 @@ typedef struct {
                                                        padding outside; tables of Cin floats from otvm_gn_table, or NULL.
                                                        Only layers for which otvm_conv2d_accepts_input_norm() returns 1 */
     int in_act;                                     /* OTVM_ACT_* applied after the input normalisation */
+    int tune;                                       /* 0 = built-in heuristic; else a configuration code returned by
+                                                       otvm_conv2d_candidates (which kernel / tile / K split runs the layer) */
     int in_fmt, res_fmt, out_fmt;                   /* OTVM_FMT_* of in / residual / out.  HL8 input: f16x3 only, Cin % 32 == 0
                                                        (the 7x7 stems read fp32), not together with in_scale           */
     void* splitk_ws; int64_t splitk_ws_bytes;       /* optional workspace (f16x3): layers with too few output tiles to fill
@@ -110,6 +113,12 @@ typedef struct {
                                                        One workspace per stream that runs convs concurrently.          */
 } otvm_conv_params;
 int otvm_conv2d(const otvm_conv_params* p, void* stream);
+/* The legal kernel configurations of a layer (f16x3): the patch kernel where the shape allows it, and the implicit-GEMM
+ * tiles 256x256 ... 64x64, each alone or with the K range of every output tile shared by S = 2..8 workgroups
+ * (deterministic fixed-order reduction through splitk_ws).  Writes up to max_n opaque codes to `out`, returns their
+ * number; a code goes into otvm_conv_params.tune.  All configurations compute the same convolution (results differ
+ * by fp32 summation order only); the host times them on the device once per layer shape and keeps the fastest.    */
+int otvm_conv2d_candidates(const otvm_conv_params* p, int* out, int max_n);
 /* 1 when otvm_conv2d would run the layer on a kernel that implements in_scale / in_shift (f16x3 3x3 stride-1 patch
  * kernel), else 0: the caller then applies otvm_gn_apply as a separate pass.                                       */
 int otvm_conv2d_accepts_input_norm(const otvm_conv_params* p);

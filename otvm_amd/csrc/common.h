@@ -55,6 +55,17 @@ __device__ __forceinline__ void otvm_split4(const otvm_f32x4 v, otvm_f16x4& hi, 
                     (_Float16)(v.w - (float)h23.y)};
 }
 
+// relu of a 16-byte piece of an HL8 tensor (8 fp16 halves, all hi or all lo): hi is rounded toward zero, so lo carries
+// the sign of x (or is zero) and relu(x) = (max(hi,0), max(lo,0)).  On the bit patterns that is a signed 16-bit integer
+// max with 0 (negative floats, incl. -0, have the sign bit set): one v_pk_max_i16 per two halves, no canonicalisation.
+__device__ __forceinline__ otvm_f32x4 otvm_relu_hl8(const otvm_f32x4 v) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    s16x8 s = __builtin_bit_cast(s16x8, v);
+    s = __builtin_elementwise_max(s, z);
+    return __builtin_bit_cast(otvm_f32x4, s);
+}
+
 // byte offset of element e's hi half inside an HL8 view (the lo half is 16 bytes further)
 __device__ __forceinline__ int64_t otvm_hl8_off(int64_t e) { return ((e >> 3) << 5) + ((e & 7) << 1); }
 
@@ -96,6 +107,25 @@ __device__ __forceinline__ void otvm_st1(float* base, int fmt, int64_t e, float 
     char* p = reinterpret_cast<char*>(base) + otvm_hl8_off(e);
     *reinterpret_cast<_Float16*>(p) = h.x;
     *reinterpret_cast<_Float16*>(p + 16) = (_Float16)(v - (float)h.x);
+}
+
+// GEN = false: the view is known to be fp32 (the common case keeps its plain 16-byte accesses, no format branch in the
+// unrolled epilogues); GEN = true: dispatch on fmt at run time
+template <bool GEN> __device__ __forceinline__ otvm_f32x4 otvm_ldq(const float* b, int fmt, int64_t e) {
+    if constexpr (GEN) return otvm_ld4(b, fmt, e);
+    else return *reinterpret_cast<const otvm_f32x4*>(b + e);
+}
+template <bool GEN> __device__ __forceinline__ void otvm_stq(float* b, int fmt, int64_t e, const otvm_f32x4 v) {
+    if constexpr (GEN) otvm_st4(b, fmt, e, v);
+    else *reinterpret_cast<otvm_f32x4*>(b + e) = v;
+}
+template <bool GEN> __device__ __forceinline__ float otvm_lds(const float* b, int fmt, int64_t e) {
+    if constexpr (GEN) return otvm_ld1(b, fmt, e);
+    else return b[e];
+}
+template <bool GEN> __device__ __forceinline__ void otvm_sts(float* b, int fmt, int64_t e, float v) {
+    if constexpr (GEN) otvm_st1(b, fmt, e, v);
+    else b[e] = v;
 }
 
 // host-side view check shared by the entry points

@@ -17,6 +17,7 @@
 #include "common.h"
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
+#include <type_traits>
 
 #ifndef OTVM_BRANCHY_LOADS
 #define OTVM_BRANCHY_LOADS 1
@@ -184,16 +185,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
             f32x4 v = ra[i];
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             v = (okmask >> i) & 1u ? v : z;
-            if (RELU_IN) {
-                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                const h2 z2 = {(_Float16)0, (_Float16)0};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    h2 t = __builtin_bit_cast(h2, v[j]);
-                    t = __builtin_elementwise_max(t, z2);
-                    v[j] = __builtin_bit_cast(float, t);
-                }
-            }
+            if (RELU_IN) v = otvm_relu_hl8(v);
             const int piece = tid & 7;
             _Float16* dst = (piece & 1) ? Al : Ah;
             *reinterpret_cast<f32x4*>(&dst[(arow + A_ROWS * i) * LDH + 8 * (piece >> 1)]) = v;
@@ -294,7 +286,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     // leaves as 16-byte row-major accesses: 4 store instructions per tile instead of 16, and bias / residual are
     // read as float4.  (With scalar accesses the residual read alone ran at 0.7 TB/s on the K=64 layers.)
     __syncthreads();                                   // all waves are done with the A/B stages
-    {
+    auto epilogue = [&](auto generic) __attribute__((always_inline)) {
+        constexpr bool GEN = decltype(generic)::value;         // false: every view is fp32 -> the plain 16-byte accesses
         float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
         const int prow = lane >> 3, pc = (lane & 7) * 4;
         // (HL8 views are 32-byte aligned with ld % 8 == 0 by contract: always vectorisable)
@@ -324,7 +317,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int m = mb + r4 * 8 + prow;
                     rres[r4] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (res_vec && m < p.M) rres[r4] = otvm_ld4(p.residual, p.res_fmt, (int64_t)m * p.res_ld + n4);
+                    if (res_vec && m < p.M) rres[r4] = otvm_ldq<GEN>(p.residual, p.res_fmt, (int64_t)m * p.res_ld + n4);
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
@@ -339,14 +332,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
                             v += rres[r4];
                             v.x = otvm_act(v.x, p.act); v.y = otvm_act(v.y, p.act);
                             v.z = otvm_act(v.z, p.act); v.w = otvm_act(v.w, p.act);
-                            otvm_st4(outp, p.out_fmt, (int64_t)m * p.out_ld + n4, v);
+                            otvm_stq<GEN>(outp, p.out_fmt, (int64_t)m * p.out_ld + n4, v);
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 if (n4 + j < p.Cout) {
                                     float x = v[j];
-                                    if (p.residual) x += otvm_ld1(p.residual, p.res_fmt, (int64_t)m * p.res_ld + n4 + j);
-                                    otvm_st1(outp, p.out_fmt, (int64_t)m * p.out_ld + n4 + j, otvm_act(x, p.act));
+                                    if (p.residual) x += otvm_lds<GEN>(p.residual, p.res_fmt, (int64_t)m * p.res_ld + n4 + j);
+                                    otvm_sts<GEN>(outp, p.out_fmt, (int64_t)m * p.out_ld + n4 + j, otvm_act(x, p.act));
                                 }
                             }
                         }
@@ -354,7 +347,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
                 }
             }
         }
-    }
+    };
+    if (p.out_fmt | p.res_fmt) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
     // ---- fused GroupNorm statistics of the tile just written (sum / sum of squares per group, fp64 atomics)
     if (p.gn_stats) {
         // (sum, sumsq) per group of the tile, at most BN/2 groups; lives behind the waves' epilogue patches in the
@@ -506,9 +501,104 @@ extern "C" int otvm_split_conv_weight_f16x3(const float* w_packed, int O, int O_
 
 int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream);    // conv_patch_f16x3.hip, -1 = not eligible
 
+// ---- dispatch.  A configuration is (tile, S): one of the implicit-GEMM tiles below with the K chunks of every output
+// tile shared by S workgroups (S > 1: partial tiles through the caller's workspace, added in a fixed order by
+// splitk_finish_kernel), or the 3x3 patch kernel.  otvm_conv_params.tune forces one (the host's plan-time autotuner,
+// otvm_amd/engine.py, times the candidates of otvm_conv2d_candidates on the device); 0 = the heuristic below.
+enum { T256x256 = 0, T256x128, T128x128, T128x64, T64x64, T256x64, T256x32, T_COUNT, T_PATCH = 14 };
+static inline int tune_code(int tile, int S) { return (tile + 1) * 16 + S; }
+static const int TILE_BM[T_COUNT] = {256, 256, 128, 128, 64, 256, 256};
+static const int TILE_BN[T_COUNT] = {256, 128, 128, 64, 64, 64, 32};
+
+static int launch_tile(int tile, Conv3Args& a, hipStream_t s, int S) {
+    switch (tile) {
+        case T256x256: return launch3<256, 256, 4, 2>(a, s, S);
+        case T256x128: return launch3<256, 128, 4, 2>(a, s, S);
+        case T128x128: return launch3<128, 128, 2, 2>(a, s, S);
+        case T128x64: return launch3<128, 64, 2, 2>(a, s, S);
+        case T64x64: return launch3<64, 64, 2, 2>(a, s, S);
+        case T256x64: return launch3<256, 64, 4, 1>(a, s, S);
+        case T256x32: return launch3<256, 32, 4, 1>(a, s, S);
+    }
+    otvm_set_error("otvm_conv2d(f16x3): unknown tile %d", tile);
+    return 1;
+}
+
+// is (tile, S) a legal configuration of this layer?
+static bool config_ok(const otvm_conv_params* p, int tile, int S) {
+    if (tile < 0 || tile >= T_COUNT || S < 1 || S > 8) return false;
+    const int64_t M = (int64_t)p->Ho * p->Wo;
+    // the weight arrays hold O_pad = Cout rounded up to 128 rows (include/otvm_hip.h): a 256-wide N tile may only be
+    // used when that is a multiple of 256, or its last tile would read rows past the allocation
+    if (TILE_BN[tile] == 256 && !(p->Cout >= 256 && (otvm_ceil_div(p->Cout, 128) & 1) == 0)) return false;
+    if (p->in_scale) return false;                                  // fused input normalisation: patch kernel only
+    if (S > 1) {
+        const int nchunks = p->K_pad / 32;
+        const int ldp = (p->Cout + 3) & ~3;
+        if (!p->splitk_ws || nchunks / S < 4) return false;
+        if ((int64_t)S * M * ldp * (int64_t)sizeof(float) > p->splitk_ws_bytes || M * (ldp / 4) >= (1ll << 32)) return false;
+    }
+    return true;
+}
+
+static int run_config(const otvm_conv_params* p, Conv3Args& a, int tile, int S, hipStream_t s) {
+    if (S <= 1) return launch_tile(tile, a, s, 1);
+    const int64_t M = a.M;
+    const int ldp = (p->Cout + 3) & ~3;
+    Conv3Args b = a;
+    b.out = (float*)p->splitk_ws; b.out_ld = ldp; b.split_stride = M * ldp;
+    b.bias = nullptr; b.residual = nullptr; b.act = OTVM_ACT_NONE; b.gn_stats = nullptr;
+    b.out_fmt = OTVM_FMT_F32;                              // partial tiles are plain fp32
+    const int rc = launch_tile(tile, b, s, S);
+    if (rc) return rc;
+    int64_t blocks = (M * (ldp / 4) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)blocks), dim3(256), 0, s, (const float*)p->splitk_ws, S,
+                       (int64_t)M * ldp, M, p->Cout, ldp, p->bias, p->residual, p->res_ld, p->res_fmt, p->act, p->out,
+                       p->out_ld, p->out_fmt);
+    OTVM_CHECK_LAUNCH("otvm_conv2d(split-K finish)");
+    if (p->gn_stats) return otvm_gn_stats(p->out, M, p->Cout, p->out_ld, p->gn_stats, (void*)s);
+    return 0;
+}
+
+int otvm_conv2d_patch_eligible(const otvm_conv_params* p);                  // conv_patch_f16x3.hip: shape-wise eligibility
+int otvm_conv2d_patch_f16x3_forced(const otvm_conv_params* p, void* stream);
+
+extern "C" int otvm_conv2d_candidates(const otvm_conv_params* p, int* out, int max_n) {
+    int n = 0;
+    if (!p || !out || p->precision != OTVM_PREC_F16X3) return 0;
+    auto add = [&](int code) { if (n < max_n) out[n++] = code; };
+    if (otvm_conv2d_patch_eligible(p)) add(tune_code(T_PATCH, 1));
+    if (p->in_scale) return n;
+    const int64_t M = (int64_t)p->Ho * p->Wo;
+    const int nchunks = p->K_pad / 32;
+    static const int tiles_wide[] = {T256x256, T256x128, T128x128, T128x64, T64x64};
+    static const int tiles_64[] = {T256x64, T128x64, T64x64};
+    static const int tiles_32[] = {T256x32, T64x64};
+    const int* tl = p->Cout <= 32 ? tiles_32 : (p->Cout <= 64 ? tiles_64 : tiles_wide);
+    const int ntl = p->Cout <= 32 ? 2 : (p->Cout <= 64 ? 3 : 5);
+    static const int splits[] = {1, 2, 3, 4, 6, 8};
+    for (int i = 0; i < ntl; ++i) {
+        const int t = tl[i];
+        const int64_t wgs = (int64_t)otvm_ceil_div(M, TILE_BM[t]) * otvm_ceil_div(p->Cout, TILE_BN[t]);
+        if (wgs > 16384 && TILE_BM[t] < 256) continue;              // huge maps: only the 256-row tiles are worth timing
+        for (int j = 0; j < 6; ++j) {
+            const int S = splits[j];
+            if (S > 1 && (wgs * S > 1536 || nchunks < 16)) continue;      // splitting K only helps launches that cannot fill the chip
+            if (config_ok(p, t, S)) add(tune_code(t, S));
+        }
+    }
+    return n;
+}
+
 int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     OTVM_REQUIRE(p->w_hi && p->w_lo && p->w_scale, "otvm_conv2d: precision f16x3 needs w_hi / w_lo / w_scale");
-    {
+    const int forced_tile = p->tune ? p->tune / 16 - 1 : -1, forced_S = p->tune & 15;
+    if (p->tune && forced_tile == T_PATCH) {
+        OTVM_REQUIRE(otvm_conv2d_patch_eligible(p), "otvm_conv2d: tune asks for the patch kernel on a layer it cannot take");
+        return otvm_conv2d_patch_f16x3_forced(p, stream);
+    }
+    if (!p->tune) {
         const int rc = otvm_conv2d_patch_f16x3_impl(p, stream);
         if (rc != -1) return rc;
     }
@@ -524,14 +614,18 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     a.split_stride = 0;
     hipStream_t s = (hipStream_t)stream;
     const int64_t M = a.M;
-    // ---- split-K for layers that cannot fill the chip with output tiles alone (OS16/OS32 maps, the whole 480p frame):
-    // 128-row tiles, the K chunks of a tile shared by up to 8 workgroups, partials through the caller's workspace
+    if (p->tune) {
+        OTVM_REQUIRE(config_ok(p, forced_tile, forced_S), "otvm_conv2d: tune code %d is not a legal configuration of this layer",
+                     p->tune);
+        return run_config(p, a, forced_tile, forced_S, s);
+    }
+    // ---- heuristic.  Split-K for layers that cannot fill the chip with output tiles alone (OS16/OS32 maps, the whole
+    // 480p frame): 128-row tiles, the K chunks of a tile shared by up to 8 workgroups
     static const int splitk = getenv("OTVM_SPLITK") ? atoi(getenv("OTVM_SPLITK")) : 1;
     static const int min_total = getenv("OTVM_SPLITK_MINTOTAL") ? atoi(getenv("OTVM_SPLITK_MINTOTAL")) : 32;
     if (splitk && p->splitk_ws && a.nchunks >= min_total) {
         const bool wide = p->Cout > 64;
         const int64_t tiles = (int64_t)otvm_ceil_div(M, 128) * otvm_ceil_div(p->Cout, wide ? 128 : 64);
-        const int ldp = (p->Cout + 3) & ~3;
         // at least 8 chunks per workgroup (16 -> 8 and 64 -> 32 total: 480p 124.9 -> 126.3 fps, 1080p unchanged); the reduction pass (and, with fused GroupNorm sums, a statistics pass over
         // the output) costs two small launches, so moderately deep layers keep the single-pass kernel (measured per
         // layer at 480p / 1080p: 1024->128 3x3 at OS16 0.186 -> 0.058 ms, 1024->256 1x1 + GN 0.035 -> 0.074 ms)
@@ -540,32 +634,15 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
         static const int min_chunks = getenv("OTVM_SPLITK_MINCHUNKS") ? atoi(getenv("OTVM_SPLITK_MINCHUNKS")) : 8;
         if (S > a.nchunks / min_chunks) S = a.nchunks / min_chunks;
         if (p->gn_stats && a.nchunks < 256 && tiles > 8) S = 1;
-        while (S >= 2 && (int64_t)S * M * ldp * (int64_t)sizeof(float) > p->splitk_ws_bytes) --S;
-        if (tiles < 192 && S >= 2 && M * (ldp / 4) < (1ll << 32)) {
-            Conv3Args b = a;
-            b.out = (float*)p->splitk_ws; b.out_ld = ldp; b.split_stride = M * ldp;
-            b.bias = nullptr; b.residual = nullptr; b.act = OTVM_ACT_NONE; b.gn_stats = nullptr;
-            b.out_fmt = OTVM_FMT_F32;                              // partial tiles are plain fp32
-            const int rc = wide ? launch3<128, 128, 2, 2>(b, s, S) : launch3<128, 64, 2, 2>(b, s, S);
-            if (rc) return rc;
-            int64_t blocks = (M * (ldp / 4) + 255) / 256;
-            if (blocks > 2048) blocks = 2048;
-            hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)blocks), dim3(256), 0, s, (const float*)p->splitk_ws, S,
-                               (int64_t)M * ldp, M, p->Cout, ldp, p->bias, p->residual, p->res_ld, p->res_fmt, p->act, p->out,
-                               p->out_ld, p->out_fmt);
-            OTVM_CHECK_LAUNCH("otvm_conv2d(split-K finish)");
-            if (p->gn_stats) return otvm_gn_stats(p->out, M, p->Cout, p->out_ld, p->gn_stats, stream);
-            return 0;
-        }
+        while (S >= 2 && !config_ok(p, wide ? T128x128 : T128x64, S)) --S;
+        if (tiles < 192 && S >= 2) return run_config(p, a, wide ? T128x128 : T128x64, S, s);
     }
     if (p->Cout <= 32) return launch3<256, 32, 4, 1>(a, s);
     if (p->Cout <= 64) return (M >= 256 * 128) ? launch3<256, 64, 4, 1>(a, s) : launch3<64, 64, 2, 2>(a, s);
     // Tile choice by workgroup count (thresholds tuned on the whole 1080p frame after the 256-row tiles got their
     // second LDS stage: 256x256 from 256 workgroups (was 480), 256x128 from 128 (was 480): 36.8 -> 37.8 frames/s;
     // OTVM_T_* override them for sweeps).
-    // the weight arrays hold O_pad = Cout rounded up to 128 rows (include/otvm_hip.h): a 256-wide N tile may only be
-    // used when that is a multiple of 256, or its last tile would read rows past the allocation
-    if (p->Cout >= 256 && (otvm_ceil_div(p->Cout, 128) & 1) == 0) {
+    if (config_ok(p, T256x256, 1)) {
         const int64_t huge = (int64_t)otvm_ceil_div(M, 256) * otvm_ceil_div(p->Cout, 256);
         static const int t_huge = getenv("OTVM_T_HUGE") ? atoi(getenv("OTVM_T_HUGE")) : 256;
         if (huge >= t_huge) return launch3<256, 256, 4, 2>(a, s);

@@ -15,6 +15,7 @@
 // as conv_f16x3.hip (filter scale, bias, residual, activation, optional fused GroupNorm statistics).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -134,15 +135,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
                     // this thread's 16-byte piece (same address as the fp32 quad it would have loaded) goes to the hi or
                     // the lo patch as it is (zeros outside the image); relu(x) = (max(hi,0), max(lo,0)) for this format
                     f32x4 v = rp[k];
-                    if (p.in_relu) {
-                        const f16x2 z2 = {(_Float16)0, (_Float16)0};
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            f16x2 t = __builtin_bit_cast(f16x2, v[j]);
-                            t = __builtin_elementwise_max(t, z2);
-                            v[j] = __builtin_bit_cast(float, t);
-                        }
-                    }
+                    if (p.in_relu) v = otvm_relu_hl8(v);
                     const int pix = idx >> 2, piece = idx & 3;
                     _Float16* dst = (piece & 1) ? Pl : Ph;
                     *reinterpret_cast<f32x4*>(&dst[pix * LDP + 8 * (piece >> 1)]) = v;
@@ -227,7 +220,8 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
     // ---- epilogue: accumulator tile -> wave-private LDS patch -> 16-byte row-major stores (see conv_f16x3.hip)
     const int col = lane & 31, rbase = (lane >> 5) * 4;
     __syncthreads();
-    {
+    auto epilogue = [&](auto generic) __attribute__((always_inline)) {
+        constexpr bool GEN = decltype(generic)::value;         // false: every view is fp32 -> the plain 16-byte accesses
         float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
         const int prow = lane >> 3, pc = (lane & 7) * 4;
         const bool vec_ok = ((p.out_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
@@ -254,7 +248,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
                     const int x = tx0 + r4 * 8 + prow;
                     rres[r4] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (res_vec && y < p.H && x < p.W)
-                        rres[r4] = otvm_ld4(p.residual, p.res_fmt, ((int64_t)y * p.W + x) * p.res_ld + n4);
+                        rres[r4] = otvm_ldq<GEN>(p.residual, p.res_fmt, ((int64_t)y * p.W + x) * p.res_ld + n4);
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
@@ -270,14 +264,14 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
                             v += rres[r4];
                             v.x = otvm_act(v.x, p.act); v.y = otvm_act(v.y, p.act);
                             v.z = otvm_act(v.z, p.act); v.w = otvm_act(v.w, p.act);
-                            otvm_st4(p.out, p.out_fmt, m * p.out_ld + n4, v);
+                            otvm_stq<GEN>(p.out, p.out_fmt, m * p.out_ld + n4, v);
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 if (n4 + j < p.Cout) {
                                     float xv = v[j];
-                                    if (p.residual) xv += otvm_ld1(p.residual, p.res_fmt, m * p.res_ld + n4 + j);
-                                    otvm_st1(p.out, p.out_fmt, m * p.out_ld + n4 + j, otvm_act(xv, p.act));
+                                    if (p.residual) xv += otvm_lds<GEN>(p.residual, p.res_fmt, m * p.res_ld + n4 + j);
+                                    otvm_sts<GEN>(p.out, p.out_fmt, m * p.out_ld + n4 + j, otvm_act(xv, p.act));
                                 }
                             }
                         }
@@ -285,7 +279,9 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
                 }
             }
         }
-    }
+    };
+    if (p.out_fmt | p.res_fmt) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 
     // ---- fused GroupNorm statistics (sum / sum of squares per group, fp64 atomics)
     if (p.gn_stats) {
@@ -399,13 +395,15 @@ extern "C" int otvm_pack_patch_weight_f16x3(const float* w_packed, int O, int K_
     return 0;
 }
 
-// 0: not eligible (the implicit-GEMM kernel takes the layer), 1: narrow tiles, 2: wide (256-channel) tiles
-static int patch_choice(const otvm_conv_params* p) {
+// 0: not eligible (the implicit-GEMM kernel takes the layer), 1: narrow tiles, 2: wide (256-channel) tiles.
+// forced: shape-wise eligibility only (the plan-time autotuner decides whether the wide tiles pay on this map)
+static int patch_choice(const otvm_conv_params* p, bool forced = false) {
     if (!p->w_frag || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->Cin % 16 != 0) return 0;
     if (p->dil != 1 && p->dil != 2 && p->dil != 4) return 0;
     static const int wide = getenv("OTVM_PATCH_WIDE") ? atoi(getenv("OTVM_PATCH_WIDE")) : 1;
     if (p->Cout <= 64) return 1;
     if (!wide || p->Cout % 256 != 0) return 0;                     // wide path: 256-channel tiles, 8 waves, 3-tap weight stages
+    if (forced) return 2;
     // needs enough 8x32 x 256-channel tiles to fill 256 CUs (OS4 maps at 1080p): 327 vs 285 TFLOP/s (256->256) and
     // 390 vs 348 (512->256) against the implicit-GEMM kernel.  On smaller maps the implicit-GEMM tiles win
     // (a 4x32-tile variant of this kernel measured 160-230 TFLOP/s vs 290-315 and was dropped).
@@ -419,9 +417,16 @@ extern "C" int otvm_conv2d_accepts_input_norm(const otvm_conv_params* p) {
     return p && p->precision == OTVM_PREC_F16X3 && patch_choice(p) != 0 ? 1 : 0;
 }
 
+int otvm_conv2d_patch_eligible(const otvm_conv_params* p) { return patch_choice(p, true) != 0 ? 1 : 0; }
+
+static int patch_run(const otvm_conv_params* p, void* stream, int choice);
+
+int otvm_conv2d_patch_f16x3_forced(const otvm_conv_params* p, void* stream) { return patch_run(p, stream, patch_choice(p, true)); }
+
 // returns -1 when the layer is not eligible (caller falls back to the implicit-GEMM kernel)
-int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream) {
-    const int choice = patch_choice(p);
+int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream) { return patch_run(p, stream, patch_choice(p)); }
+
+static int patch_run(const otvm_conv_params* p, void* stream, int choice) {
     if (choice == 0) return -1;
     const bool is_wide = choice == 2;
     PatchArgs a;

@@ -29,10 +29,21 @@ FUSE_GN_APPLY = os.environ.get("OTVM_FUSE_GN_APPLY", "1") != "0"
 # (1080p 37.6 vs 37.6 fps, 480p 124.9 vs 123.9, IO pipeline 37.0 vs 36.9), the graphs only cut the host time per frame
 # (6.8 -> 0.9 ms at 480p) -- worth switching on when many processes share few host cores.
 USE_GRAPHS = os.environ.get("OTVM_GRAPHS", "0") != "0"
-# Activations that feed f16x3 convolutions are stored PRE-SPLIT (lib.FMT_HL8: fp16 hi + lo per 8 channels, same bytes
-# as fp32): the producing kernel splits once, the consuming convolutions stage their operand tiles with 16-byte copies
-# instead of re-splitting every element once per tap and per N tile.  OTVM_HL8=0 keeps every buffer fp32 (A/B timing).
-USE_HL8 = os.environ.get("OTVM_HL8", "1") != "0"
+# OTVM_HL8=1: activations that feed f16x3 convolutions are stored PRE-SPLIT (lib.FMT_HL8: fp16 hi + lo per 8 channels,
+# same bytes as fp32): the producing kernel splits once, the consuming convolutions stage their operand tiles with
+# 16-byte copies instead of re-splitting every element once per tap and per N tile.  Built, parity-tested, measured in
+# round 2 and left OFF: on the same box the conversion it removes is worth -3..4 % on the 3x3 implicit-GEMM layers and
+# nothing on the 1x1 layers, and the 8-byte hi / lo accesses of pre-split outputs and residuals give that back
+# (1080p: 36.7 frames/s fp32 views, 36.5 pre-split).
+USE_HL8 = os.environ.get("OTVM_HL8", "0") != "0"
+# Plan-time autotuning of the convolution configurations (f16x3): every distinct layer shape is timed once on the device
+# over the legal (kernel, tile, K-split) configurations otvm_conv2d_candidates lists, the fastest is kept in
+# otvm_conv_params.tune.  All configurations compute the same convolution (fp32 summation order differs).  The choice is
+# cached per process and per layer signature, so two plans / engines of one process run identical configurations.
+# OTVM_AUTOTUNE=0 keeps the built-in heuristic (thresholds tuned by hand on the 1080p frame).
+AUTOTUNE = os.environ.get("OTVM_AUTOTUNE", "1") != "0"
+_TUNE_CACHE = {}
+TUNE_LOG = []           # (signature, chosen code, {code: ms}) of every shape timed in this process (tools / DESIGN numbers)
 
 
 def _rup(x, m):
@@ -162,7 +173,7 @@ def conv_params(x, cw, out, bias=None, stride=1, pad=0, dil=1, act=NONE, in_relu
                         0 if cw.w_frag is None else cw.w_frag.data_ptr(), 0,
                         0 if in_norm is None else in_norm[0], 0 if in_norm is None else in_norm[1],
                         0 if in_norm is None else in_norm[2],
-                        x.fmt, 0 if residual is None else residual.fmt, out.fmt,
+                        0, x.fmt, 0 if residual is None else residual.fmt, out.fmt,
                         0 if splitk_ws is None else splitk_ws.data_ptr(),
                         0 if splitk_ws is None else splitk_ws.numel() * splitk_ws.element_size())
 
@@ -193,6 +204,10 @@ class HipEngine:
         self.side = None
         import os
         self.use_side_stream = os.environ.get("OTVM_SIDE_STREAM", "1") != "0"
+        # f16x3 splits fp32 operands into fp16 halves: an activation beyond fp16's range (|x| >= 65504) becomes inf and
+        # then NaN, silently, and would live on in the recurrent memory bank.  OTVM_CHECK_FINITE=1 checks every frame's
+        # alpha (one device sync per frame) and raises; meant for the first run of a new checkpoint.
+        self.check_finite = os.environ.get("OTVM_CHECK_FINITE", "0") != "0"
         self.use_graphs = USE_GRAPHS
         self._pack_all()
 
@@ -401,6 +416,9 @@ class HipEngine:
                                       alpha.data_ptr(), alpha_u8.data_ptr(), tri_out.data_ptr(), stream), "crop")
         self.last_alpha_u8 = alpha_u8
         self.last_plan = pl
+        if self.check_finite and not bool(torch.isfinite(alpha).all()):
+            raise FloatingPointError("otvm_amd: non-finite alpha at frame %d -- an activation probably left fp16's range on the "
+                                     "f16x3 path; rerun with model.precision = 'f32' (exact-fp32 MFMA)" % frame_id)
         return scaled_imgs, tri_out, tri_gt_out, alpha, a
 
     def _memorize(self, pend, stream, tstream=None):
@@ -451,11 +469,84 @@ class FramePlan:
         self._keep = []
         self.graphs, self._graph_warm = {}, {}
         self._fused_stats = []
+        self._convs = []
         self.n_gn = 0
         self.steps = {}
         self._build()
         self.stats = torch.zeros(max(self.n_gn, 1) * 64, dtype=torch.float64, device=self.dev)
         self._bind_stats()
+        self.autotune()
+
+    # ---- plan-time autotuning (see AUTOTUNE above)
+    @staticmethod
+    def _signature(p):
+        return (p.H, p.W, p.Cin, p.in_ld, p.Cout, p.out_ld, p.kh, p.kw, p.stride, p.pad, p.dil, p.in_relu, p.act, bool(p.bias),
+                bool(p.residual), p.res_ld, bool(p.gn_stats), bool(p.in_scale), p.in_fmt, p.res_fmt, p.out_fmt,
+                bool(p.splitk_ws), p.precision)
+
+    def _time_conv(self, p, code, stream, reps=3):
+        p.tune = code
+        fn = self.lib.otvm_conv2d
+        L.check(fn(C.byref(p), stream), "autotune warm-up")
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn(C.byref(p), stream)
+        e1.record()
+        return e0, e1, reps
+
+    def tune_convs(self, convs):
+        """Pick otvm_conv_params.tune for every (params, name) in ``convs`` (cached per layer signature)."""
+        if not (AUTOTUNE and self.e.precision == L.PREC_F16X3):
+            return
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        codes = (C.c_int * 64)()
+        for p, name in convs:
+            sig = self._signature(p)
+            if sig not in _TUNE_CACHE:
+                n = int(self.lib.otvm_conv2d_candidates(C.byref(p), codes, 64))
+                cands = [0] + [int(codes[i]) for i in range(n)]           # 0 = the built-in heuristic, the incumbent
+                timed = [(c,) + self._time_conv(p, c, stream) for c in cands]
+                torch.cuda.synchronize(self.dev)
+                ms = {c: e0.elapsed_time(e1) / r for c, e0, e1, r in timed}
+                best = min(ms, key=ms.get)
+                if ms[best] > 0.97 * ms[0]:                                # keep the incumbent unless clearly beaten
+                    best = 0
+                _TUNE_CACHE[sig] = best
+                TUNE_LOG.append((name, sig, best, ms))
+            p.tune = _TUNE_CACHE[sig]
+
+    def autotune(self):
+        if not (AUTOTUNE and self.e.precision == L.PREC_F16X3):
+            return
+        # realistic operand values while timing (zero-filled operands run the matrix cores at an unrepresentative power)
+        filled = []
+        for b in self._bufs.values():
+            t = b.t if isinstance(b, Act) else b
+            if not t.is_floating_point():
+                continue
+            if isinstance(b, Act) and b.fmt:
+                t.view(torch.float16).normal_()
+            elif t.dtype == torch.float32:
+                t.normal_()
+            else:
+                continue
+            filled.append(t)
+        # the key / value convolutions of STM.memorize are bound to a bank slot at run time (kv_into_slot): time their
+        # shapes here against scratch outputs, so the first memorised frame finds them in the cache
+        H16, W16 = self.Hp // 16, self.Wp // 16
+        tk = Act(torch.empty(self.hw * 128, dtype=torch.float32, device=self.dev), H16, W16, 128)
+        tv = Act(torch.empty(self.hw * 512, dtype=torch.float32, device=self.dev), H16, W16, 512)
+        n0, k0 = len(self._convs), len(self._keep)
+        self.conv([], self.r4m, "trimap.model.KV_M_r4.Key", tk, pad=1)
+        self.conv([], self.r4m, "trimap.model.KV_M_r4.Value", tv, pad=1)
+        self.tune_convs(self._convs)
+        torch.cuda.synchronize(self.dev)
+        del self._convs[n0:], self._keep[k0:]                  # scratch-bound parameter blocks: not kept
+        for t in filled:
+            t.zero_()
+        self.stats.zero_()
+        torch.cuda.synchronize(self.dev)
 
     # ---- buffers
     def buf(self, name, H, W, C, fmt=0):
@@ -479,6 +570,7 @@ class FramePlan:
         assert (out.H, out.W) == (Ho, Wo) and out.C >= w.O, (wname, out.H, out.W, Ho, Wo, out.C, w.O)
         p = conv_params(x, w, out, w.bias, stride, pad, dil, act, in_relu, residual, self.e.precision, in_norm, self._ws)
         self._keep.append(p)
+        self._convs.append((p, wname))
         flops = 2 * Ho * Wo * w.O * w.kh * w.kw * w.I           # algorithmic (un-padded) 2*MAC
         # algorithmic bytes: read the input once, the weights once, write the output once (+ residual read), fp32
         abytes = 4 * (x.H * x.W * w.I + w.O * w.I * w.kh * w.kw + Ho * Wo * w.O * (2 if residual is not None else 1))
@@ -846,8 +938,10 @@ class FramePlan:
     def kv_into_slot(self, slot, stream):
         if "kv_steps" not in slot:
             S = []
+            n0 = len(self._convs)
             self.conv(S, self.r4m, "trimap.model.KV_M_r4.Key", slot["k"], pad=1)
             self.conv(S, self.r4m, "trimap.model.KV_M_r4.Value", slot["v"], pad=1)
+            self.tune_convs(self._convs[n0:])                  # (first slot of a plan: timed once; later ones hit the cache)
             slot["kv_steps"] = S
         prof = self.e.prof
         for st in slot["kv_steps"]:

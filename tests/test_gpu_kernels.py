@@ -279,7 +279,7 @@ def test_conv_fused_input_groupnorm(G, Cin, Cout, dil, H, W, act):
     # bit-identical to the two-pass route (same table arithmetic, same staging)
     xa2 = G.to_act(x)
     L.check(lib.otvm_gn_apply(xa2.ptr, H * W, Cin, xa2.ld, stats.data_ptr(), g_d.data_ptr(), b_d.data_ptr(), 0, 0, 0, act,
-                              xa2.ptr, xa2.ld, G.stream()))
+                              xa2.ptr, xa2.ld, 0, G.stream()))
     out2 = G.empty_act(H, W, max(4, Cout))
     G.conv2d(xa2, cw, out2, bias_d, pad=dil, dil=dil, precision=1)
     assert torch.equal(G.from_act(out2, Cout), got)
