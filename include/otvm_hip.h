@@ -9,9 +9,8 @@
  *
  * Conventions
  *   - all pointers are DEVICE pointers unless noted; `stream` is a hipStream_t passed as void*;
- *   - activations are NHWC with an explicit pixel stride `ld` (elements), so a tensor may be
+ *   - activations are NHWC fp32 with an explicit pixel stride `ld` (elements), so a tensor may be
  *     a channel slice of a wider buffer (this is how every torch.cat of the reference disappears);
- *     storage is fp32 (OTVM_FMT_F32) or, where a `*_fmt` argument says so, the pre-split form OTVM_FMT_HL8;
  *   - channel counts of device tensors are padded to a multiple of 4 (zero weights on the pad);
  *   - every function returns 0 on success, non-zero on error; otvm_last_error() describes it.
  */
@@ -35,22 +34,10 @@ extern "C" {
 #define OTVM_PREC_F32 0
 #define OTVM_PREC_F16X3 1
 
-/* Activation storage formats.  Both take 4 bytes per element and use the same element indexing (pixel * ld + channel):
- *   F32 : fp32.
- *   HL8 : fp32 values stored already split for the f16x3 kernels: every 8 consecutive elements (32 bytes) are 8 fp16
- *         "hi" halves then 8 fp16 "lo" halves, x ~= hi + lo, hi = fp16(x) rounded toward zero, lo = fp16(x - hi)
- *         (22 significant bits -- exactly what an f16x3 convolution would make of an fp32 input anyway).  The producing
- *         kernel splits ONCE; every consuming convolution stages its operand tiles with plain 16-byte copies instead of
- *         re-splitting each element once per tap and per N tile.  Requires ld % 8 == 0, a 32-byte aligned view origin
- *         and |x| < 65504 (same range assumption as the f16x3 convolution inputs).                                    */
-#define OTVM_FMT_F32 0
-#define OTVM_FMT_HL8 1
-
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 7    /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
+#define OTVM_ABI_VERSION 6    /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
                                  4: otvm_conv_params.splitk_ws; 5: otvm_preprocess_params.fg_u8/bg_u8/u8_rgb;
-                                 6: OTVM_FMT_HL8 -- *_fmt fields / arguments on every activation view;
-                                 7: otvm_conv_params.tune + otvm_conv2d_candidates */
+                                 6: otvm_conv_params.tune + otvm_conv2d_candidates */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -105,8 +92,6 @@ typedef struct {
     int in_act;                                     /* OTVM_ACT_* applied after the input normalisation */
     int tune;                                       /* 0 = built-in heuristic; else a configuration code returned by
                                                        otvm_conv2d_candidates (which kernel / tile / K split runs the layer) */
-    int in_fmt, res_fmt, out_fmt;                   /* OTVM_FMT_* of in / residual / out.  HL8 input: f16x3 only, Cin % 32 == 0
-                                                       (the 7x7 stems read fp32), not together with in_scale           */
     void* splitk_ws; int64_t splitk_ws_bytes;       /* optional workspace (f16x3): layers with too few output tiles to fill
                                                        the chip split K over up to 8 workgroups per tile and reduce the
                                                        partial tiles in a fixed order (deterministic); NULL = never split.
@@ -139,26 +124,23 @@ int otvm_gn_stats(const float* x, int64_t P, int C, int ld, double* stats, void*
  * otvm_conv_params.in_scale / in_shift: identical arithmetic to otvm_gn_apply's                                   */
 int otvm_gn_table(const double* stats, int64_t P, int C, const float* gamma, const float* beta, float* scale,
                   float* shift, void* stream);
-/* x is the raw fp32 conv output; residual / out are views in res_fmt / out_fmt (OTVM_FMT_*).  In place (out == x) is
- * allowed for either output format.                                                                                */
 int otvm_gn_apply(const float* x, int64_t P, int C, int ld, const double* stats, const float* gamma,
-                  const float* beta, const float* residual, int res_ld, int res_fmt, int act,
-                  float* out, int out_ld, int out_fmt, void* stream);
+                  const float* beta, const float* residual, int res_ld, int act,
+                  float* out, int out_ld, void* stream);
 
 /* ---------------------------------------------------------------- pooling / resampling ---------*/
 /* F.max_pool2d(3, 2, 1) (resnet_GN_WS.py:98, torchvision resnet maxpool in STM.py:47,83) */
-int otvm_maxpool3x3s2(const float* in, int H, int W, int C, int ld, int in_fmt, float* out, int out_ld, int out_fmt,
-                      void* stream);
+int otvm_maxpool3x3s2(const float* in, int H, int W, int C, int ld, float* out, int out_ld, void* stream);
 /* F.interpolate(mode='bilinear', align_corners=False) to (Ho,Wo); out = up(in) [+ add]
  * (FBA/models.py:358-376, STM.py:115) */
-int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, int in_ld, int in_fmt, const float* add, int add_ld,
-                           int add_fmt, float* out, int Ho, int Wo, int out_ld, int out_fmt, void* stream);
+int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, int in_ld, const float* add, int add_ld,
+                           float* out, int Ho, int Wo, int out_ld, void* stream);
 /* nn.AdaptiveAvgPool2d(s) for s in {1,2,3,6} in one launch (FBA/models.py:300-306);
  * out = 50 bins x C, bins ordered scale-major then row-major.
  * ws >= otvm_ppm_pool_ws_bytes(H, C): per-row sums of the 12 column bins (one pass over the map, then a
  * fixed-order reduction over the rows of every bin).                                                */
 int64_t otvm_ppm_pool_ws_bytes(int H, int C);
-int otvm_ppm_pool(const float* in, int H, int W, int C, int ld, int in_fmt, float* out, void* ws, void* stream);
+int otvm_ppm_pool(const float* in, int H, int W, int C, int ld, float* out, void* ws, void* stream);
 
 /* ---------------------------------------------------------------- memory read (STM.py:140-163) -
  * mem[q, :] = sum_m softmax_m(K[m,:].Q[q,:] / sqrt(128)) V[m,:], m over T slots x hw positions.
@@ -179,7 +161,7 @@ int otvm_memory_read(const float* q_key, int q_ld, const float* const* keys, con
 int64_t otvm_bank_slot_bytes_f16x3(int hw);
 int otvm_bank_pack_f16x3(const float* key, const float* val, int hw, void* slot, void* stream);
 int otvm_memory_read_f16x3(const float* q_key, int q_ld, const void* const* slots, int T, int hw, float* out,
-                           int out_ld, int out_fmt, void* ws, void* stream);
+                           int out_ld, void* ws, void* stream);
 
 /* ---------------------------------------------------------------- frame glue --------------------
  * preprocess: alpha/model.py:380-389,408-414 + STM.py:53-57,89-93.  fg,bg: [3,H,W] fp32 BGR 0..255

@@ -17,7 +17,6 @@
 #include "common.h"
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
-#include <type_traits>
 
 #ifndef OTVM_BRANCHY_LOADS
 #define OTVM_BRANCHY_LOADS 1
@@ -36,7 +35,6 @@ struct Conv3Args {
     const float* residual; float* out; double* gn_stats;
     int H, W, Cin, in_ld, K_pad, res_ld, Ho, Wo, Cout, out_ld;
     int kh, kw, stride, pad, dil, in_relu, act;
-    int in_fmt, res_fmt, out_fmt;     // OTVM_FMT_*; HL8 input only on the FAST path (template HL8)
     int M, taps, nchunks, tiles_m, tiles_n;
     // split-K (layers too small to fill the chip): gridDim.y workgroups share an output tile, each walks a contiguous
     // range of the K chunks and writes its un-biased partial tile to out + blockIdx.y * split_stride (the host points
@@ -49,15 +47,21 @@ constexpr int LDH = 40;          // halfs per LDS row (32 + 8 pad) = 80 bytes
 
 inline bool f16x3_fast_layout(int taps, int I_pad) { return I_pad % 32 == 0 && taps <= 32; }
 
-__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) { otvm_split4(v, hi, lo); }
+__device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
+    // hi: round-toward-zero pack (any rounding works, lo is computed exactly against it)
+    typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+    const fp16x2 p01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y);
+    const fp16x2 p23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+    const f16x2 h01 = __builtin_bit_cast(f16x2, p01);
+    const f16x2 h23 = __builtin_bit_cast(f16x2, p23);
+    hi = f16x4{h01.x, h01.y, h23.x, h23.y};
+    lo = f16x4{(_Float16)(v.x - (float)h01.x), (_Float16)(v.y - (float)h01.y), (_Float16)(v.z - (float)h23.x),
+               (_Float16)(v.w - (float)h23.y)};
+}
 
 // FAST: Cin % 32 == 0 and <= 32 taps -> a K chunk never straddles a tap, so the tap walk is wave-uniform
 // (scalar registers) and the per-row work per chunk shrinks to one add and one mask test.
-// HL8 (FAST only): the input is stored pre-split (common.h): the 128 bytes of a pixel's 32-channel chunk are the 16-byte
-// pieces h0 l0 h1 l1 h2 l2 h3 l3 (8 channels each), so the thread that would load channels 4j..4j+3 as a float4 loads
-// piece j from the SAME address and copies it to the hi or lo operand tile in LDS: no conversion, one 16-byte LDS
-// write instead of two 8-byte ones (measured on the staging alone: 3x3 layers -9..12 %, deep 1x1 layers -7..8 %).
-template <int BM, int BN, int WM, int WN, bool FAST, bool RELU_IN, bool HL8>
+template <int BM, int BN, int WM, int WN, bool FAST, bool RELU_IN>
 __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Conv3Args p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -179,18 +183,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
         _Float16* Al = Ah + BM * LDH;
         _Float16* Bh = Al + BM * LDH;
         _Float16* Bl = Bh + BN * LDH;
-        if (HL8) {
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i) {
-            f32x4 v = ra[i];
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            v = (okmask >> i) & 1u ? v : z;
-            if (RELU_IN) v = otvm_relu_hl8(v);
-            const int piece = tid & 7;
-            _Float16* dst = (piece & 1) ? Al : Ah;
-            *reinterpret_cast<f32x4*>(&dst[(arow + A_ROWS * i) * LDH + 8 * (piece >> 1)]) = v;
-        }
-        } else {
 #pragma unroll
         for (int i = 0; i < A_LD; ++i) {
             f16x4 hi, lo;
@@ -203,7 +195,6 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
             split4(v, hi, lo);
             *reinterpret_cast<f16x4*>(&Ah[(arow + A_ROWS * i) * LDH + ak]) = hi;
             *reinterpret_cast<f16x4*>(&Al[(arow + A_ROWS * i) * LDH + ak]) = lo;
-        }
         }
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
@@ -286,11 +277,9 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     // leaves as 16-byte row-major accesses: 4 store instructions per tile instead of 16, and bias / residual are
     // read as float4.  (With scalar accesses the residual read alone ran at 0.7 TB/s on the K=64 layers.)
     __syncthreads();                                   // all waves are done with the A/B stages
-    auto epilogue = [&](auto generic) __attribute__((always_inline)) {
-        constexpr bool GEN = decltype(generic)::value;         // false: every view is fp32 -> the plain 16-byte accesses
+    {
         float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
         const int prow = lane >> 3, pc = (lane & 7) * 4;
-        // (HL8 views are 32-byte aligned with ld % 8 == 0 by contract: always vectorisable)
         const bool vec_ok = ((p.out_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(outp) & 15) == 0) &&
                             (!p.residual || (((p.res_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0)));
 #pragma unroll
@@ -317,7 +306,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int m = mb + r4 * 8 + prow;
                     rres[r4] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (res_vec && m < p.M) rres[r4] = otvm_ldq<GEN>(p.residual, p.res_fmt, (int64_t)m * p.res_ld + n4);
+                    if (res_vec && m < p.M) rres[r4] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)m * p.res_ld + n4);
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
@@ -332,14 +321,14 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
                             v += rres[r4];
                             v.x = otvm_act(v.x, p.act); v.y = otvm_act(v.y, p.act);
                             v.z = otvm_act(v.z, p.act); v.w = otvm_act(v.w, p.act);
-                            otvm_stq<GEN>(outp, p.out_fmt, (int64_t)m * p.out_ld + n4, v);
+                            *reinterpret_cast<f32x4*>(outp + (int64_t)m * p.out_ld + n4) = v;
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 if (n4 + j < p.Cout) {
                                     float x = v[j];
-                                    if (p.residual) x += otvm_lds<GEN>(p.residual, p.res_fmt, (int64_t)m * p.res_ld + n4 + j);
-                                    otvm_sts<GEN>(outp, p.out_fmt, (int64_t)m * p.out_ld + n4 + j, otvm_act(x, p.act));
+                                    if (p.residual) x += p.residual[(int64_t)m * p.res_ld + n4 + j];
+                                    outp[(int64_t)m * p.out_ld + n4 + j] = otvm_act(x, p.act);
                                 }
                             }
                         }
@@ -347,9 +336,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
                 }
             }
         }
-    };
-    if (p.out_fmt | p.res_fmt) epilogue(std::true_type{});
-    else epilogue(std::false_type{});
+    }
     // ---- fused GroupNorm statistics of the tile just written (sum / sum of squares per group, fp64 atomics)
     if (p.gn_stats) {
         // (sum, sumsq) per group of the tile, at most BN/2 groups; lives behind the waves' epilogue patches in the
@@ -404,8 +391,8 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
 // split-K epilogue: out = act(sum_z part[z] + bias + residual), partials added in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int S, int64_t stride, int64_t M,
                                                             int Cout, int ldp, const float* __restrict__ bias,
-                                                            const float* __restrict__ residual, int res_ld, int res_fmt, int act,
-                                                            float* __restrict__ out, int out_ld, int out_fmt) {
+                                                            const float* __restrict__ residual, int res_ld, int act,
+                                                            float* __restrict__ out, int out_ld) {
     const unsigned Q = (unsigned)ldp >> 2;
     const unsigned total = (unsigned)M * Q;                     // split layers are small: M * ldp / 4 < 2^32 (host check)
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -417,8 +404,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
         for (int j = 0; j < 4; ++j) {
             if (c + j < Cout) {
                 float x = v[j] + (bias ? bias[c + j] : 0.f);
-                if (residual) x += otvm_ld1(residual, res_fmt, m * res_ld + c + j);
-                otvm_st1(out, out_fmt, m * out_ld + c + j, otvm_act(x, act));
+                if (residual) x += residual[m * res_ld + c + j];
+                out[m * out_ld + c + j] = otvm_act(x, act);
             }
         }
     }
@@ -436,19 +423,12 @@ int launch3(Conv3Args& a, hipStream_t s, int ksplit = 1) {
         otvm_set_error("otvm_conv2d(f16x3): input view too large for 32-bit offsets");
         return 1;
     }
-    if (a.in_fmt == OTVM_FMT_HL8 && !fast) {
-        otvm_set_error("otvm_conv2d(f16x3): pre-split (HL8) input needs Cin %% 32 == 0 (Cin = %d)", a.Cin);
-        return 1;
-    }
-    if (fast && a.in_fmt == OTVM_FMT_HL8) {
-        if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, false, true>), grid, block, 0, s, a);
-    } else if (fast) {
-        if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, true, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, false, false>), grid, block, 0, s, a);
+    if (fast) {
+        if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, a);
     } else {
-        if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, true, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, false, false>), grid, block, 0, s, a);
+        if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, a);
     }
     OTVM_CHECK_LAUNCH("otvm_conv2d(f16x3)");
     return 0;
@@ -548,14 +528,13 @@ static int run_config(const otvm_conv_params* p, Conv3Args& a, int tile, int S, 
     Conv3Args b = a;
     b.out = (float*)p->splitk_ws; b.out_ld = ldp; b.split_stride = M * ldp;
     b.bias = nullptr; b.residual = nullptr; b.act = OTVM_ACT_NONE; b.gn_stats = nullptr;
-    b.out_fmt = OTVM_FMT_F32;                              // partial tiles are plain fp32
     const int rc = launch_tile(tile, b, s, S);
     if (rc) return rc;
     int64_t blocks = (M * (ldp / 4) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)blocks), dim3(256), 0, s, (const float*)p->splitk_ws, S,
-                       (int64_t)M * ldp, M, p->Cout, ldp, p->bias, p->residual, p->res_ld, p->res_fmt, p->act, p->out,
-                       p->out_ld, p->out_fmt);
+                       (int64_t)M * ldp, M, p->Cout, ldp, p->bias, p->residual, p->res_ld, p->act, p->out,
+                       p->out_ld);
     OTVM_CHECK_LAUNCH("otvm_conv2d(split-K finish)");
     if (p->gn_stats) return otvm_gn_stats(p->out, M, p->Cout, p->out_ld, p->gn_stats, (void*)s);
     return 0;
@@ -609,7 +588,6 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     a.Ho = p->Ho; a.Wo = p->Wo; a.Cout = p->Cout; a.out_ld = p->out_ld;
     a.kh = p->kh; a.kw = p->kw; a.stride = p->stride; a.pad = p->pad; a.dil = p->dil;
     a.in_relu = p->in_relu; a.act = p->act;
-    a.in_fmt = p->in_fmt; a.res_fmt = p->res_fmt; a.out_fmt = p->out_fmt;
     a.M = p->Ho * p->Wo; a.taps = p->kh * p->kw; a.nchunks = p->K_pad / 32;
     a.split_stride = 0;
     hipStream_t s = (hipStream_t)stream;

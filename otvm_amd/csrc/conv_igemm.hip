@@ -315,17 +315,6 @@ extern "C" int otvm_conv2d(const otvm_conv_params* p, void* stream) {
     OTVM_REQUIRE(!p->in_scale == !p->in_shift, "otvm_conv2d: in_scale and in_shift go together");
     OTVM_REQUIRE(!p->in_scale || otvm_conv2d_accepts_input_norm(p),
                  "otvm_conv2d: fused input normalisation requested for a layer otvm_conv2d_accepts_input_norm() rejects");
-    // activation storage formats (OTVM_FMT_*): the pre-split form exists for the f16x3 kernels
-    OTVM_REQUIRE((unsigned)p->in_fmt <= 1u && (unsigned)p->res_fmt <= 1u && (unsigned)p->out_fmt <= 1u, "otvm_conv2d: unknown format");
-    OTVM_REQUIRE(p->precision == OTVM_PREC_F16X3 || (p->in_fmt | p->res_fmt | p->out_fmt) == OTVM_FMT_F32,
-                 "otvm_conv2d: HL8 views need precision f16x3");
-    OTVM_REQUIRE(otvm_view_ok(p->in, p->in_ld, p->in_fmt) && otvm_view_ok(p->out, p->out_ld, p->out_fmt) &&
-                 (!p->residual || otvm_view_ok(p->residual, p->res_ld, p->res_fmt)),
-                 "otvm_conv2d: an HL8 view needs ld %% 8 == 0 and a 32-byte aligned origin");
-    OTVM_REQUIRE(p->out_fmt == OTVM_FMT_F32 || (p->Cout % 8 == 0 && !p->gn_stats),
-                 "otvm_conv2d: HL8 output needs Cout %% 8 == 0 and no fused GroupNorm statistics (the raw tensor stays fp32)");
-    OTVM_REQUIRE(p->in_fmt == OTVM_FMT_F32 || (p->Cin % 32 == 0 && !p->in_scale),
-                 "otvm_conv2d: HL8 input needs Cin %% 32 == 0 (got %d) and no fused input normalisation", p->Cin);
     if (p->precision == OTVM_PREC_F16X3) return otvm_conv2d_f16x3_impl(p, stream);
     ConvArgs a;
     a.in = p->in; a.w = p->w; a.bias = p->bias; a.residual = p->residual; a.out = p->out; a.gn_stats = p->gn_stats;

@@ -15,7 +15,6 @@
 // as conv_f16x3.hip (filter scale, bias, residual, activation, optional fused GroupNorm statistics).
 #include "common.h"
 #include <stdlib.h>
-#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -29,7 +28,6 @@ struct PatchArgs {
     const float* in; const _Float16* wf; const float* wscale; const float* bias; const float* residual; float* out;
     double* gn_stats;
     int H, W, Cin, in_ld, res_ld, Cout, out_ld, n_pad32, in_relu, act;
-    int in_fmt, res_fmt, out_fmt;     // OTVM_FMT_* (common.h); an HL8 input is copied into the patch, never converted
     int tiles_x, tiles_y, tiles_n;
     // fused input normalisation (GroupNorm apply of the producer folded into the staging): x' = in_act(x * in_scale[c]
     // + in_shift[c]) for pixels inside the image, 0 for the conv's zero padding; nullptr = plain input
@@ -39,7 +37,16 @@ struct PatchArgs {
 constexpr int CB = 16;           // channels per stage = one MFMA k-step
 constexpr int LDP = 24;          // halfs per patch pixel (16 channels + 8 pad) = 48 bytes: 3r mod 16 distinct -> conflict-free b128
 
-__device__ __forceinline__ void split4p(const f32x4 v, f16x4& hi, f16x4& lo) { otvm_split4(v, hi, lo); }
+__device__ __forceinline__ void split4p(const f32x4 v, f16x4& hi, f16x4& lo) {
+    typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+    const fp16x2 p01 = __builtin_amdgcn_cvt_pkrtz(v.x, v.y);
+    const fp16x2 p23 = __builtin_amdgcn_cvt_pkrtz(v.z, v.w);
+    const f16x2 h01 = __builtin_bit_cast(f16x2, p01);
+    const f16x2 h23 = __builtin_bit_cast(f16x2, p23);
+    hi = f16x4{h01.x, h01.y, h23.x, h23.y};
+    lo = f16x4{(_Float16)(v.x - (float)h01.x), (_Float16)(v.y - (float)h01.y), (_Float16)(v.z - (float)h23.x),
+               (_Float16)(v.w - (float)h23.y)};
+}
 
 // Per stage (16 input channels) a workgroup holds in LDS the split input patch and, per group of TAPG taps, the B
 // fragments of its BN output channels, copied verbatim from the fragment-major weight array (1-KiB blocks).
@@ -130,16 +137,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int idx = tid + k * NT;
-                if (idx < NPIX * 4 && p.in_fmt == OTVM_FMT_HL8) {
-                    // pre-split input: the 64 bytes of a pixel's 16 channels are the pieces h0 l0 h1 l1 (8 channels each);
-                    // this thread's 16-byte piece (same address as the fp32 quad it would have loaded) goes to the hi or
-                    // the lo patch as it is (zeros outside the image); relu(x) = (max(hi,0), max(lo,0)) for this format
-                    f32x4 v = rp[k];
-                    if (p.in_relu) v = otvm_relu_hl8(v);
-                    const int pix = idx >> 2, piece = idx & 3;
-                    _Float16* dst = (piece & 1) ? Pl : Ph;
-                    *reinterpret_cast<f32x4*>(&dst[pix * LDP + 8 * (piece >> 1)]) = v;
-                } else if (idx < NPIX * 4) {
+                if (idx < NPIX * 4) {
                     f32x4 v = rp[k];
                     if (p.in_scale) {
                         const int pix = idx >> 2;
@@ -220,8 +218,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
     // ---- epilogue: accumulator tile -> wave-private LDS patch -> 16-byte row-major stores (see conv_f16x3.hip)
     const int col = lane & 31, rbase = (lane >> 5) * 4;
     __syncthreads();
-    auto epilogue = [&](auto generic) __attribute__((always_inline)) {
-        constexpr bool GEN = decltype(generic)::value;         // false: every view is fp32 -> the plain 16-byte accesses
+    {
         float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
         const int prow = lane >> 3, pc = (lane & 7) * 4;
         const bool vec_ok = ((p.out_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
@@ -248,7 +245,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
                     const int x = tx0 + r4 * 8 + prow;
                     rres[r4] = f32x4{0.f, 0.f, 0.f, 0.f};
                     if (res_vec && y < p.H && x < p.W)
-                        rres[r4] = otvm_ldq<GEN>(p.residual, p.res_fmt, ((int64_t)y * p.W + x) * p.res_ld + n4);
+                        rres[r4] = *reinterpret_cast<const f32x4*>(p.residual + ((int64_t)y * p.W + x) * p.res_ld + n4);
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
@@ -264,14 +261,14 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
                             v += rres[r4];
                             v.x = otvm_act(v.x, p.act); v.y = otvm_act(v.y, p.act);
                             v.z = otvm_act(v.z, p.act); v.w = otvm_act(v.w, p.act);
-                            otvm_stq<GEN>(p.out, p.out_fmt, m * p.out_ld + n4, v);
+                            *reinterpret_cast<f32x4*>(p.out + m * p.out_ld + n4) = v;
                         } else {
 #pragma unroll
                             for (int j = 0; j < 4; ++j) {
                                 if (n4 + j < p.Cout) {
                                     float xv = v[j];
-                                    if (p.residual) xv += otvm_lds<GEN>(p.residual, p.res_fmt, m * p.res_ld + n4 + j);
-                                    otvm_sts<GEN>(p.out, p.out_fmt, m * p.out_ld + n4 + j, otvm_act(xv, p.act));
+                                    if (p.residual) xv += p.residual[m * p.res_ld + n4 + j];
+                                    p.out[m * p.out_ld + n4 + j] = otvm_act(xv, p.act);
                                 }
                             }
                         }
@@ -279,9 +276,7 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
                 }
             }
         }
-    };
-    if (p.out_fmt | p.res_fmt) epilogue(std::true_type{});
-    else epilogue(std::false_type{});
+    }
 
     // ---- fused GroupNorm statistics (sum / sum of squares per group, fp64 atomics)
     if (p.gn_stats) {
@@ -434,8 +429,6 @@ static int patch_run(const otvm_conv_params* p, void* stream, int choice) {
     a.out = p->out; a.gn_stats = p->gn_stats;
     a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.in_ld = p->in_ld; a.res_ld = p->res_ld; a.Cout = p->Cout; a.out_ld = p->out_ld;
     a.n_pad32 = (p->Cout + 31) / 32 * 32; a.in_relu = p->in_relu; a.act = p->act;
-    a.in_fmt = p->in_fmt; a.res_fmt = p->res_fmt; a.out_fmt = p->out_fmt;
-    OTVM_REQUIRE(!(p->in_fmt == OTVM_FMT_HL8 && p->in_scale), "otvm_conv2d(patch): in_scale applies to a raw fp32 input, not to HL8");
     hipStream_t s = (hipStream_t)stream;
     a.in_scale = p->in_scale; a.in_shift = p->in_shift; a.in_act = p->in_act;
     if (is_wide) {
@@ -443,6 +436,9 @@ static int patch_run(const otvm_conv_params* p, void* stream, int choice) {
         if (p->dil == 2) return launch_patch<8, 256, 8, 2, 3>(a, s);
         return launch_patch<8, 256, 8, 4, 3>(a, s);
     }
+    static const int th16 = getenv("OTVM_PATCH_TH16") ? atoi(getenv("OTVM_PATCH_TH16")) : 0;
+    if (p->dil == 1 && th16 && (int64_t)p->H * p->W >= (1 << 18))      // 16x32 pixel blocks, 8 waves: half the weight stream per pixel
+        return p->Cout <= 32 ? launch_patch<16, 32, 8, 1>(a, s) : launch_patch<16, 64, 8, 1>(a, s);
     // (measured and rejected, round 2: 16x32-pixel blocks with 8 waves -- half the weight stream and less halo per pixel --
     // 64->64 at 1088x1920 0.604 vs 0.604 ms, 64->32 0.317 vs 0.306, 32->16 0.201 vs 0.187: the weight stream is not the limit)
     if (p->dil == 1) return p->Cout <= 32 ? launch_patch<8, 32, 4, 1>(a, s) : launch_patch<8, 64, 4, 1>(a, s);

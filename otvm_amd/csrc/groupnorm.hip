@@ -46,15 +46,14 @@ __global__ void gn_stats_kernel(const float* __restrict__ x, int64_t P, int C, i
     if (threadIdx.x < G * 2) atomicAdd(&stats[threadIdx.x], red[threadIdx.x]);
 }
 
-// ---- all-fp32 views: one channel quad per thread
 // y = act((x - mean_g) * rstd_g * gamma_c + beta_c [+ residual]).  The grid stride (gridDim.x * 256 float4 items) is a
 // multiple of the C/4 quads of a pixel (host side), so a thread keeps ONE channel quad for the whole launch: its
 // scale/shift live in registers and the pixel index advances by a constant.  mean / rstd are derived from the fp64
 // sums once per group per block (32 fp64 divisions and square roots, not C of them as in the first version).
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, int64_t P, int C, int ld,
                                                        const double* __restrict__ stats, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, const float* residual,
-                                                       int res_ld, int act, float* out, int out_ld) {
+                                                       const float* __restrict__ beta, const float* __restrict__ residual,
+                                                       int res_ld, int act, float* __restrict__ out, int out_ld) {
     __shared__ float mean_s[G], rstd_s[G];
     const int cg = C / G;
     if (threadIdx.x < G) {
@@ -106,69 +105,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     }
 }
 
-// ---- residual / output in either storage format: one channel octet per thread
-// y = act((x - mean_g) * rstd_g * gamma_c + beta_c [+ residual]).  The grid stride (gridDim.x * 256 octet items) is a
-// multiple of the C/8 octets of a pixel (host side), so a thread keeps ONE channel octet for the whole launch: its
-// scale/shift live in registers and the pixel index advances by a constant.  mean / rstd are derived from the fp64
-// sums once per group per block.  x is the raw fp32 conv output; residual / out may be fp32 or pre-split HL8
-// (common.h): a thread reads its whole octet (32 bytes) before it writes the same 32 bytes, so the pass may run in
-// place for either output format.
-__global__ __launch_bounds__(256) void gn_apply_fmt_kernel(const float* __restrict__ x, int64_t P, int C, int ld,
-                                                       const double* __restrict__ stats, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, const float* residual,
-                                                       int res_ld, int res_fmt, int act, float* out, int out_ld, int out_fmt) {
-    __shared__ float mean_s[G], rstd_s[G];
-    const int cg = C / G;
-    if (threadIdx.x < G) {
-        const double cnt = (double)P * cg;
-        const double mean = stats[threadIdx.x * 2] / cnt;
-        double var = stats[threadIdx.x * 2 + 1] / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        mean_s[threadIdx.x] = (float)mean;
-        rstd_s[threadIdx.x] = (float)(1.0 / sqrt(var + 1e-5));
-    }
-    __syncthreads();
-    const int Q = C >> 3;
-    const int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;            // multiple of Q
-    int64_t pix = i0 / Q;
-    const int c = (int)(i0 - pix * Q) * 8;
-    const int64_t dpix = stride / Q;
-    float as[8], bs[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const int g = (c + j) / cg;
-        as[j] = rstd_s[g] * gamma[c + j];
-        bs[j] = beta[c + j] - mean_s[g] * as[j];
-    }
-    const f32x4 a[2] = {f32x4{as[0], as[1], as[2], as[3]}, f32x4{as[4], as[5], as[6], as[7]}};
-    const f32x4 b[2] = {f32x4{bs[0], bs[1], bs[2], bs[3]}, f32x4{bs[4], bs[5], bs[6], bs[7]}};
-    for (; pix < P; pix += dpix) {
-        f32x4 v0 = *reinterpret_cast<const f32x4*>(x + pix * ld + c);
-        f32x4 v1 = *reinterpret_cast<const f32x4*>(x + pix * ld + c + 4);
-        v0 = v0 * a[0] + b[0];
-        v1 = v1 * a[1] + b[1];
-        if (residual) {
-            v0 += otvm_ld4(residual, res_fmt, pix * res_ld + c);
-            v1 += otvm_ld4(residual, res_fmt, pix * res_ld + c + 4);
-        }
-        v0.x = otvm_act(v0.x, act); v0.y = otvm_act(v0.y, act); v0.z = otvm_act(v0.z, act); v0.w = otvm_act(v0.w, act);
-        v1.x = otvm_act(v1.x, act); v1.y = otvm_act(v1.y, act); v1.z = otvm_act(v1.z, act); v1.w = otvm_act(v1.w, act);
-        if (out_fmt == OTVM_FMT_F32) {
-            *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = v0;
-            *reinterpret_cast<f32x4*>(out + pix * out_ld + c + 4) = v1;
-        } else {                                                     // one octet = 16 B of hi halves + 16 B of lo halves
-            otvm_f16x4 h0, l0, h1, l1;
-            otvm_split4(v0, h0, l0);
-            otvm_split4(v1, h1, l1);
-            typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
-            char* o = reinterpret_cast<char*>(out) + ((pix * out_ld + c) << 2);
-            *reinterpret_cast<f16x8*>(o) = f16x8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
-            *reinterpret_cast<f16x8*>(o + 16) = f16x8{l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
-        }
-    }
-}
-
 __global__ void gn_table_kernel(const double* __restrict__ stats, int64_t P, int C, const float* __restrict__ gamma,
                                 const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift) {
     __shared__ float mean_s[G], rstd_s[G];
@@ -214,28 +150,21 @@ extern "C" int otvm_gn_stats(const float* x, int64_t P, int C, int ld, double* s
 }
 
 extern "C" int otvm_gn_apply(const float* x, int64_t P, int C, int ld, const double* stats, const float* gamma,
-                             const float* beta, const float* residual, int res_ld, int res_fmt, int act, float* out,
-                             int out_ld, int out_fmt, void* stream) {
+                             const float* beta, const float* residual, int res_ld, int act, float* out, int out_ld,
+                             void* stream) {
     OTVM_REQUIRE(C % 64 == 0 && C <= 2048, "otvm_gn_apply: C=%d unsupported", C);
     OTVM_REQUIRE(ld % 4 == 0 && out_ld % 4 == 0 && (!residual || res_ld % 4 == 0), "otvm_gn_apply: unaligned view");
-    OTVM_REQUIRE(otvm_view_ok(out, out_ld, out_fmt) && (!residual || otvm_view_ok(residual, res_ld, res_fmt)),
-                 "otvm_gn_apply: bad HL8 view (needs ld %% 8 == 0 and a 32-byte aligned origin)");
-    const bool f32 = res_fmt == OTVM_FMT_F32 && out_fmt == OTVM_FMT_F32;
-    const int Q = f32 ? C / 4 : C / 8;                        // channel quads (fp32 kernel) / octets per pixel
+    const int Q = C / 4;
     const int64_t total = P * Q;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    // the grid stride must be a multiple of Q (a thread keeps one channel quad / octet): Q | blocks * 256
+    // the grid stride must be a multiple of Q (the kernel keeps one channel quad per thread): Q | blocks * 256
     int gcd = 256, r = Q;
     while (r) { const int t = gcd % r; gcd = r; r = t; }
     const int m = Q / gcd;                                   // smallest m with Q | 256 m
     blocks = (blocks + m - 1) / m * m;
-    if (f32)
-        hipLaunchKernelGGL(gn_apply_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, P, C, ld, stats, gamma, beta,
-                           residual, res_ld, act, out, out_ld);
-    else
-        hipLaunchKernelGGL(gn_apply_fmt_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, P, C, ld, stats, gamma,
-                           beta, residual, res_ld, res_fmt, act, out, out_ld, out_fmt);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, P, C, ld, stats, gamma, beta,
+                       residual, res_ld, act, out, out_ld);
     OTVM_CHECK_LAUNCH("otvm_gn_apply");
     return 0;
 }

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256) void memory_read_partial_kernel(const MemArgs 
 }
 
 __global__ void memory_read_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, int T, int hw,
-                                           float* __restrict__ out, int out_ld, int out_fmt) {
+                                           float* __restrict__ out, int out_ld) {
     const int64_t total = (int64_t)hw * (DV / 4);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int q = (int)(i / (DV / 4)), c = (int)(i - (int64_t)q * (DV / 4)) * 4;
@@ -217,17 +217,16 @@ __global__ void memory_read_combine_kernel(const float* __restrict__ part_o, con
             l += w * part_ml[((int64_t)t * hw + q) * 2 + 1];
             o += w * *reinterpret_cast<const f32x4*>(part_o + ((int64_t)t * hw + q) * DV + c);
         }
-        otvm_st4(out, out_fmt, (int64_t)q * out_ld + c, o * (1.f / l));
+        *reinterpret_cast<f32x4*>(out + (int64_t)q * out_ld + c) = o * (1.f / l);
     }
 }
 
 }  // namespace
 
-int otvm_memory_read_combine(const float* part_o, const float* part_ml, int T, int hw, float* out, int out_ld, int out_fmt,
-                             void* stream) {
+int otvm_memory_read_combine(const float* part_o, const float* part_ml, int T, int hw, float* out, int out_ld, void* stream) {
     const int64_t total = (int64_t)hw * (DV / 4);
     hipLaunchKernelGGL(memory_read_combine_kernel, dim3((int)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part_o,
-                       part_ml, T, hw, out, out_ld, out_fmt);
+                       part_ml, T, hw, out, out_ld);
     OTVM_CHECK_LAUNCH("otvm_memory_read(combine)");
     return 0;
 }
@@ -257,5 +256,5 @@ extern "C" int otvm_memory_read(const float* q_key, int q_ld, const float* const
         hipLaunchKernelGGL(memory_read_partial_kernel, dim3(otvm_ceil_div(hw, BQ), n), dim3(256), 0, s, a);
     }
     OTVM_CHECK_LAUNCH("otvm_memory_read");
-    return otvm_memory_read_combine(a.part_o, a.part_ml, T, hw, out, out_ld, OTVM_FMT_F32, stream);
+    return otvm_memory_read_combine(a.part_o, a.part_ml, T, hw, out, out_ld, stream);
 }

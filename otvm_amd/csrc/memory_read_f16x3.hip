@@ -278,8 +278,7 @@ __global__ __launch_bounds__(256, 2) void memory_read_f16x3_kernel(const Mem3Arg
 
 }  // namespace
 
-int otvm_memory_read_combine(const float* part_o, const float* part_ml, int T, int hw, float* out, int out_ld, int out_fmt,
-                             void* stream);
+int otvm_memory_read_combine(const float* part_o, const float* part_ml, int T, int hw, float* out, int out_ld, void* stream);
 
 static inline int hw_pad64(int hw) { return (hw + 63) / 64 * 64; }
 
@@ -314,11 +313,10 @@ extern "C" int otvm_bank_pack_f16x3(const float* key, const float* val, int hw, 
 }
 
 extern "C" int otvm_memory_read_f16x3(const float* q_key, int q_ld, const void* const* slots, int T, int hw, float* out,
-                                      int out_ld, int out_fmt, void* ws, void* stream) {
+                                      int out_ld, void* ws, void* stream) {
     OTVM_REQUIRE(T >= 1 && T <= 4096, "otvm_memory_read_f16x3: T=%d out of range [1,4096]", T);
     OTVM_REQUIRE(q_key && slots && out && ws && hw > 0, "otvm_memory_read_f16x3: bad arguments");
     OTVM_REQUIRE(q_ld % 4 == 0 && out_ld % 4 == 0, "otvm_memory_read_f16x3: views must be 16-byte aligned");
-    OTVM_REQUIRE(otvm_view_ok(out, out_ld, out_fmt), "otvm_memory_read_f16x3: bad HL8 output view");
     const int hp = hw_pad64(hw);
     Mem3Args a;
     a.q = q_key; a.q_ld = q_ld; a.hw = hw;
@@ -345,5 +343,5 @@ extern "C" int otvm_memory_read_f16x3(const float* q_key, int q_ld, const void* 
         part0 += used;
     }
     OTVM_CHECK_LAUNCH("otvm_memory_read_f16x3");
-    return otvm_memory_read_combine(a.part_o, a.part_ml, part0, hw, out, out_ld, out_fmt, stream);
+    return otvm_memory_read_combine(a.part_o, a.part_ml, part0, hw, out, out_ld, stream);
 }

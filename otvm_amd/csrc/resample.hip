@@ -1,4 +1,4 @@
-// Pooling / resampling kernels on NHWC activations, fp32 or pre-split HL8 (common.h) (HBM-bound, 16-byte accesses along channels).
+// Pooling / resampling kernels on NHWC fp32 (HBM-bound, 16-byte accesses along channels).
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -11,8 +11,8 @@ __device__ __forceinline__ f32x4 vmax(f32x4 a, f32x4 b) {
 }
 
 // F.max_pool2d(kernel 3, stride 2, padding 1): padding acts as -inf
-__global__ void maxpool3x3s2_kernel(const float* __restrict__ in, int H, int W, int C, int ld, int in_fmt,
-                                    float* __restrict__ out, int Ho, int Wo, int out_ld, int out_fmt) {
+__global__ void maxpool3x3s2_kernel(const float* __restrict__ in, int H, int W, int C, int ld, float* __restrict__ out,
+                                    int Ho, int Wo, int out_ld) {
     const int Q = C >> 2;
     const int64_t total = (int64_t)Ho * Wo * Q;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -29,10 +29,10 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, int H, int W, 
             for (int dx = -1; dx <= 1; ++dx) {
                 const int ix = ox * 2 + dx;
                 if ((unsigned)ix >= (unsigned)W) continue;
-                m = vmax(m, otvm_ld4(in, in_fmt, ((int64_t)iy * W + ix) * ld + c));
+                m = vmax(m, *reinterpret_cast<const f32x4*>(in + ((int64_t)iy * W + ix) * ld + c));
             }
         }
-        otvm_st4(out, out_fmt, pix * out_ld + c, m);
+        *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = m;
     }
 }
 
@@ -41,9 +41,9 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, int H, int W, 
 // One output row per blockIdx.y: the row terms (y0, y1, ly) are uniform, the column index is a 32-bit division by
 // the channel-quad count (the flat 64-bit index of the first version cost two int64 divisions per float4).
 __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ in, int Hi, int Wi, int C, int in_ld,
-                                                                int in_fmt, const float* __restrict__ add, int add_ld,
-                                                                int add_fmt, float* __restrict__ out, int Ho, int Wo,
-                                                                int out_ld, int out_fmt, float sy, float sx) {
+                                                                const float* __restrict__ add, int add_ld,
+                                                                float* __restrict__ out, int Ho, int Wo, int out_ld, float sy,
+                                                                float sx) {
     const int Q = C >> 2;
     const int oy = blockIdx.y;
     float fy = ((float)oy + 0.5f) * sy - 0.5f;
@@ -51,8 +51,8 @@ __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __r
     const int y0 = (int)fy;
     const int y1 = y0 + (y0 < Hi - 1 ? 1 : 0);
     const float ly = fy - (float)y0, hy = 1.f - ly;
-    const int64_t r0 = (int64_t)y0 * Wi * in_ld;       // element offsets of the two source rows
-    const int64_t r1 = (int64_t)y1 * Wi * in_ld;
+    const float* r0 = in + (int64_t)y0 * Wi * in_ld;
+    const float* r1 = in + (int64_t)y1 * Wi * in_ld;
     const unsigned total = (unsigned)Wo * (unsigned)Q;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const unsigned ox = i / (unsigned)Q;
@@ -62,14 +62,14 @@ __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __r
         const int x0 = (int)fx;
         const int x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
         const float lx = fx - (float)x0, hx = 1.f - lx;
-        const f32x4 v00 = otvm_ld4(in, in_fmt, r0 + (int64_t)x0 * in_ld + c);
-        const f32x4 v01 = otvm_ld4(in, in_fmt, r0 + (int64_t)x1 * in_ld + c);
-        const f32x4 v10 = otvm_ld4(in, in_fmt, r1 + (int64_t)x0 * in_ld + c);
-        const f32x4 v11 = otvm_ld4(in, in_fmt, r1 + (int64_t)x1 * in_ld + c);
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(r0 + (int64_t)x0 * in_ld + c);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(r0 + (int64_t)x1 * in_ld + c);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(r1 + (int64_t)x0 * in_ld + c);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(r1 + (int64_t)x1 * in_ld + c);
         f32x4 v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
         const int64_t pix = (int64_t)oy * Wo + ox;
-        if (add) v += otvm_ld4(add, add_fmt, pix * add_ld + c);
-        otvm_st4(out, out_fmt, pix * out_ld + c, v);
+        if (add) v += *reinterpret_cast<const f32x4*>(add + pix * add_ld + c);
+        *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = v;
     }
 }
 
@@ -86,7 +86,7 @@ __device__ __forceinline__ void ppm_scale(int bin, int& s, int& base, int& xbase
     else { s = 6; base = 14; xbase = 6; }
 }
 
-__global__ __launch_bounds__(256) void ppm_pool_rows_kernel(const float* __restrict__ in, int H, int W, int C, int ld, int in_fmt,
+__global__ __launch_bounds__(256) void ppm_pool_rows_kernel(const float* __restrict__ in, int H, int W, int C, int ld,
                                                             float* __restrict__ rowsum) {
     const int y = blockIdx.x;
     const int q = threadIdx.x & 63, lanep = threadIdx.x >> 6;
@@ -106,9 +106,9 @@ __global__ __launch_bounds__(256) void ppm_pool_rows_kernel(const float* __restr
     for (int j = 0; j < PPM_XBINS; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
-        const int64_t row = (int64_t)y * W * ld + c;
+        const float* row = in + (int64_t)y * W * ld + c;
         for (int x = lanep; x < W; x += 4) {
-            const f32x4 v = otvm_ld4(in, in_fmt, row + (int64_t)x * ld);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(row + (int64_t)x * ld);
 #pragma unroll
             for (int j = 0; j < PPM_XBINS; ++j) acc[j] += (x >= x0[j] && x < x1[j]) ? v : zero;
         }
@@ -147,40 +147,35 @@ static int grid_for(int64_t total) {
     return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
 }
 
-extern "C" int otvm_maxpool3x3s2(const float* in, int H, int W, int C, int ld, int in_fmt, float* out, int out_ld, int out_fmt,
-                                 void* stream) {
+extern "C" int otvm_maxpool3x3s2(const float* in, int H, int W, int C, int ld, float* out, int out_ld, void* stream) {
     OTVM_REQUIRE(C % 4 == 0 && ld % 4 == 0 && out_ld % 4 == 0, "otvm_maxpool3x3s2: channels must be multiples of 4");
-    OTVM_REQUIRE(otvm_view_ok(in, ld, in_fmt) && otvm_view_ok(out, out_ld, out_fmt), "otvm_maxpool3x3s2: bad HL8 view");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for((int64_t)Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream,
-                       in, H, W, C, ld, in_fmt, out, Ho, Wo, out_ld, out_fmt);
+                       in, H, W, C, ld, out, Ho, Wo, out_ld);
     OTVM_CHECK_LAUNCH("otvm_maxpool3x3s2");
     return 0;
 }
 
-extern "C" int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, int in_ld, int in_fmt, const float* add, int add_ld,
-                                      int add_fmt, float* out, int Ho, int Wo, int out_ld, int out_fmt, void* stream) {
+extern "C" int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, int in_ld, const float* add, int add_ld,
+                                      float* out, int Ho, int Wo, int out_ld, void* stream) {
     OTVM_REQUIRE(C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0 && (!add || add_ld % 4 == 0),
                  "otvm_upsample_bilinear: channels must be multiples of 4");
-    OTVM_REQUIRE(otvm_view_ok(in, in_ld, in_fmt) && otvm_view_ok(out, out_ld, out_fmt) && (!add || otvm_view_ok(add, add_ld, add_fmt)),
-                 "otvm_upsample_bilinear: bad HL8 view");
     const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
     OTVM_REQUIRE(Ho <= 65535 && (int64_t)Wo * (C / 4) < (1ll << 31), "otvm_upsample_bilinear: output %dx%d too large", Ho, Wo);
     int bx = otvm_ceil_div(Wo * (C / 4), 256);
     if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(bx, Ho), dim3(256), 0, (hipStream_t)stream, in, Hi, Wi, C, in_ld, in_fmt,
-                       add, add_ld, add_fmt, out, Ho, Wo, out_ld, out_fmt, sy, sx);
+    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(bx, Ho), dim3(256), 0, (hipStream_t)stream, in, Hi, Wi, C, in_ld, add,
+                       add_ld, out, Ho, Wo, out_ld, sy, sx);
     OTVM_CHECK_LAUNCH("otvm_upsample_bilinear");
     return 0;
 }
 
 extern "C" int64_t otvm_ppm_pool_ws_bytes(int H, int C) { return (int64_t)H * PPM_XBINS * C * sizeof(float); }
 
-extern "C" int otvm_ppm_pool(const float* in, int H, int W, int C, int ld, int in_fmt, float* out, void* ws, void* stream) {
+extern "C" int otvm_ppm_pool(const float* in, int H, int W, int C, int ld, float* out, void* ws, void* stream) {
     OTVM_REQUIRE(C % 4 == 0 && ld % 4 == 0 && ws, "otvm_ppm_pool: channels must be multiples of 4, ws required");
-    OTVM_REQUIRE(otvm_view_ok(in, ld, in_fmt), "otvm_ppm_pool: bad HL8 view");
     hipLaunchKernelGGL(ppm_pool_rows_kernel, dim3(H, otvm_ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, in, H, W, C,
-                       ld, in_fmt, (float*)ws);
+                       ld, (float*)ws);
     hipLaunchKernelGGL(ppm_pool_final_kernel, dim3(50, otvm_ceil_div(C, 1024)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)ws, H, W, C, out);
     OTVM_CHECK_LAUNCH("otvm_ppm_pool");

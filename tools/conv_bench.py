@@ -35,25 +35,20 @@ def main():
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--gn", type=int, default=0, help="fused GroupNorm statistics in the epilogue")
     ap.add_argument("--bias", type=int, default=0)
-    ap.add_argument("--hl8", default="0,0,0", help="input,residual,output stored pre-split (OTVM_FMT_HL8): e.g. 1,1,1")
     args = ap.parse_args()
-    ifmt, rfmt, ofmt = (int(v) for v in args.hl8.split(","))
-    from otvm_amd.hl8 import encode
     shapes = [tuple(int(v) for v in s.split(",")) for s in args.shape] if args.shape else DEFAULT
     lib = L.load()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     for (Cin, Cout, k, stride, dil, H, W) in shapes:
         pad = dil * (k - 1) // 2
-        xv = torch.randn(H * W * Cin, device=dev)
-        x = Act(encode(xv) if ifmt else xv, H, W, Cin, fmt=ifmt)
+        x = Act(torch.randn(H * W * Cin, device=dev), H, W, Cin)
         w = torch.randn(Cout, Cin, k, k, device=dev) / math.sqrt(Cin * k * k)
         cw = pack_conv_weight(lib, dev, w, split=True, stream=st)
         Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
         Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
-        out = Act(torch.empty(Ho * Wo * max(4, Cout), device=dev), Ho, Wo, Cout, fmt=ofmt)
-        rv = torch.randn(Ho * Wo * Cout, device=dev) if args.res else None
-        res = Act(encode(rv) if rfmt else rv, Ho, Wo, Cout, fmt=rfmt) if args.res else None
+        out = Act(torch.empty(Ho * Wo * max(4, Cout), device=dev), Ho, Wo, Cout)
+        res = Act(torch.randn(Ho * Wo * Cout, device=dev), Ho, Wo, Cout) if args.res else None
         bias = torch.randn(Cout, device=dev) if args.bias else None
         p = conv_params(x, cw, out, bias, stride, pad, dil, 0, args.relu, res, args.prec)
         stats = torch.zeros(64, dtype=torch.float64, device=dev)

@@ -3,8 +3,7 @@
     python tools/conv_fuzz.py [--n 200] [--seed 0]
 
 Shapes are drawn so that all tile families, the patch kernels, the split-K route, ragged M / N tiles, channel-slice
-views (ld > C, offset), the epilogue options (bias, residual, activation, fused GroupNorm sums) and, on the f16x3
-path, pre-split (OTVM_FMT_HL8) input / residual / output views are hit.
+views (ld > C, offset) and the epilogue options (bias, residual, activation, fused GroupNorm sums) are hit.
 """
 import argparse
 import math
@@ -59,19 +58,11 @@ def main():
             ref = ref + res
         ref = F.relu(ref) if act == 1 else (F.leaky_relu(ref, 0.01) if act == 2 else ref)
         cw = G.pack_weight(w)
-        # storage formats: pre-split (HL8) views exist on the f16x3 path for Cin % 32 == 0 inputs and Cout % 8 == 0,
-        # non-GroupNorm outputs; such views start on 8-channel boundaries
-        ifmt = int(prec == 1 and Cin % 32 == 0 and k != 7 and rng.random() < 0.5)
-        ofmt = int(prec == 1 and Cout % 8 == 0 and not gn and rng.random() < 0.5)
-        rfmt = int(prec == 1 and Cout % 8 == 0 and rng.random() < 0.5)
-        off = rng.choice([0, 8]) if ifmt else rng.choice([0, 4, 8])
-        xa = G.to_act(x, ld=cw.I_pad + off, off=off, fmt=ifmt)
-        if ofmt:
-            out = G.empty_act(ref.shape[2], ref.shape[3], Cout, ld=Cout + rng.choice([0, 8]), off=rng.choice([0, 8]), fmt=1)
-        else:
-            out = G.empty_act(ref.shape[2], ref.shape[3], max(4, (Cout + 3) // 4 * 4), ld=(Cout + 3) // 4 * 4 + rng.choice([0, 4]),
-                              off=rng.choice([0, 4]))
-        ra = G.to_act(res, fmt=rfmt) if use_res else None
+        off = rng.choice([0, 4, 8])
+        xa = G.to_act(x, ld=cw.I_pad + off, off=off)
+        out = G.empty_act(ref.shape[2], ref.shape[3], max(4, (Cout + 3) // 4 * 4), ld=(Cout + 3) // 4 * 4 + rng.choice([0, 4]),
+                          off=rng.choice([0, 4]))
+        ra = G.to_act(res) if use_res else None
         bd = None if b is None else b.to(G.DEV)
         stats = torch.zeros(64, dtype=torch.float64, device=G.DEV) if gn else None
         G.conv2d(xa, cw, out, bd, stride, pad, dil, act, in_relu, ra, precision=prec, gn_stats=stats,
@@ -79,8 +70,8 @@ def main():
         got = G.from_act(out, Cout)
         err = G.maxdiff(got, ref) / max(1.0, float(ref.abs().max()))
         worst = max(worst, err)
-        tag = "Cin %4d Cout %4d k%d s%d d%d p%d %3dx%-3d prec %d bias %d act %d relu_in %d res %d gn %d fmt i%d r%d o%d" % (
-            Cin, Cout, k, stride, dil, pad, H, W, prec, use_bias, act, in_relu, use_res, gn, ifmt, rfmt, ofmt)
+        tag = "Cin %4d Cout %4d k%d s%d d%d p%d %3dx%-3d prec %d bias %d act %d relu_in %d res %d gn %d" % (
+            Cin, Cout, k, stride, dil, pad, H, W, prec, use_bias, act, in_relu, use_res, gn)
         ok = bool(torch.isfinite(got).all()) and err <= 3e-5
         if gn:
             gg = ref.double().reshape(32, Cout // 32, -1)

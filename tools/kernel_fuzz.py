@@ -52,20 +52,16 @@ def main():
         if use_res:
             ref = ref + res
         ref = F.relu(ref) if act == 1 else (F.leaky_relu(ref, 0.01) if act == 2 else ref)
-        # output / residual views fp32 or pre-split (HL8, include/otvm_hip.h): HL8 views sit on 8-channel boundaries
-        ofmt, rfmt = rng.choice([0, 1]), rng.choice([0, 1])
-        al = 8 if ofmt else 4
-        xa = G.to_act(x, ld=Cc + rng.choice([0, al]), off=rng.choice([0, al]))
-        out = xa.as_fmt(ofmt) if inplace else G.empty_act(H, W, Cc, ld=Cc + rng.choice([0, 8]), off=rng.choice([0, 8]), fmt=ofmt)
-        ra = G.to_act(res, fmt=rfmt) if use_res else None
+        xa = G.to_act(x, ld=Cc + rng.choice([0, 4]), off=rng.choice([0, 4]))
+        out = xa if inplace else G.empty_act(H, W, Cc)
+        ra = G.to_act(res) if use_res else None
         gd, bd = ga.to(G.DEV), be.to(G.DEV)
         stats = torch.zeros(64, dtype=torch.float64, device=G.DEV)
         L.check(lib.otvm_gn_stats(xa.ptr, H * W, Cc, xa.ld, stats.data_ptr(), st))
         L.check(lib.otvm_gn_apply(xa.ptr, H * W, Cc, xa.ld, stats.data_ptr(), gd.data_ptr(), bd.data_ptr(),
-                                  0 if ra is None else ra.ptr, 0 if ra is None else ra.ld, rfmt, act, out.ptr, out.ld, ofmt, st))
+                                  0 if ra is None else ra.ptr, 0 if ra is None else ra.ld, act, out.ptr, out.ld, st))
         torch.cuda.synchronize()
-        worst["gn"] = max(worst.get("gn", 0), check("groupnorm", G.from_act(out), ref, 3e-5,
-                                                    "C%d %dx%d act%d res%d fmt%d%d ip%d" % (Cc, H, W, act, use_res, rfmt, ofmt, inplace)))
+        worst["gn"] = max(worst.get("gn", 0), check("groupnorm", G.from_act(out), ref, 3e-5, "C%d %dx%d act%d res%d" % (Cc, H, W, act, use_res)))
         # ---- upsample (+ add)
         Cu = rng.choice([4, 16, 64, 256])
         hi, wi = rng.randint(1, 24), rng.randint(1, 24)
@@ -75,31 +71,27 @@ def main():
         refu = F.interpolate(xu, size=(ho, wo), mode="bilinear", align_corners=False)
         if add is not None:
             refu = refu + add
-        hl_ok = Cu % 8 == 0
-        ifmt, afmt, ofmt = [rng.choice([0, 1]) if hl_ok else 0 for _ in range(3)]
-        xua, oua = G.to_act(xu, fmt=ifmt), G.empty_act(ho, wo, Cu, fmt=ofmt)
-        aa = G.to_act(add, fmt=afmt) if add is not None else None
-        L.check(lib.otvm_upsample_bilinear(xua.ptr, hi, wi, Cu, xua.ld, ifmt, 0 if aa is None else aa.ptr,
-                                           0 if aa is None else aa.ld, afmt, oua.ptr, ho, wo, oua.ld, ofmt, st))
+        xua, oua = G.to_act(xu), G.empty_act(ho, wo, Cu)
+        aa = G.to_act(add) if add is not None else None
+        L.check(lib.otvm_upsample_bilinear(xua.ptr, hi, wi, Cu, xua.ld, 0 if aa is None else aa.ptr, 0 if aa is None else aa.ld,
+                                           oua.ptr, ho, wo, oua.ld, st))
         torch.cuda.synchronize()
         worst["up"] = max(worst.get("up", 0), check("upsample", G.from_act(oua), refu, 1e-5, "C%d %dx%d->%dx%d" % (Cu, hi, wi, ho, wo)))
         # ---- maxpool 3x3 / 2, pad 1
         hm, wm = rng.randint(2, 40), rng.randint(2, 40)
         xm = torch.randn(1, 64, hm, wm, generator=g)
         refm = F.max_pool2d(xm, 3, 2, 1)
-        ifmt, ofmt = rng.choice([0, 1]), rng.choice([0, 1])
-        xma, oma = G.to_act(xm, fmt=ifmt), G.empty_act(refm.shape[2], refm.shape[3], 64, fmt=ofmt)
-        L.check(lib.otvm_maxpool3x3s2(xma.ptr, hm, wm, 64, xma.ld, ifmt, oma.ptr, oma.ld, ofmt, st))
+        xma, oma = G.to_act(xm), G.empty_act(refm.shape[2], refm.shape[3], 64)
+        L.check(lib.otvm_maxpool3x3s2(xma.ptr, hm, wm, 64, xma.ld, oma.ptr, oma.ld, st))
         torch.cuda.synchronize()
-        check("maxpool", G.from_act(oma), refm, 0.0 if not (ifmt or ofmt) else 2e-6, "%dx%d fmt%d%d" % (hm, wm, ifmt, ofmt))
+        check("maxpool", G.from_act(oma), refm, 0.0, "%dx%d" % (hm, wm))
         # ---- PPM pooling
         hp, wp, Cp = rng.randint(1, 40), rng.randint(1, 40), rng.choice([4, 64, 260, 512, 2048])
         xp = torch.randn(1, Cp, hp, wp, generator=g)
-        pfmt = rng.choice([0, 1]) if Cp % 8 == 0 else 0
-        xpa = G.to_act(xp, fmt=pfmt)
+        xpa = G.to_act(xp)
         pool = torch.empty(50 * Cp, device=G.DEV)
         pws = torch.empty(int(lib.otvm_ppm_pool_ws_bytes(hp, Cp)), dtype=torch.uint8, device=G.DEV)
-        L.check(lib.otvm_ppm_pool(xpa.ptr, hp, wp, Cp, xpa.ld, pfmt, pool.data_ptr(), pws.data_ptr(), st))
+        L.check(lib.otvm_ppm_pool(xpa.ptr, hp, wp, Cp, xpa.ld, pool.data_ptr(), pws.data_ptr(), st))
         torch.cuda.synchronize()
         base = 0
         for s in (1, 2, 3, 6):
@@ -125,7 +117,7 @@ def main():
                 L.check(lib.otvm_bank_pack_f16x3(keys[t].data_ptr(), vals[t].data_ptr(), hw, sl.data_ptr(), st))
                 slots.append(sl)
             sp = (C.c_void_p * T)(*[s_.data_ptr() for s_ in slots])
-            L.check(lib.otvm_memory_read_f16x3(q.data_ptr(), 128, sp, T, hw, outr.data_ptr(), 512, 0, ws.data_ptr(), st))
+            L.check(lib.otvm_memory_read_f16x3(q.data_ptr(), 128, sp, T, hw, outr.data_ptr(), 512, ws.data_ptr(), st))
             torch.cuda.synchronize()
             worst["mem"] = max(worst.get("mem", 0), check("memory_read_f16x3", outr.cpu(), refr, 2e-5, "T%d %dx%d" % (T, h, w)))
         # ---- trimap distance encoding

@@ -39,7 +39,7 @@ def main():
         ws = torch.empty(int(lib.otvm_memory_read_ws_bytes(hw, T)), dtype=torch.uint8, device=dev)
 
         def run():
-            L.check(lib.otvm_memory_read_f16x3(q.data_ptr(), 128, sp, T, hw, out.data_ptr(), 512, 0, ws.data_ptr(), st))
+            L.check(lib.otvm_memory_read_f16x3(q.data_ptr(), 128, sp, T, hw, out.data_ptr(), 512, ws.data_ptr(), st))
         for _ in range(3):
             run()
         torch.cuda.synchronize()
