@@ -122,7 +122,9 @@ def main():
 
     def run_frames(t0, t1, sink=None):
         for t in range(t0, t1):
-            out = model(a, frames[t], frames[t], tri=None, tri_gt=tri, large_input=False,
+            # _inputs_ready: the clip is resident in HBM and complete before the timed region starts (the bench contract),
+            # so the query encoder of frame t may start while frame t-1's alpha network is still executing
+            out = model(a, frames[t], frames[t], tri=None, tri_gt=tri, large_input=False, _inputs_ready=True,
                         **frame_kwargs(t, T, args.skip, args.max_num))
             t_read[t] = model._engine.last_T_read
             if sink is not None:

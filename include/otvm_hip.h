@@ -35,9 +35,10 @@ extern "C" {
 #define OTVM_PREC_F16X3 1
 
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 6    /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
+#define OTVM_ABI_VERSION 7    /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
                                  4: otvm_conv_params.splitk_ws; 5: otvm_preprocess_params.fg_u8/bg_u8/u8_rgb;
-                                 6: otvm_conv_params.tune + otvm_conv2d_candidates */
+                                 6: otvm_conv_params.tune + otvm_conv2d_candidates;
+                                 7: folded GroupNorm tables on otvm_gn_apply's residual and otvm_upsample_bilinear's input */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -56,6 +57,13 @@ int otvm_pack_conv_weight(const float* w_oihw, int O, int I, int kh, int kw, int
 int64_t otvm_patch_weight_bytes_f16x3(int O, int I_pad);
 int otvm_pack_patch_weight_f16x3(const float* w_packed, int O, int K_pad, int I_pad, void* w_frag, float* w_scale,
                                  void* stream);
+
+/* f16x3, 7x7 stride-2 stems with few input channels (I_pad <= 64, O <= 64): weights in MFMA B-fragment order for the stem
+ * kernel (conv_stem_f16x3.hip), [ceil(I_pad/8) channel groups][25 k-steps of two taps][2 n-tiles][hi|lo][64 lanes][8 halfs];
+ * goes into otvm_conv_params.w_frag of such a layer.                                                              */
+int64_t otvm_stem_weight_bytes_f16x3(int I_pad);
+int otvm_pack_stem_weight_f16x3(const float* w_packed, int O, int K_pad, int I_pad, void* w_frag, float* w_scale,
+                                void* stream);
 
 /* Fold an eval-mode BatchNorm (eps 1e-5, running statistics; torchvision Bottleneck used by
  * STM.py:43-51,79-87) into a per-channel scale/bias: scale = gamma/sqrt(var+eps),
@@ -79,7 +87,8 @@ typedef struct {
     const void* w_hi; const void* w_lo;             /* f16x3: split weights [O_pad][K_pad] fp16   */
     const float* w_scale;                           /* f16x3: per-filter power-of-two scale [Cout] */
     const void* w_frag;                             /* f16x3, optional: fragment-major weights for the 3x3 patch kernel
-                                                       (otvm_pack_patch_weight_f16x3) or NULL                    */
+                                                       (otvm_pack_patch_weight_f16x3) or, for a 7x7 stride-2 layer, the
+                                                       stem kernel (otvm_pack_stem_weight_f16x3); NULL = implicit GEMM only */
     double* gn_stats;                               /* optional: fused GroupNorm(32) statistics of the OUTPUT
                                                        (sum, sum of squares per group, [32][2] fp64, accumulated
                                                        atomically; Cout = 64, 128, 256, ... (32 groups of a power-of-two
@@ -124,17 +133,21 @@ int otvm_gn_stats(const float* x, int64_t P, int C, int ld, double* stats, void*
  * otvm_conv_params.in_scale / in_shift: identical arithmetic to otvm_gn_apply's                                   */
 int otvm_gn_table(const double* stats, int64_t P, int C, const float* gamma, const float* beta, float* scale,
                   float* shift, void* stream);
+/* res_scale / res_shift (optional, tables from otvm_gn_table): the residual is itself a raw GroupNorm input whose apply
+ * pass was skipped; it is normalised on the fly, residual' = res_act(residual * res_scale[c] + res_shift[c]).        */
 int otvm_gn_apply(const float* x, int64_t P, int C, int ld, const double* stats, const float* gamma,
-                  const float* beta, const float* residual, int res_ld, int act,
-                  float* out, int out_ld, void* stream);
+                  const float* beta, const float* residual, int res_ld, const float* res_scale, const float* res_shift,
+                  int res_act, int act, float* out, int out_ld, void* stream);
 
 /* ---------------------------------------------------------------- pooling / resampling ---------*/
 /* F.max_pool2d(3, 2, 1) (resnet_GN_WS.py:98, torchvision resnet maxpool in STM.py:47,83) */
 int otvm_maxpool3x3s2(const float* in, int H, int W, int C, int ld, float* out, int out_ld, void* stream);
 /* F.interpolate(mode='bilinear', align_corners=False) to (Ho,Wo); out = up(in) [+ add]
  * (FBA/models.py:358-376, STM.py:115) */
-int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, int in_ld, const float* add, int add_ld,
-                           float* out, int Ho, int Wo, int out_ld, void* stream);
+/* in_scale / in_shift (optional, tables from otvm_gn_table): the GroupNorm apply of the input folded into the resampling,
+ * in' = in_act(in * in_scale[c] + in_shift[c]) per source pixel (FBA/models.py:364-376: GN + LeakyReLU, then interpolate). */
+int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, int in_ld, const float* in_scale, const float* in_shift,
+                           int in_act, const float* add, int add_ld, float* out, int Ho, int Wo, int out_ld, void* stream);
 /* nn.AdaptiveAvgPool2d(s) for s in {1,2,3,6} in one launch (FBA/models.py:300-306);
  * out = 50 bins x C, bins ordered scale-major then row-major.
  * ws >= otvm_ppm_pool_ws_bytes(H, C): per-row sums of the 12 column bins (one pass over the map, then a
@@ -166,7 +179,8 @@ int otvm_memory_read_f16x3(const float* q_key, int q_ld, const void* const* slot
 /* ---------------------------------------------------------------- frame glue --------------------
  * preprocess: alpha/model.py:380-389,408-414 + STM.py:53-57,89-93.  fg,bg: [3,H,W] fp32 BGR 0..255
  * planes; a: [H,W] in [0,1].  Writes the zero-padded 0..1 RGB composite and its normalised copies
- * into channel slices of the consumers' input buffers and the un-padded `scaled_imgs` [3,H,W].   */
+ * into channel slices of the consumers' input buffers and the un-padded `scaled_imgs` [3,H,W].
+ * Every destination (scaled_imgs, x11, sq, sm, d80) is optional: NULL = not written by this call.  */
 typedef struct {
     const float* fg; const float* bg; const float* a;
     int H, W, Hp, Wp, lh, lw;

@@ -55,7 +55,8 @@ class EvalModel(nn.Module):
 
     @torch.no_grad()
     def forward(self, a, fg, bg, tri=None, tri_gt=None, first_frame=False, last_frame=False, memorize=False,
-                max_memory_num=2, large_input=False, _frame_id=None, _cls_override=None, _frames_rgb=False):
+                max_memory_num=2, large_input=False, _frame_id=None, _cls_override=None, _frames_rgb=False,
+                _inputs_ready=None):
         if tri is not None:
             # alpha/model.py:395-396: unreachable from eval.py (EvalDataset is built with trimap=None, eval.py:133)
             raise NotImplementedError("per-frame `tri` input is not part of the reference eval path")
@@ -63,6 +64,6 @@ class EvalModel(nn.Module):
         out = eng.frame(a, fg, bg, tri_gt=tri_gt, first_frame=bool(first_frame), last_frame=bool(last_frame),
                         memorize=bool(memorize), max_memory_num=int(max_memory_num),
                         dilate_kernel=self.DILATION_KERNEL, frame_id=_frame_id, cls_override=_cls_override,
-                        frames_rgb=bool(_frames_rgb))
+                        frames_rgb=bool(_frames_rgb), inputs_ready=_inputs_ready)
         self.memory_update = memorize
         return out

@@ -15,6 +15,7 @@ SOURCES = [
     ("conv_igemm.hip", []),
     ("conv_f16x3.hip", []),
     ("conv_patch_f16x3.hip", []),
+    ("conv_stem_f16x3.hip", []),
     ("groupnorm.hip", []),
     ("resample.hip", ["-ffp-contract=off"]),
     ("glue.hip", ["-ffp-contract=off"]),

@@ -485,7 +485,7 @@ int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream);    //
 // tile shared by S workgroups (S > 1: partial tiles through the caller's workspace, added in a fixed order by
 // splitk_finish_kernel), or the 3x3 patch kernel.  otvm_conv_params.tune forces one (the host's plan-time autotuner,
 // otvm_amd/engine.py, times the candidates of otvm_conv2d_candidates on the device); 0 = the heuristic below.
-enum { T256x256 = 0, T256x128, T128x128, T128x64, T64x64, T256x64, T256x32, T_COUNT, T_PATCH = 14 };
+enum { T256x256 = 0, T256x128, T128x128, T128x64, T64x64, T256x64, T256x32, T_COUNT, T_STEM = 12, T_PATCH = 14 };
 static inline int tune_code(int tile, int S) { return (tile + 1) * 16 + S; }
 static const int TILE_BM[T_COUNT] = {256, 256, 128, 128, 64, 256, 256};
 static const int TILE_BN[T_COUNT] = {256, 128, 128, 64, 64, 64, 32};
@@ -542,11 +542,14 @@ static int run_config(const otvm_conv_params* p, Conv3Args& a, int tile, int S, 
 
 int otvm_conv2d_patch_eligible(const otvm_conv_params* p);                  // conv_patch_f16x3.hip: shape-wise eligibility
 int otvm_conv2d_patch_f16x3_forced(const otvm_conv_params* p, void* stream);
+int otvm_conv2d_stem_eligible(const otvm_conv_params* p);                   // conv_stem_f16x3.hip: 7x7 stride-2 stems
+int otvm_conv2d_stem_f16x3(const otvm_conv_params* p, void* stream);
 
 extern "C" int otvm_conv2d_candidates(const otvm_conv_params* p, int* out, int max_n) {
     int n = 0;
     if (!p || !out || p->precision != OTVM_PREC_F16X3) return 0;
     auto add = [&](int code) { if (n < max_n) out[n++] = code; };
+    if (otvm_conv2d_stem_eligible(p)) add(tune_code(T_STEM, 1));
     if (otvm_conv2d_patch_eligible(p)) add(tune_code(T_PATCH, 1));
     if (p->in_scale) return n;
     const int64_t M = (int64_t)p->Ho * p->Wo;
@@ -573,6 +576,10 @@ extern "C" int otvm_conv2d_candidates(const otvm_conv_params* p, int* out, int m
 int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     OTVM_REQUIRE(p->w_hi && p->w_lo && p->w_scale, "otvm_conv2d: precision f16x3 needs w_hi / w_lo / w_scale");
     const int forced_tile = p->tune ? p->tune / 16 - 1 : -1, forced_S = p->tune & 15;
+    if (forced_tile == T_STEM || (!p->tune && otvm_conv2d_stem_eligible(p))) {
+        OTVM_REQUIRE(otvm_conv2d_stem_eligible(p), "otvm_conv2d: tune asks for the stem kernel on a layer it cannot take");
+        return otvm_conv2d_stem_f16x3(p, stream);
+    }
     if (p->tune && forced_tile == T_PATCH) {
         OTVM_REQUIRE(otvm_conv2d_patch_eligible(p), "otvm_conv2d: tune asks for the patch kernel on a layer it cannot take");
         return otvm_conv2d_patch_f16x3_forced(p, stream);

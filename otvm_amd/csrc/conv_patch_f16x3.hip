@@ -8,7 +8,8 @@
 // (pixel rows are 80 bytes apart in LDS -> conflict-free ds_read_b128 for 32 consecutive pixels).
 //
 // Weights never touch LDS: like the memory bank they are packed at load time in MFMA B-fragment order
-// (otvm_pack_patch_weight_f16x3: [cin/32][tap][n/32][k-step][hi|lo][lane][8 halfs] = 1-KiB blocks), so a wave fetches
+// (otvm_pack_patch_weight_f16x3: [cin/32][tap][n/32][k-step][hi|lo][lane][8 halfs] = 1-KiB blocks, taps ordered
+// kx-major: tap = kx*3 + ky, so a 3-tap weight stage holds one filter COLUMN), so a wave fetches
 // a B operand with one coalesced 16-byte-per-lane load from L2.
 //
 // One wave owns TM = TH/NW output rows (M tiles of 32 pixels) x TN = BN/32 channel tiles.  fp32 accumulate; epilogue
@@ -172,10 +173,14 @@ __global__ __launch_bounds__(NW * 64) void conv_patch_f16x3_kernel(const PatchAr
             if (g + 1 < NG) prefetch(cb, g + 1);
             else if (cb + 1 < ncb) prefetch(cb + 1, 0);
             // ---- TAPG taps out of LDS
+            // (measured and rejected, round 2: a "row reuse" variant -- one filter column per weight stage, its 3 x TN weight
+            // fragments in registers, every patch row of the column read once and used for all (output row, ky) pairs: a
+            // third of the LDS fragment reads per MFMA with 4 rows per wave -- 64->64 at 1088x1920 0.543 vs 0.526 ms,
+            // 64->32 0.300 vs 0.304, 320->64 at 544x960 0.591 vs 0.520: the kernel is not bound by LDS fragment reads)
 #pragma unroll
             for (int tl = 0; tl < TAPG; ++tl) {
                 const int tap = g * TAPG + tl;
-                const int ky = tap / 3, kx = tap - ky * 3;
+                const int kx = tap / 3, ky = tap - kx * 3;        // kx-major tap order (weight packing)
                 f16x8 ah[TM], al[TM];
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
@@ -351,7 +356,8 @@ __global__ __launch_bounds__(256) void pack_patch_weight_kernel(const float* __r
     if (threadIdx.x == 0 && real) wscale[n] = ldexpf(1.f, e);
     const int nb = n >> 5, nl = n & 31, nbs = n_pad32 >> 5;
     for (int k = threadIdx.x; k < 9 * I_pad; k += 256) {
-        const int tap = k / I_pad, c = k - tap * I_pad;
+        const int tap0 = k / I_pad, c = k - tap0 * I_pad;     // packed fp32 weight: tap0 = ky*3 + kx
+        const int tap = (tap0 % 3) * 3 + tap0 / 3;            // fragment-major copy: kx-major (see the kernel)
         const float v = real ? row[k] * inv : 0.f;
         const _Float16 hi = (_Float16)v;
         const _Float16 lo = (_Float16)(v - (float)hi);

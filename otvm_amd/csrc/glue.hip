@@ -31,7 +31,7 @@ __global__ void preprocess_kernel(const otvm_preprocess_params p) {
                     sb = p.bg[(2 - c) * plane + o] * s;
                 }
                 img[c] = sf * a + sb * (1.f - a);             // alpha/model.py:386
-                p.scaled_imgs[c * plane + o] = img[c];
+                if (p.scaled_imgs) p.scaled_imgs[c * plane + o] = img[c];
             }
         }
         float n[3], q[3], m[3];
@@ -44,11 +44,15 @@ __global__ void preprocess_kernel(const otvm_preprocess_params p) {
         // 16-byte stores into the interleaved buffers (a pixel's three scalars 48 / 320 bytes apart from the next
         // pixel's were three uncoalesced store instructions each).  The fourth lane of every vector is a channel a
         // LATER kernel of the frame owns and overwrites: x11[3] (distance encoding), sq[3] / sm[+3] (zero pad / p_un).
-        *reinterpret_cast<f32x4*>(p.x11 + i * p.x11_ld) = f32x4{n[0], n[1], n[2], 0.f};
-        *reinterpret_cast<f32x4*>(p.d80 + i * p.d80_ld + 64) = f32x4{n[0], n[1], n[2], img[0]};   // FBA/models.py:377
-        *reinterpret_cast<f32x2*>(p.d80 + i * p.d80_ld + 68) = f32x2{img[1], img[2]};
-        *reinterpret_cast<f32x4*>(p.sq + i * p.sq_ld) = f32x4{q[0], q[1], q[2], 0.f};
-        *reinterpret_cast<f32x4*>(p.sm + i * p.sm_ld) = f32x4{m[0], m[1], m[2], 0.f};
+        // Every destination is optional (NULL = skip): the host launches the query-encoder input (sq) on its own stream
+        // ahead of the rest (otvm_amd/engine.py: the query encoder of frame t+1 overlaps the alpha network of frame t).
+        if (p.x11) *reinterpret_cast<f32x4*>(p.x11 + i * p.x11_ld) = f32x4{n[0], n[1], n[2], 0.f};
+        if (p.d80) {
+            *reinterpret_cast<f32x4*>(p.d80 + i * p.d80_ld + 64) = f32x4{n[0], n[1], n[2], img[0]};   // FBA/models.py:377
+            *reinterpret_cast<f32x2*>(p.d80 + i * p.d80_ld + 68) = f32x2{img[1], img[2]};
+        }
+        if (p.sq) *reinterpret_cast<f32x4*>(p.sq + i * p.sq_ld) = f32x4{q[0], q[1], q[2], 0.f};
+        if (p.sm) *reinterpret_cast<f32x4*>(p.sm + i * p.sm_ld) = f32x4{m[0], m[1], m[2], 0.f};
     }
 }
 
@@ -231,8 +235,8 @@ int grid_for(int64_t total) {
 }  // namespace
 
 extern "C" int otvm_preprocess(const otvm_preprocess_params* p, void* stream) {
-    OTVM_REQUIRE(p && ((p->fg && p->bg) || (p->fg_u8 && p->bg_u8)) && p->a && p->x11 && p->sq && p->sm && p->d80 &&
-                     p->scaled_imgs, "otvm_preprocess: null pointer");
+    OTVM_REQUIRE(p && ((p->fg && p->bg) || (p->fg_u8 && p->bg_u8)) && p->a, "otvm_preprocess: null input pointer");
+    OTVM_REQUIRE(p->x11 || p->sq || p->sm || p->d80 || p->scaled_imgs, "otvm_preprocess: no destination given");
     OTVM_REQUIRE(p->x11_ld % 4 == 0 && p->d80_ld % 4 == 0 && p->sq_ld % 4 == 0 && p->sm_ld % 4 == 0 &&
                      (((uintptr_t)p->x11 | (uintptr_t)p->d80 | (uintptr_t)p->sq | (uintptr_t)p->sm) & 15) == 0,
                  "otvm_preprocess: x11 / d80 / sq / sm views must be 16-byte aligned with strides that are multiples of 4");

@@ -40,7 +40,11 @@ __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, int H, int W, 
 // the upper neighbour index is clamped to the last row/col (PyTorch area_pixel_compute_source_index).
 // One output row per blockIdx.y: the row terms (y0, y1, ly) are uniform, the column index is a 32-bit division by
 // the channel-quad count (the flat 64-bit index of the first version cost two int64 divisions per float4).
+// in_scale / in_shift (optional): the input is a raw GroupNorm input whose apply pass is folded in here -- every source
+// pixel is normalised in' = in_act(in * in_scale[c] + in_shift[c]) (table from otvm_gn_table) before it is interpolated.
 __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ in, int Hi, int Wi, int C, int in_ld,
+                                                                const float* __restrict__ in_scale,
+                                                                const float* __restrict__ in_shift, int in_act,
                                                                 const float* __restrict__ add, int add_ld,
                                                                 float* __restrict__ out, int Ho, int Wo, int out_ld, float sy,
                                                                 float sx) {
@@ -62,10 +66,19 @@ __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __r
         const int x0 = (int)fx;
         const int x1 = x0 + (x0 < Wi - 1 ? 1 : 0);
         const float lx = fx - (float)x0, hx = 1.f - lx;
-        const f32x4 v00 = *reinterpret_cast<const f32x4*>(r0 + (int64_t)x0 * in_ld + c);
-        const f32x4 v01 = *reinterpret_cast<const f32x4*>(r0 + (int64_t)x1 * in_ld + c);
-        const f32x4 v10 = *reinterpret_cast<const f32x4*>(r1 + (int64_t)x0 * in_ld + c);
-        const f32x4 v11 = *reinterpret_cast<const f32x4*>(r1 + (int64_t)x1 * in_ld + c);
+        f32x4 v00 = *reinterpret_cast<const f32x4*>(r0 + (int64_t)x0 * in_ld + c);
+        f32x4 v01 = *reinterpret_cast<const f32x4*>(r0 + (int64_t)x1 * in_ld + c);
+        f32x4 v10 = *reinterpret_cast<const f32x4*>(r1 + (int64_t)x0 * in_ld + c);
+        f32x4 v11 = *reinterpret_cast<const f32x4*>(r1 + (int64_t)x1 * in_ld + c);
+        if (in_scale) {
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(in_scale + c), sb = *reinterpret_cast<const f32x4*>(in_shift + c);
+            v00 = v00 * sa + sb; v01 = v01 * sa + sb; v10 = v10 * sa + sb; v11 = v11 * sa + sb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v00[j] = otvm_act(v00[j], in_act); v01[j] = otvm_act(v01[j], in_act);
+                v10[j] = otvm_act(v10[j], in_act); v11[j] = otvm_act(v11[j], in_act);
+            }
+        }
         f32x4 v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
         const int64_t pix = (int64_t)oy * Wo + ox;
         if (add) v += *reinterpret_cast<const f32x4*>(add + pix * add_ld + c);
@@ -156,16 +169,18 @@ extern "C" int otvm_maxpool3x3s2(const float* in, int H, int W, int C, int ld, f
     return 0;
 }
 
-extern "C" int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, int in_ld, const float* add, int add_ld,
+extern "C" int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, int in_ld, const float* in_scale,
+                                      const float* in_shift, int in_act, const float* add, int add_ld,
                                       float* out, int Ho, int Wo, int out_ld, void* stream) {
+    OTVM_REQUIRE(!in_scale == !in_shift, "otvm_upsample_bilinear: in_scale and in_shift go together");
     OTVM_REQUIRE(C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0 && (!add || add_ld % 4 == 0),
                  "otvm_upsample_bilinear: channels must be multiples of 4");
     const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
     OTVM_REQUIRE(Ho <= 65535 && (int64_t)Wo * (C / 4) < (1ll << 31), "otvm_upsample_bilinear: output %dx%d too large", Ho, Wo);
     int bx = otvm_ceil_div(Wo * (C / 4), 256);
     if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(bx, Ho), dim3(256), 0, (hipStream_t)stream, in, Hi, Wi, C, in_ld, add,
-                       add_ld, out, Ho, Wo, out_ld, sy, sx);
+    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(bx, Ho), dim3(256), 0, (hipStream_t)stream, in, Hi, Wi, C, in_ld,
+                       in_scale, in_shift, in_act, add, add_ld, out, Ho, Wo, out_ld, sy, sx);
     OTVM_CHECK_LAUNCH("otvm_upsample_bilinear");
     return 0;
 }

@@ -132,6 +132,10 @@ def pack_conv_weight(lib, dev, w, ws=False, scale=None, i_pad=None, split=True, 
         cw.w_scale = torch.empty(O, dtype=torch.float32, device=dev)
         L.check(lib.otvm_split_conv_weight_f16x3(cw.w.data_ptr(), O, O_pad, cw.K_pad, kh * kw, cw.I_pad, cw.w_hi.data_ptr(),
                                                  cw.w_lo.data_ptr(), cw.w_scale.data_ptr(), stream), "split_conv_weight")
+        if kh == 7 and kw == 7 and O <= 64 and cw.I_pad <= 64:   # 7x7 stems: fragment-major copy for the stem kernel
+            cw.w_frag = torch.zeros(int(lib.otvm_stem_weight_bytes_f16x3(cw.I_pad)), dtype=torch.uint8, device=dev)
+            L.check(lib.otvm_pack_stem_weight_f16x3(cw.w.data_ptr(), O, cw.K_pad, cw.I_pad, cw.w_frag.data_ptr(),
+                                                    cw.w_scale.data_ptr(), stream), "pack_stem_weight")
         if kh == 3 and kw == 3 and cw.I_pad % 16 == 0:          # 3x3: also the fragment-major copy for the patch kernel
             cw.w_frag = torch.zeros(int(lib.otvm_patch_weight_bytes_f16x3(O, cw.I_pad)), dtype=torch.uint8, device=dev)
             L.check(lib.otvm_pack_patch_weight_f16x3(cw.w.data_ptr(), O, cw.K_pad, cw.I_pad, cw.w_frag.data_ptr(),
@@ -180,6 +184,7 @@ class HipEngine:
         self.stream = 0
         self.prof = None
         self.pending = None          # deferred memorize of the previous frame
+        self.ev_dec = None           # fires when the last STM decoder has read the query encoder's buffers
         self.frame_counter = 0
         self.last_T_read = 0
         self.parity = 0
@@ -269,12 +274,15 @@ class HipEngine:
             return self._frame(*args, **kw)
 
     def _frame(self, a, fg, bg, tri_gt=None, first_frame=False, last_frame=False, memorize=False, max_memory_num=2,
-               dilate_kernel=None, frame_id=None, cls_override=None, frames_rgb=False):
+               dilate_kernel=None, frame_id=None, cls_override=None, frames_rgb=False, inputs_ready=None):
         """One call of EvalModel.forward (reference models/alpha/model.py:391-512) on the HIP path.
 
         a [1,1,1,H,W] in [0,1]; fg, bg [1,1,3,H,W] BGR 0..255; tri_gt [1,1,3,H,W] or None.
         Extension: fg / bg may be the decoded uint8 images themselves, [H,W,3] interleaved (BGR, or RGB with
         ``frames_rgb``): the preprocess kernel reads them directly (same arithmetic as ``.float()`` + permute).
+        inputs_ready: True = a / fg / bg are device tensors whose contents are complete (nothing still in flight writes
+        them); a torch.cuda.Event = complete once that event has fired; None = unknown (ordered after everything issued on
+        the launch stream so far).  Only matters for how early the query encoder may start.
         Returns the reference's 5-tuple (scaled_imgs, preds_trimap, tri_gt, preds_alpha, scaled_gts)."""
         dev, lib = self.dev, self.lib
         f32 = torch.float32
@@ -321,20 +329,6 @@ class HipEngine:
         par = self.parity
         self.parity ^= 1
         main = torch.cuda.current_stream(dev)
-        ev_side = None
-        if pend is not None:
-            if self.prof is None and self.use_side_stream:
-                if self.side is None:
-                    self.side = torch.cuda.Stream(device=dev)
-                ev_main = torch.cuda.Event()
-                ev_main.record(main)
-                self.side.wait_event(ev_main)
-                self._memorize(pend, self.side.cuda_stream, self.side)
-                ev_side = torch.cuda.Event()
-                ev_side.record(self.side)
-            else:
-                self._memorize(pend, stream)
-        pl.stats.zero_()
         pp = L.PreprocessParams()
         pp.a = a.data_ptr()
         if u8:
@@ -346,9 +340,43 @@ class HipEngine:
                           ("std_q", "trimap.model.Encoder_Q.std"), ("mean_m", "trimap.model.Encoder_M.mean"),
                           ("std_m", "trimap.model.Encoder_M.std")):
             setattr(pp, name, (C.c_float * 3)(*self._consts(key)))
+        # ---- the query encoder (STM.segment's Encoder_Q + KV_Q) needs nothing but the frame itself.  It runs on a side
+        # stream: next to Encoder_M of the previous frame (two chains of small launches that cannot fill 256 CUs on their
+        # own), and -- when the caller vouches that the frame is already in device memory (inputs_ready) and the host runs
+        # ahead of the device -- already under the previous frame's alpha network, which is still executing on the launch
+        # stream.  Its buffers (SQ, the q_ trunk, QK, M4[512:]) were last read by the previous frame's STM decoder (ev_dec).
+        use_side = self.prof is None and self.use_side_stream and not first_frame
+        ev_q = None
+        if use_side:
+            if self.side is None:
+                self.side = torch.cuda.Stream(device=dev)
+            side = self.side
+            if self.ev_dec is not None:
+                side.wait_event(self.ev_dec)
+            if isinstance(inputs_ready, torch.cuda.Event):
+                side.wait_event(inputs_ready)
+                main.wait_event(inputs_ready)
+            elif inputs_ready is not True:                   # unknown producer: everything issued so far on the launch stream
+                ev_in = torch.cuda.Event()
+                ev_in.record(main)
+                side.wait_event(ev_in)
+            pq = L.PreprocessParams.from_buffer_copy(pp)
+            pq.sq, pq.sq_ld = pl.SQ.ptr, pl.SQ.ld
+            L.check(lib.otvm_preprocess(C.byref(pq), side.cuda_stream), "preprocess (query encoder input)")
+            pl.run("segment_a", side.cuda_stream, side)
+            ev_q = torch.cuda.Event()
+            ev_q.record(side)
+        elif isinstance(inputs_ready, torch.cuda.Event):
+            main.wait_event(inputs_ready)
+        # ---- deferred memorize of the previous frame (reference order: memorize(t) ends frame t, alpha/model.py:461-493;
+        # here it opens frame t+1 on the launch stream, concurrently with the query encoder above)
+        if pend is not None:
+            self._memorize(pend, stream)
+        pl.stats.zero_()
         pp.scaled_imgs = scaled_imgs.data_ptr()
         pp.x11, pp.x11_ld = pl.X11.ptr, pl.X11.ld
-        pp.sq, pp.sq_ld = pl.SQ.ptr, pl.SQ.ld
+        if not use_side:
+            pp.sq, pp.sq_ld = pl.SQ.ptr, pl.SQ.ld
         smv = pl.SMs[par].ch(16, 8)
         pp.sm, pp.sm_ld = smv.ptr, smv.ld
         pp.d80, pp.d80_ld = pl.D80.ptr, pl.D80.ld
@@ -370,9 +398,10 @@ class HipEngine:
             L.check(lib.otvm_pad_trimap(tri_src.data_ptr(), H, W, pl.PROBS.data_ptr(), pl.Hp, pl.Wp, pl.lh, pl.lw, stream),
                     "pad_trimap")
         else:
-            pl.run("segment_a", stream)
-            if ev_side is not None:
-                main.wait_event(ev_side)
+            if ev_q is not None:
+                main.wait_event(ev_q)
+            else:
+                pl.run("segment_a", stream)
             if not self.bank:
                 raise RuntimeError("otvm_amd: non-first frame with an empty memory bank (call with first_frame=True first)")
             self.last_T_read = len(self.bank)
@@ -384,8 +413,8 @@ class HipEngine:
                 e1.record()
                 self.prof.append(("memory_read", 1280.0 * len(self.bank) * pl.hw * pl.hw, e0, e1, len(self.bank)))
             pl.run("segment_b", stream)
-        if first_frame and ev_side is not None:
-            main.wait_event(ev_side)
+            self.ev_dec = torch.cuda.Event()                  # the query encoder's buffers are free again
+            self.ev_dec.record(main)
         pl.encode(stream, cls_override)
         pl.run("fba", stream)
         pl.run("fba_tail%d" % par, stream)
@@ -487,9 +516,15 @@ class FramePlan:
             if sig not in _TUNE_CACHE:
                 n = int(self.lib.otvm_conv2d_candidates(C.byref(p), codes, 64))
                 cands = [0] + [int(codes[i]) for i in range(n)]           # 0 = the built-in heuristic, the incumbent
-                timed = [(c,) + self._time_conv(p, c, stream) for c in cands]
+                # the first timing of a layer runs on cold caches and ramping clocks (measured: the same kernel 14 % slower
+                # as first candidate than as second): a throw-away pass first, the incumbent timed again at the end
+                self._time_conv(p, 0, stream, reps=2)
+                timed = [(c,) + self._time_conv(p, c, stream) for c in cands + [0]]
                 torch.cuda.synchronize(self.dev)
-                ms = {c: e0.elapsed_time(e1) / r for c, e0, e1, r in timed}
+                ms = {}
+                for c, e0, e1, r in timed:
+                    t = e0.elapsed_time(e1) / r
+                    ms[c] = min(ms.get(c, t), t)
                 best = min(ms, key=ms.get)
                 if ms[best] > 0.97 * ms[0]:                                # keep the incumbent unless clearly beaten
                     best = 0
@@ -556,9 +591,10 @@ class FramePlan:
         S.append((self.lib.otvm_conv2d, (C.byref(p),), "conv " + wname, flops, abytes))
         return p
 
-    def gn(self, S, x, name, act, out=None, residual=None, conv_p=None):
+    def gn(self, S, x, name, act, out=None, residual=None, conv_p=None, res_norm=None):
         """GroupNorm(32) of the raw conv output ``x``.  With ``conv_p`` (the params of the conv that produced x)
-        the statistics are accumulated in that conv's epilogue and the separate stats pass is dropped."""
+        the statistics are accumulated in that conv's epilogue and the separate stats pass is dropped.
+        res_norm = (scale_ptr, shift_ptr, act): the residual is a raw GroupNorm input normalised on the fly."""
         out = x if out is None else out
         sd = self.e.sd
         idx = self.n_gn
@@ -569,8 +605,21 @@ class FramePlan:
             S.append(("gn_stats", (x.ptr, x.P, x.C, x.ld), idx, "gn_stats " + name))
         S.append(("gn_apply", (x.ptr, x.P, x.C, x.ld), idx,
                   (sd[name + ".weight"].data_ptr(), sd[name + ".bias"].data_ptr(),
-                   0 if residual is None else residual.ptr, 0 if residual is None else residual.ld, act,
-                   out.ptr, out.ld), "gn_apply " + name))
+                   0 if residual is None else residual.ptr, 0 if residual is None else residual.ld,
+                   0 if res_norm is None else res_norm[0], 0 if res_norm is None else res_norm[1],
+                   0 if res_norm is None else res_norm[2], act, out.ptr, out.ld), "gn_apply " + name))
+
+    def gn_table_step(self, S, x, gn_name, producer_p):
+        """Per-channel scale / shift of GroupNorm(gn_name) over the raw conv output ``x`` (statistics from the producing
+        conv's epilogue) for consumers that normalise on the fly instead of reading a normalised copy."""
+        sd = self.e.sd
+        idx = self.n_gn
+        self.n_gn += 1
+        self._fused_stats.append((producer_p, idx))
+        tab = self.raw("gntab_" + gn_name, 2 * x.C)
+        S.append(("gn_table", (x.P, x.C, sd[gn_name + ".weight"].data_ptr(), sd[gn_name + ".bias"].data_ptr(),
+                               tab.data_ptr(), tab.data_ptr() + 4 * x.C), idx, "gn_table " + gn_name))
+        return tab.data_ptr(), tab.data_ptr() + 4 * x.C
 
     def gn_then_conv(self, S, x, gn_name, gn_act, producer_p, wname, out, **kw):
         """GroupNorm(32) + activation of the raw conv output ``x`` whose ONLY consumer is the conv ``wname``.  When
@@ -582,13 +631,8 @@ class FramePlan:
             probe = conv_params(x, w, out, w.bias, kw.get("stride", 1), kw.get("pad", 0), kw.get("dil", 1), kw.get("act", NONE),
                                 0, kw.get("residual"), self.e.precision, (1, 1, gn_act))
             if self.lib.otvm_conv2d_accepts_input_norm(C.byref(probe)):
-                idx = self.n_gn
-                self.n_gn += 1
-                self._fused_stats.append((producer_p, idx))
-                tab = self.raw("gntab_" + gn_name, 2 * x.C)
-                S.append(("gn_table", (x.P, x.C, sd[gn_name + ".weight"].data_ptr(), sd[gn_name + ".bias"].data_ptr(),
-                                       tab.data_ptr(), tab.data_ptr() + 4 * x.C), idx, "gn_table " + gn_name))
-                return self.conv(S, x, wname, out, in_norm=(tab.data_ptr(), tab.data_ptr() + 4 * x.C, gn_act), **kw)
+                sc, sh = self.gn_table_step(S, x, gn_name, producer_p)
+                return self.conv(S, x, wname, out, in_norm=(sc, sh, gn_act), **kw)
         self.gn(S, x, gn_name, gn_act, conv_p=producer_p)
         return self.conv(S, x, wname, out, **kw)
 
@@ -608,10 +652,22 @@ class FramePlan:
                     _, a, idx, b, label = st
                     S[i] = (self.lib.otvm_gn_apply, a + (base + idx * 512,) + b, label)
 
-    def upsample(self, S, x, out, add=None):
+    def upsample(self, S, x, out, add=None, norm=None):
+        """norm = (scale_ptr, shift_ptr, act): x is a raw GroupNorm input, normalised per source pixel while resampling."""
         S.append((self.lib.otvm_upsample_bilinear,
-                  (x.ptr, x.H, x.W, x.C, x.ld, 0 if add is None else add.ptr, 0 if add is None else add.ld,
+                  (x.ptr, x.H, x.W, x.C, x.ld, 0 if norm is None else norm[0], 0 if norm is None else norm[1],
+                   0 if norm is None else norm[2], 0 if add is None else add.ptr, 0 if add is None else add.ld,
                    out.ptr, out.H, out.W, out.ld), "upsample"))
+
+    def gn_then_upsample(self, S, x, gn_name, gn_act, producer_p, out):
+        """GroupNorm + activation of the raw conv output ``x`` whose only consumer is a bilinear resampling: the apply
+        pass is folded into the resampling kernel (x stays raw, the normalised tensor is never written)."""
+        if FUSE_GN_APPLY and FUSE_GN_STATS and producer_p is not None:
+            sc, sh = self.gn_table_step(S, x, gn_name, producer_p)
+            self.upsample(S, x, out, norm=(sc, sh, gn_act))
+        else:
+            self.gn(S, x, gn_name, gn_act, conv_p=producer_p)
+            self.upsample(S, x, out)
 
     def maxpool(self, S, x, out):
         S.append((self.lib.otvm_maxpool3x3s2, (x.ptr, x.H, x.W, x.C, x.ld, out.ptr, out.ld), "maxpool"))
@@ -674,10 +730,10 @@ class FramePlan:
         H2, W2, H4, W4, H8, W8, H16, W16 = Hp // 2, Wp // 2, Hp // 4, Wp // 4, Hp // 8, Wp // 8, Hp // 16, Wp // 16
         self.hw = H16 * W16
 
-        # split-K workspaces: one for the launch stream, one for the memorize steps (they run on the side stream
-        # concurrently with the next frame's segment steps)
-        self.SPLITK_WS = [self.raw("splitk_ws0", 16 << 20), self.raw("splitk_ws1", 16 << 20)]
-        self._ws = self.SPLITK_WS[0]
+        # split-K workspaces, one per chain that may run concurrently with the others: [0] decoder + alpha network (launch
+        # stream), [1] memorize (launch stream, but tuned / timed separately), [2] query encoder (side stream)
+        self.SPLITK_WS = [self.raw("splitk_ws0", 16 << 20), self.raw("splitk_ws1", 16 << 20), self.raw("splitk_ws2", 16 << 20)]
+        self._ws = self.SPLITK_WS[2]
         # ---------------- frame-level buffers
         self.X11 = self.buf("X11", Hp, Wp, 12)          # 0-2 normalised RGB, 3-8 distance encoding, 9-10 soft, 11 zero
         self.SQ = self.buf("SQ", Hp, Wp, 4)             # Encoder_Q input (normalised RGB)
@@ -704,6 +760,7 @@ class FramePlan:
         self.conv(S, r4, "trimap.model.KV_Q_r4.Key", self.QK, pad=1)
         self.conv(S, r4, "trimap.model.KV_Q_r4.Value", self.M4.ch(512, 512), pad=1)
         self.steps["segment_a"] = S
+        self._ws = self.SPLITK_WS[0]
         S = []
         d = "trimap.model.Decoder."
         m = self.buf("d_m4a", H16, W16, 256)
@@ -765,24 +822,20 @@ class FramePlan:
             pin = Act(self.POOL, s, s, 2048, 2048, base * 2048)
             y = self.buf("ppm_y%d" % i, s, s, 256)
             cp = self.conv(S, pin, de + "ppm.%d.1" % i, y)
-            self.gn(S, y, de + "ppm.%d.2" % i, LEAKY, conv_p=cp)
-            self.upsample(S, y, self.PPMCAT.ch(2048 + 256 * i, 256))
+            self.gn_then_upsample(S, y, de + "ppm.%d.2" % i, LEAKY, cp, self.PPMCAT.ch(2048 + 256 * i, 256))
             base += s * s
         u1 = self.buf("u1a", H8, W8, 256)
         cp = self.conv(S, self.PPMCAT, de + "conv_up1.0", u1, pad=1)
         self.gn(S, u1, de + "conv_up1.1", LEAKY, conv_p=cp)
         u1b = self.buf("u1b", H8, W8, 256)
         cp = self.conv(S, u1, de + "conv_up1.3", u1b, pad=1)
-        self.gn(S, u1b, de + "conv_up1.4", LEAKY, conv_p=cp)
-        self.upsample(S, u1b, self.U2.ch(0, 256))
+        self.gn_then_upsample(S, u1b, de + "conv_up1.4", LEAKY, cp, self.U2.ch(0, 256))
         u2 = self.buf("u2", H4, W4, 256)
         cp = self.conv(S, self.U2, de + "conv_up2.0", u2, pad=1)
-        self.gn(S, u2, de + "conv_up2.1", LEAKY, conv_p=cp)
-        self.upsample(S, u2, self.U3.ch(0, 256))
+        self.gn_then_upsample(S, u2, de + "conv_up2.1", LEAKY, cp, self.U3.ch(0, 256))
         u3 = self.buf("u3", H2, W2, 64)
         cp = self.conv(S, self.U3, de + "conv_up3.0", u3, pad=1)
-        self.gn(S, u3, de + "conv_up3.1", LEAKY, conv_p=cp)
-        self.upsample(S, u3, self.D80.ch(0, 64))
+        self.gn_then_upsample(S, u3, de + "conv_up3.1", LEAKY, cp, self.D80.ch(0, 64))
         h32 = self.buf("h32", Hp, Wp, 32)
         self.conv(S, self.D80, de + "conv_up4.0", h32, pad=1, act=LEAKY)      # ch 72.. carry zero weights
         hid_d = self.buf("hid_d", Hp, Wp, 16)
@@ -795,16 +848,24 @@ class FramePlan:
         rf = "NET.refine."
         r0 = self.buf("r0", Hp, Wp, 64)
         cp = self.conv(S, self.D80, rf + "conv1.0", r0, pad=1)
-        self.gn(S, r0, rf + "conv1.1", LEAKY, conv_p=cp)
-        x = r0
+        # conv1's GroupNorm + LeakyReLU is read twice, by layer1.conv1 (a patch conv: normalises while staging) and as the
+        # residual of layer1.bn2's apply pass (normalises on the fly): the normalised 535 MB tensor is never written
+        x, x_norm = r0, None
+        w1 = e.W[rf + "layer1.conv1"]
+        t1 = self.buf("rt1", Hp, Wp, 64)
+        probe = conv_params(r0, w1, t1, w1.bias, 1, 1, 1, NONE, 0, None, e.precision, (1, 1, LEAKY))
+        if FUSE_GN_APPLY and FUSE_GN_STATS and lib.otvm_conv2d_accepts_input_norm(C.byref(probe)):
+            sc, sh = self.gn_table_step(S, r0, rf + "conv1.1", cp)
+            x_norm = (sc, sh, LEAKY)
+        else:
+            self.gn(S, r0, rf + "conv1.1", LEAKY, conv_p=cp)
         for l in ("layer1", "layer2"):
-            t1 = self.buf("rt1", Hp, Wp, 64)
-            cp = self.conv(S, x, rf + l + ".conv1", t1, pad=1)
+            cp = self.conv(S, x, rf + l + ".conv1", t1, pad=1, in_norm=x_norm)
             t2 = self.buf("rt2", Hp, Wp, 64)
             cp = self.gn_then_conv(S, t1, rf + l + ".bn1", RELU, cp, rf + l + ".conv2", t2, pad=1)
             o = self.buf("r_" + l, Hp, Wp, 64)
-            self.gn(S, t2, rf + l + ".bn2", RELU, out=o, residual=x, conv_p=cp)
-            x = o
+            self.gn(S, t2, rf + l + ".bn2", RELU, out=o, residual=x, conv_p=cp, res_norm=x_norm)
+            x, x_norm = o, None
         self.conv(S, x, rf + "pred.0", h32, pad=1, act=LEAKY)
         self.steps["fba"] = S
         for par in (0, 1):

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3 = 0, 1
-ABI_VERSION = 6          # include/otvm_hip.h OTVM_ABI_VERSION
+ABI_VERSION = 7          # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -44,6 +44,8 @@ _PROTOS = {
     "otvm_abi_version": (i32, []),
     "otvm_patch_weight_bytes_f16x3": (i64, [i32, i32]),
     "otvm_pack_patch_weight_f16x3": (i32, [vp, i32, i32, i32, vp, vp, vp]),
+    "otvm_stem_weight_bytes_f16x3": (i64, [i32]),
+    "otvm_pack_stem_weight_f16x3": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "otvm_fold_bn": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp]),
     "otvm_pack_conv_weight": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp]),
     "otvm_conv2d": (i32, [C.POINTER(ConvParams), vp]),
@@ -52,9 +54,9 @@ _PROTOS = {
     "otvm_gn_table": (i32, [vp, i64, i32, vp, vp, vp, vp, vp]),
     "otvm_conv2d_accepts_input_norm": (i32, [C.POINTER(ConvParams)]),
     "otvm_conv2d_candidates": (i32, [C.POINTER(ConvParams), C.POINTER(i32), i32]),
-    "otvm_gn_apply": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i32, i32, vp, i32, vp]),
+    "otvm_gn_apply": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, i32, vp]),
     "otvm_maxpool3x3s2": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
-    "otvm_upsample_bilinear": (i32, [vp, i32, i32, i32, i32, vp, i32, vp, i32, i32, i32, vp]),
+    "otvm_upsample_bilinear": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp]),
     "otvm_ppm_pool_ws_bytes": (i64, [i32, i32]),
     "otvm_ppm_pool": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "otvm_memory_read_ws_bytes": (i64, [i32, i32]),

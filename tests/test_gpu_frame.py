@@ -375,3 +375,47 @@ def test_autotuned_plan_matches_heuristic_plan(synth_sd):
     c = matte(False)
     assert torch.equal(a["alpha"], b["alpha"]) and torch.equal(a["trimap"], b["trimap"])
     assert float((a["alpha"] - c["alpha"]).abs().max()) <= 1e-3
+
+
+def test_early_query_encoder_is_hazard_free(synth_sd):
+    """With device-resident frames (``_inputs_ready=True``) the query encoder of frame t+1 is issued on a side stream and
+    may run while frame t's alpha network still executes (otvm_amd/engine.py).  Its buffers are guarded by events: a clip
+    matted with the host running far ahead of the device must be bit-identical to the same clip matted with a device
+    synchronisation after every frame, and to the conservative ordering (``_inputs_ready=None``).  Large enough frames
+    that a frame takes several milliseconds, so the host really is ahead."""
+    from otvm_amd import helpers
+    from otvm_amd.synth_data import synthetic_clip
+    from otvm_amd.video import memory_schedule
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    cfg = helpers.default_cfg()
+    H, W, T = 480, 832, 12
+    frames, tri = synthetic_clip(H, W, T, seed=91)
+    dev = torch.device("cuda:0")
+    fr = [torch.from_numpy(frames[t]).to(dev) for t in range(T)]            # uint8 [H,W,3], resident
+    tri_d = torch.from_numpy(tri)[None, None].to(dev)
+    ones = torch.ones(1, 1, 1, H, W, device=dev)
+    torch.cuda.synchronize()
+
+    def matte(ready, sync):
+        m = helpers.get_model_alpha(cfg, helpers.get_model_trimap(cfg, "Test", 12), "Test", 12)
+        m.load_state_dict(synth_sd, strict=True)
+        m = m.cuda().eval()
+        outs = []
+        for t in range(T):
+            memorize, mx, large = memory_schedule(t, H, W, 3, 3)
+            o = m(ones, fr[t], fr[t], tri_gt=tri_d, first_frame=(t == 0), last_frame=(t == T - 1), memorize=memorize,
+                  max_memory_num=mx, large_input=large, _inputs_ready=ready)
+            outs.append((o[3], o[1]))
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return torch.stack([a for a, _ in outs]), torch.stack([b for _, b in outs])
+    ref = matte(None, True)
+    for ready, sync in ((True, False), (None, False), (True, True)):
+        got = matte(ready, sync)
+        assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]), (ready, sync)
+    ev = torch.cuda.Event()
+    ev.record()
+    got = matte(ev, False)
+    assert torch.equal(got[0], ref[0])

@@ -212,7 +212,7 @@ def test_conv_fused_input_groupnorm(G, Cin, Cout, dil, H, W, act):
     assert G.maxdiff(got, ref) <= 3e-5 * max(1.0, float(ref.abs().max()))
     # bit-identical to the two-pass route (same table arithmetic, same staging)
     xa2 = G.to_act(x)
-    L.check(lib.otvm_gn_apply(xa2.ptr, H * W, Cin, xa2.ld, stats.data_ptr(), g_d.data_ptr(), b_d.data_ptr(), 0, 0, act,
+    L.check(lib.otvm_gn_apply(xa2.ptr, H * W, Cin, xa2.ld, stats.data_ptr(), g_d.data_ptr(), b_d.data_ptr(), 0, 0, 0, 0, 0, act,
                               xa2.ptr, xa2.ld, G.stream()))
     out2 = G.empty_act(H, W, max(4, Cout))
     G.conv2d(xa2, cw, out2, bias_d, pad=dil, dil=dil, precision=1)
@@ -270,7 +270,8 @@ def test_weight_standardisation_and_bn_fold(G):
 
 @pytest.mark.parametrize("Cc,H,W,act,use_res", [(64, 33, 47, 1, False), (128, 16, 20, 2, False), (256, 9, 11, 1, True),
                                                 (2048, 5, 7, 0, False), (1024, 6, 6, 1, True), (256, 1, 1, 2, False),
-                                                (256, 2, 2, 2, False), (64, 128, 160, 2, True)])
+                                                (256, 2, 2, 2, False), (64, 128, 160, 2, True),
+                                                (64, 300, 400, 1, True)])            # > 4096 blocks: the grid-stride loop
 def test_groupnorm(G, Cc, H, W, act, use_res):
     from otvm_amd import lib as L
     lib = L.load()
@@ -288,9 +289,27 @@ def test_groupnorm(G, Cc, H, W, act, use_res):
     gd, bd = gamma.to(G.DEV), beta.to(G.DEV)
     L.check(lib.otvm_gn_stats(xa.ptr, H * W, Cc, xa.ld, stats.data_ptr(), G.stream()))
     L.check(lib.otvm_gn_apply(xa.ptr, H * W, Cc, xa.ld, stats.data_ptr(), gd.data_ptr(), bd.data_ptr(),
-                              0 if ra is None else ra.ptr, 0 if ra is None else ra.ld, act, out.ptr, out.ld, G.stream()))
+                              0 if ra is None else ra.ptr, 0 if ra is None else ra.ld, 0, 0, 0, act, out.ptr, out.ld, G.stream()))
     torch.cuda.synchronize()
     assert G.maxdiff(G.from_act(out), ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    if use_res:
+        # the residual is itself a raw GroupNorm input whose apply pass is folded in (res_scale / res_shift / res_act):
+        # out = act(GN(x) + leaky(GN_r(r))), as the refinement's first BasicBlock reads the un-normalised conv1 output
+        g2, b2 = rnd(Cc, seed=15) + 1, rnd(Cc, seed=16)
+        rn = F.leaky_relu(F.group_norm(res, 32, g2, b2, 1e-5), 0.01)
+        ref2 = F.group_norm(x, 32, gamma, beta, 1e-5) + rn
+        ref2 = F.relu(ref2) if act == 1 else (F.leaky_relu(ref2, 0.01) if act == 2 else ref2)
+        st2 = torch.zeros(64, dtype=torch.float64, device=G.DEV)
+        g2d, b2d = g2.to(G.DEV), b2.to(G.DEV)
+        tab = torch.zeros(2 * Cc, device=G.DEV)
+        L.check(lib.otvm_gn_stats(ra.ptr, H * W, Cc, ra.ld, st2.data_ptr(), G.stream()))
+        L.check(lib.otvm_gn_table(st2.data_ptr(), H * W, Cc, g2d.data_ptr(), b2d.data_ptr(), tab.data_ptr(), tab.data_ptr() + 4 * Cc,
+                                  G.stream()))
+        out.t.fill_(float("nan"))
+        L.check(lib.otvm_gn_apply(xa.ptr, H * W, Cc, xa.ld, stats.data_ptr(), gd.data_ptr(), bd.data_ptr(), ra.ptr, ra.ld,
+                                  tab.data_ptr(), tab.data_ptr() + 4 * Cc, 2, act, out.ptr, out.ld, G.stream()))
+        torch.cuda.synchronize()
+        assert G.maxdiff(G.from_act(out), ref2) <= 2e-5 * max(1.0, float(ref2.abs().max()))
 
 
 def test_maxpool_upsample_ppm(G):
@@ -306,15 +325,28 @@ def test_maxpool_upsample_ppm(G):
     add = rnd(1, 64, 68, 100, seed=16)
     out = G.empty_act(68, 100, 64, ld=80, off=8)
     aa = G.to_act(add)
-    L.check(lib.otvm_upsample_bilinear(xa.ptr, 34, 50, 64, xa.ld, aa.ptr, aa.ld, out.ptr, 68, 100, out.ld, G.stream()))
+    L.check(lib.otvm_upsample_bilinear(xa.ptr, 34, 50, 64, xa.ld, 0, 0, 0, aa.ptr, aa.ld, out.ptr, 68, 100, out.ld, G.stream()))
     torch.cuda.synchronize()
     ref = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False) + add
     assert G.maxdiff(G.from_act(out), ref) <= 1e-5
+    # GroupNorm apply + LeakyReLU folded into the resampling (FBA decoder: GN, LeakyReLU, then x2 upsample)
+    gam, bet = rnd(64, seed=18) + 1, rnd(64, seed=19)
+    gd, bd = gam.to(G.DEV), bet.to(G.DEV)
+    st = torch.zeros(64, dtype=torch.float64, device=G.DEV)
+    tab = torch.zeros(128, device=G.DEV)
+    L.check(lib.otvm_gn_stats(xa.ptr, 34 * 50, 64, xa.ld, st.data_ptr(), G.stream()))
+    L.check(lib.otvm_gn_table(st.data_ptr(), 34 * 50, 64, gd.data_ptr(), bd.data_ptr(), tab.data_ptr(), tab.data_ptr() + 256, G.stream()))
+    out.t.fill_(float("nan"))
+    L.check(lib.otvm_upsample_bilinear(xa.ptr, 34, 50, 64, xa.ld, tab.data_ptr(), tab.data_ptr() + 256, 2, 0, 0, out.ptr, 68, 100,
+                                       out.ld, G.stream()))
+    torch.cuda.synchronize()
+    refn = F.interpolate(F.leaky_relu(F.group_norm(x, 32, gam, bet, 1e-5), 0.01), scale_factor=2, mode="bilinear", align_corners=False)
+    assert G.maxdiff(G.from_act(out), refn) <= 2e-5 * max(1.0, float(refn.abs().max()))
     for s in (1, 2, 3, 6):
         y = rnd(1, 256, s, s, seed=17 + s)
         ya = G.to_act(y)
         out = G.empty_act(17, 30, 256)
-        L.check(lib.otvm_upsample_bilinear(ya.ptr, s, s, 256, ya.ld, 0, 0, out.ptr, 17, 30, out.ld, G.stream()))
+        L.check(lib.otvm_upsample_bilinear(ya.ptr, s, s, 256, ya.ld, 0, 0, 0, 0, 0, out.ptr, 17, 30, out.ld, G.stream()))
         torch.cuda.synchronize()
         ref = F.interpolate(y, size=(17, 30), mode="bilinear", align_corners=False)
         assert G.maxdiff(G.from_act(out), ref) <= 1e-5
@@ -605,7 +637,7 @@ def test_reference_vectors_ws_conv_groupnorm(G):
         G.conv2d(xa, cw, raw, bias=torch.from_numpy(ops["ws_b"]).to(G.DEV), pad=2, dil=2, precision=prec, gn_stats=stats)
         gam, bet = torch.from_numpy(ops["ws_g"]).to(G.DEV), torch.from_numpy(ops["ws_be"]).to(G.DEV)
         out = G.empty_act(H, W, Cout)
-        L.check(lib.otvm_gn_apply(raw.ptr, H * W, Cout, raw.ld, stats.data_ptr(), gam.data_ptr(), bet.data_ptr(), 0, 0, 0,
+        L.check(lib.otvm_gn_apply(raw.ptr, H * W, Cout, raw.ld, stats.data_ptr(), gam.data_ptr(), bet.data_ptr(), 0, 0, 0, 0, 0, 0,
                                   out.ptr, out.ld, G.stream()))
         torch.cuda.synchronize()
         assert G.maxdiff(G.from_act(out), ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
@@ -639,8 +671,11 @@ def test_reference_vectors_fba_fusion(G):
     (1024, 512, 3, 1, 1, 17, 30, False, 0, False),      # deep, small map: the shape class the tuner moves to 256x256 / S
     (2048, 256, 1, 1, 1, 6, 6, False, 0, True),         # PPM 1x1 with fused GroupNorm sums: split-K + statistics pass
     (64, 64, 3, 1, 1, 33, 47, False, 2, False),         # narrow output: patch, 256x64, 128x64, 64x64
+    (64, 32, 3, 1, 1, 37, 70, True, 1, False),          # 32 channels, ragged 8-row / 32-column blocks
+    (80, 64, 3, 1, 1, 50, 33, False, 0, True),          # 80 input channels (5 stages), fused GroupNorm sums on the patch kernel
     (128, 128, 3, 2, 1, 34, 50, False, 1, False),       # strided 3x3
-    (24, 64, 7, 2, 1, 40, 64, False, 1, False),         # stem: generic K decode on every tile it may use
+    (24, 64, 7, 2, 1, 40, 64, False, 1, False),         # stem: the 7x7 stem kernel and the generic K decode on every tile
+    (12, 64, 7, 2, 1, 37, 51, False, 0, True),          # FBA stem: odd sizes, fused GroupNorm sums
 ])
 def test_conv_every_tunable_configuration(G, Cin, Cout, k, stride, dil, H, W, use_res, act, gn):
     """otvm_conv2d_candidates / otvm_conv_params.tune: every configuration the plan-time autotuner may pick for a layer

@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--gn", type=int, default=0, help="fused GroupNorm statistics in the epilogue")
     ap.add_argument("--bias", type=int, default=0)
+    ap.add_argument("--tune", default="0", help="otvm_conv_params.tune codes to time, comma separated; 'all' = every candidate")
     args = ap.parse_args()
     shapes = [tuple(int(v) for v in s.split(",")) for s in args.shape] if args.shape else DEFAULT
     lib = L.load()
@@ -54,18 +55,31 @@ def main():
         stats = torch.zeros(64, dtype=torch.float64, device=dev)
         if args.gn:
             p.gn_stats = stats.data_ptr()
-        for _ in range(3):
-            L.check(lib.otvm_conv2d(C.byref(p), st))
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(args.iters):
-            L.check(lib.otvm_conv2d(C.byref(p), st))
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / args.iters
-        fl = 2.0 * Ho * Wo * Cout * k * k * Cin
-        print("Cin %4d Cout %4d k%d s%d d%d %4dx%-4d : %7.3f ms  %7.1f TFLOP/s" % (Cin, Cout, k, stride, dil, H, W, ms, fl / ms / 1e9))
+        ws = torch.empty(16 << 20, device=dev)
+        p.splitk_ws, p.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
+        if args.tune == "all":
+            codes = (C.c_int * 64)()
+            n = int(lib.otvm_conv2d_candidates(C.byref(p), codes, 64))
+            tunes = [0] + [int(codes[i]) for i in range(n)]
+        else:
+            tunes = [int(v) for v in args.tune.split(",")]
+        names = {0: "256x256", 1: "256x128", 2: "128x128", 3: "128x64", 4: "64x64", 5: "256x64", 6: "256x32", 12: "stem", 14: "patch"}
+        for tune in tunes:
+            p.tune = tune
+            for _ in range(3):
+                L.check(lib.otvm_conv2d(C.byref(p), st))
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                L.check(lib.otvm_conv2d(C.byref(p), st))
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / args.iters
+            fl = 2.0 * Ho * Wo * Cout * k * k * Cin
+            label = "heuristic" if tune == 0 else "%s/S%d" % (names.get(tune // 16 - 1, "?"), tune & 15)
+            print("Cin %4d Cout %4d k%d s%d d%d %4dx%-4d %-14s: %7.3f ms  %7.1f TFLOP/s" %
+                  (Cin, Cout, k, stride, dil, H, W, label, ms, fl / ms / 1e9))
 
 
 if __name__ == "__main__":

@@ -59,7 +59,7 @@ def main():
         stats = torch.zeros(64, dtype=torch.float64, device=G.DEV)
         L.check(lib.otvm_gn_stats(xa.ptr, H * W, Cc, xa.ld, stats.data_ptr(), st))
         L.check(lib.otvm_gn_apply(xa.ptr, H * W, Cc, xa.ld, stats.data_ptr(), gd.data_ptr(), bd.data_ptr(),
-                                  0 if ra is None else ra.ptr, 0 if ra is None else ra.ld, act, out.ptr, out.ld, st))
+                                  0 if ra is None else ra.ptr, 0 if ra is None else ra.ld, 0, 0, 0, act, out.ptr, out.ld, st))
         torch.cuda.synchronize()
         worst["gn"] = max(worst.get("gn", 0), check("groupnorm", G.from_act(out), ref, 3e-5, "C%d %dx%d act%d res%d" % (Cc, H, W, act, use_res)))
         # ---- upsample (+ add)
@@ -73,7 +73,7 @@ def main():
             refu = refu + add
         xua, oua = G.to_act(xu), G.empty_act(ho, wo, Cu)
         aa = G.to_act(add) if add is not None else None
-        L.check(lib.otvm_upsample_bilinear(xua.ptr, hi, wi, Cu, xua.ld, 0 if aa is None else aa.ptr, 0 if aa is None else aa.ld,
+        L.check(lib.otvm_upsample_bilinear(xua.ptr, hi, wi, Cu, xua.ld, 0, 0, 0, 0 if aa is None else aa.ptr, 0 if aa is None else aa.ld,
                                            oua.ptr, ho, wo, oua.ld, st))
         torch.cuda.synchronize()
         worst["up"] = max(worst.get("up", 0), check("upsample", G.from_act(oua), refu, 1e-5, "C%d %dx%d->%dx%d" % (Cu, hi, wi, ho, wo)))
