@@ -39,6 +39,25 @@ USE_GRAPHS = os.environ.get("OTVM_GRAPHS", "0") != "0"
 AUTOTUNE = os.environ.get("OTVM_AUTOTUNE", "1") != "0"
 _TUNE_CACHE = {}
 TUNE_LOG = []           # (signature, chosen code, {code: ms}) of every shape timed in this process (tools / DESIGN numbers)
+# OTVM_TUNE_FILE=path: choices are loaded from / saved to a JSON file, so a later process (a profiler run, a service
+# restart) launches the tuned configurations without timing anything.
+TUNE_FILE = os.environ.get("OTVM_TUNE_FILE")
+
+
+def _load_tune_file():
+    if TUNE_FILE and os.path.exists(TUNE_FILE):
+        import json
+        for k, v in json.load(open(TUNE_FILE)).items():
+            _TUNE_CACHE[tuple(json.loads(k))] = int(v)
+
+
+def _save_tune_file():
+    if TUNE_FILE:
+        import json
+        json.dump({json.dumps([int(x) for x in k]): v for k, v in _TUNE_CACHE.items()}, open(TUNE_FILE, "w"), indent=0)
+
+
+_load_tune_file()
 
 
 def _rup(x, m):
@@ -360,6 +379,8 @@ class HipEngine:
                 ev_in = torch.cuda.Event()
                 ev_in.record(main)
                 side.wait_event(ev_in)
+            for t_ in (a, fg, bg):                           # read on the side stream too: keep the allocator from reusing them early
+                t_.record_stream(side)
             pq = L.PreprocessParams.from_buffer_copy(pp)
             pq.sq, pq.sq_ld = pl.SQ.ptr, pl.SQ.ld
             L.check(lib.otvm_preprocess(C.byref(pq), side.cuda_stream), "preprocess (query encoder input)")
@@ -491,8 +512,8 @@ class FramePlan:
     # ---- plan-time autotuning (see AUTOTUNE above)
     @staticmethod
     def _signature(p):
-        return (p.H, p.W, p.Cin, p.in_ld, p.Cout, p.out_ld, p.kh, p.kw, p.stride, p.pad, p.dil, p.in_relu, p.act, bool(p.bias),
-                bool(p.residual), p.res_ld, bool(p.gn_stats), bool(p.in_scale), bool(p.splitk_ws), p.precision)
+        return (p.H, p.W, p.Cin, p.in_ld, p.Cout, p.out_ld, p.kh, p.kw, p.stride, p.pad, p.dil, p.in_relu, p.act, int(bool(p.bias)),
+                int(bool(p.residual)), p.res_ld, int(bool(p.gn_stats)), int(bool(p.in_scale)), int(bool(p.splitk_ws)), p.precision)
 
     def _time_conv(self, p, code, stream, reps=3):
         p.tune = code
@@ -511,6 +532,7 @@ class FramePlan:
             return
         stream = torch.cuda.current_stream(self.dev).cuda_stream
         codes = (C.c_int * 64)()
+        timed_any = False
         for p, name in convs:
             sig = self._signature(p)
             if sig not in _TUNE_CACHE:
@@ -530,7 +552,10 @@ class FramePlan:
                     best = 0
                 _TUNE_CACHE[sig] = best
                 TUNE_LOG.append((name, sig, best, ms))
+                timed_any = True
             p.tune = _TUNE_CACHE[sig]
+        if timed_any:
+            _save_tune_file()
 
     def autotune(self):
         if not (AUTOTUNE and self.e.precision == L.PREC_F16X3):
@@ -971,8 +996,10 @@ class FramePlan:
     def kv_into_slot(self, slot, stream):
         if "kv_steps" not in slot:
             S = []
+            n0 = len(self._convs)
             self.conv(S, self.r4m, "trimap.model.KV_M_r4.Key", slot["k"], pad=1)
             self.conv(S, self.r4m, "trimap.model.KV_M_r4.Value", slot["v"], pad=1)
+            self.tune_convs(self._convs[n0:])                  # shapes timed at plan time (autotune): cache hits
             slot["kv_steps"] = S
         prof = self.e.prof
         for st in slot["kv_steps"]:

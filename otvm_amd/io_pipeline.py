@@ -62,8 +62,11 @@ class FramePrefetcher:
                 d = host.to(self.dev, non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record(self.copy_stream)
-            torch.cuda.current_stream(self.dev).wait_event(ev)
+            # the consumer waits for the upload itself (run_video_matte hands the event to the model as _inputs_ready:
+            # launch stream and query-encoder stream both wait on it, and the query encoder of this frame may start under
+            # the previous frame's alpha network instead of behind it)
             d.record_stream(torch.cuda.current_stream(self.dev))
+            d._otvm_ready = ev
             yield d
 
     def close(self):

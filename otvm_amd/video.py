@@ -83,10 +83,13 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
         if f.dtype == torch.uint8 and (b is None or b.dtype == torch.uint8):
             # decoded images go to the device as they are ([H,W,3] uint8): the preprocess kernel converts, flips the
             # channel order and composites -- no per-frame torch conversion / transposition kernels
+            ready = getattr(f, "_otvm_ready", None)           # upload event of the IO pipeline's prefetcher
             fg = f.to(dev, non_blocking=True)
             bg = fg if b is None else b.to(dev, non_blocking=True)
             H, W = fg.shape[:2]
             extra["_frames_rgb"] = bool(frames_are_rgb)
+            if ready is not None and b is None and fg is f:
+                extra["_inputs_ready"] = ready
         else:
             f = f.to(dev).float()
             if frames_are_rgb:
