@@ -35,10 +35,11 @@ extern "C" {
 #define OTVM_PREC_F16X3 1
 
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 7    /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
+#define OTVM_ABI_VERSION 8    /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
                                  4: otvm_conv_params.splitk_ws; 5: otvm_preprocess_params.fg_u8/bg_u8/u8_rgb;
                                  6: otvm_conv_params.tune + otvm_conv2d_candidates;
-                                 7: folded GroupNorm tables on otvm_gn_apply's residual and otvm_upsample_bilinear's input */
+                                 7: folded GroupNorm tables on otvm_gn_apply's residual and otvm_upsample_bilinear's input;
+                                 8: otvm_memory_read_f16x3_partial / _combine / _partial_count */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -175,6 +176,17 @@ int64_t otvm_bank_slot_bytes_f16x3(int hw);
 int otvm_bank_pack_f16x3(const float* key, const float* val, int hw, void* slot, void* stream);
 int otvm_memory_read_f16x3(const float* q_key, int q_ld, const void* const* slots, int T, int hw, float* out,
                            int out_ld, void* ws, void* stream);
+
+/* The same read in two steps, for a caller that knows part of the bank earlier than the rest (the engine reads the slots
+ * that are already resident on a side stream, under the previous frame's alpha network, and only the slot of the frame
+ * just memorised on the critical path): the softmax over the memory axis is merged from per-chunk partials (running
+ * max, sum, weighted value sum), so the bank may be visited in any grouping.  A workspace laid out for np_cap partials
+ * holds np_cap * hw * (512 + 2) floats; a group of n slots writes otvm_memory_read_f16x3_partial_count(n, hw) partials
+ * starting at part0 (*part_end = one past its last); combine merges partials [0, n_partials) into out.             */
+int otvm_memory_read_f16x3_partial_count(int n_slots, int hw);
+int otvm_memory_read_f16x3_partial(const float* q_key, int q_ld, const void* const* slots, int n_slots, int hw, void* ws,
+                                   int np_cap, int part0, int* part_end, void* stream);
+int otvm_memory_read_f16x3_combine(const void* ws, int np_cap, int n_partials, int hw, float* out, int out_ld, void* stream);
 
 /* ---------------------------------------------------------------- frame glue --------------------
  * preprocess: alpha/model.py:380-389,408-414 + STM.py:53-57,89-93.  fg,bg: [3,H,W] fp32 BGR 0..255

@@ -62,7 +62,9 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
 // FAST: Cin % 32 == 0 and <= 32 taps -> a K chunk never straddles a tap, so the tap walk is wave-uniform
 // (scalar registers) and the per-row work per chunk shrinks to one add and one mask test.
 template <int BM, int BN, int WM, int WN, bool FAST, bool RELU_IN>
-__global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Conv3Args p) {
+__global__ __launch_bounds__(WM* WN * 64)
+__attribute__((amdgpu_waves_per_eu((BM * BN == 32768 && WM * WN == 4) ? 2 : 1, (BM * BN == 32768 && WM * WN == 4) ? 2 : 10)))
+void conv_igemm_f16x3_kernel(const Conv3Args p) {
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_ROWS = NT / 8, A_LD = BM / A_ROWS;        // 8 float4 per 32-wide row
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(WM* WN * 64) void conv_igemm_f16x3_kernel(const Con
     constexpr int STAGE = 2 * (BM + BN) * LDH;                 // halfs per LDS stage (A_hi, A_lo, B_hi, B_lo)
     // Two LDS stages + one barrier per chunk on the 256-row tiles (+5..14 % on the layers that use them; the smaller
     // tiles lose more from the halved occupancy than they gain: 32.7 vs 33.1 frames/s with DBUF everywhere).
-    constexpr bool DBUF = BM == 256 && BN >= 128;
+    constexpr bool DBUF = BM == 256 && BN >= 128 && WM * WN == 8;   // (the 4-wave 256x128 / 128x256 tiles: one stage, two workgroups per CU)
     __shared__ __attribute__((aligned(16))) _Float16 smem[(DBUF ? 2 : 1) * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -485,10 +487,10 @@ int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream);    //
 // tile shared by S workgroups (S > 1: partial tiles through the caller's workspace, added in a fixed order by
 // splitk_finish_kernel), or the 3x3 patch kernel.  otvm_conv_params.tune forces one (the host's plan-time autotuner,
 // otvm_amd/engine.py, times the candidates of otvm_conv2d_candidates on the device); 0 = the heuristic below.
-enum { T256x256 = 0, T256x128, T128x128, T128x64, T64x64, T256x64, T256x32, T_COUNT, T_STEM = 12, T_PATCH = 14 };
+enum { T256x256 = 0, T256x128, T128x128, T128x64, T64x64, T256x64, T256x32, T256x128W4, T128x256W4, T_COUNT, T_STEM = 12, T_PATCH = 14 };
 static inline int tune_code(int tile, int S) { return (tile + 1) * 16 + S; }
-static const int TILE_BM[T_COUNT] = {256, 256, 128, 128, 64, 256, 256};
-static const int TILE_BN[T_COUNT] = {256, 128, 128, 64, 64, 64, 32};
+static const int TILE_BM[T_COUNT] = {256, 256, 128, 128, 64, 256, 256, 256, 128};
+static const int TILE_BN[T_COUNT] = {256, 128, 128, 64, 64, 64, 32, 128, 256};
 
 static int launch_tile(int tile, Conv3Args& a, hipStream_t s, int S) {
     switch (tile) {
@@ -499,6 +501,10 @@ static int launch_tile(int tile, Conv3Args& a, hipStream_t s, int S) {
         case T64x64: return launch3<64, 64, 2, 2>(a, s, S);
         case T256x64: return launch3<256, 64, 4, 1>(a, s, S);
         case T256x32: return launch3<256, 32, 4, 1>(a, s, S);
+        // 4-wave workgroups with a single LDS stage (61 KB): two per CU, so one workgroup's epilogue (output stores,
+        // GroupNorm sums) overlaps the other's main loop -- candidates for the short-K, output-heavy 1x1 layers
+        case T256x128W4: return launch3<256, 128, 2, 2>(a, s, S);
+        case T128x256W4: return launch3<128, 256, 2, 2>(a, s, S);
     }
     otvm_set_error("otvm_conv2d(f16x3): unknown tile %d", tile);
     return 1;
@@ -512,6 +518,9 @@ static bool config_ok(const otvm_conv_params* p, int tile, int S) {
     // used when that is a multiple of 256, or its last tile would read rows past the allocation
     if (TILE_BN[tile] == 256 && !(p->Cout >= 256 && (otvm_ceil_div(p->Cout, 128) & 1) == 0)) return false;
     if (p->in_scale) return false;                                  // fused input normalisation: patch kernel only
+    // the 4-wave big tiles hold 128 accumulator registers per lane: only their wave-uniform-tap-walk variants fit two
+    // waves per SIMD without spilling
+    if ((tile == T256x128W4 || tile == T128x256W4) && !f16x3_fast_layout(p->kh * p->kw, p->Cin)) return false;
     if (S > 1) {
         const int nchunks = p->K_pad / 32;
         const int ldp = (p->Cout + 3) & ~3;
@@ -554,11 +563,11 @@ extern "C" int otvm_conv2d_candidates(const otvm_conv_params* p, int* out, int m
     if (p->in_scale) return n;
     const int64_t M = (int64_t)p->Ho * p->Wo;
     const int nchunks = p->K_pad / 32;
-    static const int tiles_wide[] = {T256x256, T256x128, T128x128, T128x64, T64x64};
+    static const int tiles_wide[] = {T256x256, T256x128, T128x128, T128x64, T64x64, T256x128W4, T128x256W4};
     static const int tiles_64[] = {T256x64, T128x64, T64x64};
     static const int tiles_32[] = {T256x32, T64x64};
     const int* tl = p->Cout <= 32 ? tiles_32 : (p->Cout <= 64 ? tiles_64 : tiles_wide);
-    const int ntl = p->Cout <= 32 ? 2 : (p->Cout <= 64 ? 3 : 5);
+    const int ntl = p->Cout <= 32 ? 2 : (p->Cout <= 64 ? 3 : 7);
     static const int splits[] = {1, 2, 3, 4, 6, 8};
     for (int i = 0; i < ntl; ++i) {
         const int t = tl[i];

@@ -312,23 +312,19 @@ extern "C" int otvm_bank_pack_f16x3(const float* key, const float* val, int hw, 
     return 0;
 }
 
-extern "C" int otvm_memory_read_f16x3(const float* q_key, int q_ld, const void* const* slots, int T, int hw, float* out,
-                                      int out_ld, void* ws, void* stream) {
-    OTVM_REQUIRE(T >= 1 && T <= 4096, "otvm_memory_read_f16x3: T=%d out of range [1,4096]", T);
-    OTVM_REQUIRE(q_key && slots && out && ws && hw > 0, "otvm_memory_read_f16x3: bad arguments");
-    OTVM_REQUIRE(q_ld % 4 == 0 && out_ld % 4 == 0, "otvm_memory_read_f16x3: views must be 16-byte aligned");
+// partial launches over `n` slots: writes partials [part0, return value) of a workspace laid out for `np_cap` partials
+static int mr_launch_partials(const float* q_key, int q_ld, const void* const* slots, int n_slots, int hw, void* ws, int np_cap,
+                              int part0, hipStream_t stream) {
     const int hp = hw_pad64(hw);
     Mem3Args a;
     a.q = q_key; a.q_ld = q_ld; a.hw = hw;
-    const int np = otvm_memory_read_f16x3_partials(T, hw);
     a.part_o = (float*)ws;
-    a.part_ml = a.part_o + (int64_t)np * hw * DV;
+    a.part_ml = a.part_o + (int64_t)np_cap * hw * DV;
     a.tiles_per_slot = hp / BKV;
     // the reference's bank holds at most 5 slots (config.py:22); larger banks (the "unbounded bank" stress knob of
     // BASELINE configs[4]) are handled 8 slots per launch, one combine over all partials
-    int part0 = 0;
-    for (int s0 = 0; s0 < T; s0 += 8) {
-        const int n = T - s0 < 8 ? T - s0 : 8;
+    for (int s0 = 0; s0 < n_slots; s0 += 8) {
+        const int n = n_slots - s0 < 8 ? n_slots - s0 : 8;
         for (int t = 0; t < 8; ++t) {
             a.kf[t] = t < n ? (const _Float16*)slots[s0 + t] : nullptr;
             a.vf[t] = t < n ? (const _Float16*)slots[s0 + t] + (int64_t)hp * DK * 2 : nullptr;
@@ -339,9 +335,45 @@ extern "C" int otvm_memory_read_f16x3(const float* q_key, int q_ld, const void* 
         a.part0 = part0;
         // every chunk index < chunks owns at least one tile: chunks <= total_tiles and chunk_tiles = ceil(total/chunks)
         const int used = otvm_ceil_div(a.total_tiles, a.chunk_tiles);
-        hipLaunchKernelGGL(memory_read_f16x3_kernel, dim3(otvm_ceil_div(hw, BQ), used), dim3(256), 0, (hipStream_t)stream, a);
+        hipLaunchKernelGGL(memory_read_f16x3_kernel, dim3(otvm_ceil_div(hw, BQ), used), dim3(256), 0, stream, a);
         part0 += used;
     }
-    OTVM_CHECK_LAUNCH("otvm_memory_read_f16x3");
-    return otvm_memory_read_combine(a.part_o, a.part_ml, part0, hw, out, out_ld, stream);
+    return part0;
 }
+
+extern "C" int otvm_memory_read_f16x3(const float* q_key, int q_ld, const void* const* slots, int T, int hw, float* out,
+                                      int out_ld, void* ws, void* stream) {
+    OTVM_REQUIRE(T >= 1 && T <= 4096, "otvm_memory_read_f16x3: T=%d out of range [1,4096]", T);
+    OTVM_REQUIRE(q_key && slots && out && ws && hw > 0, "otvm_memory_read_f16x3: bad arguments");
+    OTVM_REQUIRE(q_ld % 4 == 0 && out_ld % 4 == 0, "otvm_memory_read_f16x3: views must be 16-byte aligned");
+    const int np = otvm_memory_read_f16x3_partials(T, hw);
+    const int used = mr_launch_partials(q_key, q_ld, slots, T, hw, ws, np, 0, (hipStream_t)stream);
+    OTVM_CHECK_LAUNCH("otvm_memory_read_f16x3");
+    return otvm_memory_read_combine((float*)ws, (float*)ws + (int64_t)np * hw * DV, used, hw, out, out_ld, stream);
+}
+
+// The read in two steps, for callers that know part of the bank earlier than the rest (the softmax over the memory axis
+// is computed flash-style from per-chunk partials, so the bank may be visited in any grouping and order):
+//   otvm_memory_read_f16x3_partial : partials over `n_slots` slots into [part0, *part_end) of a workspace laid out for
+//                                    np_cap partials (np_cap >= the sum of otvm_memory_read_f16x3_partials(n, hw) over
+//                                    all groups; ws >= np_cap * hw * (512 + 2) floats);
+//   otvm_memory_read_f16x3_combine : merges partials [0, n_partials) into out.
+extern "C" int otvm_memory_read_f16x3_partial(const float* q_key, int q_ld, const void* const* slots, int n_slots, int hw, void* ws,
+                                              int np_cap, int part0, int* part_end, void* stream) {
+    OTVM_REQUIRE(n_slots >= 1 && n_slots <= 4096 && q_key && slots && ws && hw > 0 && part_end && q_ld % 4 == 0,
+                 "otvm_memory_read_f16x3_partial: bad arguments");
+    OTVM_REQUIRE(part0 >= 0 && part0 + otvm_memory_read_f16x3_partials(n_slots, hw) <= np_cap,
+                 "otvm_memory_read_f16x3_partial: workspace laid out for %d partials is too small", np_cap);
+    *part_end = mr_launch_partials(q_key, q_ld, slots, n_slots, hw, ws, np_cap, part0, (hipStream_t)stream);
+    OTVM_CHECK_LAUNCH("otvm_memory_read_f16x3_partial");
+    return 0;
+}
+
+extern "C" int otvm_memory_read_f16x3_combine(const void* ws, int np_cap, int n_partials, int hw, float* out, int out_ld,
+                                              void* stream) {
+    OTVM_REQUIRE(ws && out && n_partials >= 1 && n_partials <= np_cap && out_ld % 4 == 0,
+                 "otvm_memory_read_f16x3_combine: bad arguments");
+    return otvm_memory_read_combine((const float*)ws, (const float*)ws + (int64_t)np_cap * hw * DV, n_partials, hw, out, out_ld, stream);
+}
+
+extern "C" int otvm_memory_read_f16x3_partial_count(int n_slots, int hw) { return otvm_memory_read_f16x3_partials(n_slots, hw); }

@@ -208,6 +208,7 @@ class HipEngine:
         self.last_T_read = 0
         self.parity = 0
         self.side = None
+        self.side2 = None
         import os
         self.use_side_stream = os.environ.get("OTVM_SIDE_STREAM", "1") != "0"
         # f16x3 splits fp32 operands into fp16 halves: an activation beyond fp16's range (|x| >= 65504) becomes inf and
@@ -365,7 +366,8 @@ class HipEngine:
         # ahead of the device -- already under the previous frame's alpha network, which is still executing on the launch
         # stream.  Its buffers (SQ, the q_ trunk, QK, M4[512:]) were last read by the previous frame's STM decoder (ev_dec).
         use_side = self.prof is None and self.use_side_stream and not first_frame
-        ev_q = None
+        ev_q = ev_s2 = None
+        split = None                                          # memory read started on a side stream (see below)
         if use_side:
             if self.side is None:
                 self.side = torch.cuda.Stream(device=dev)
@@ -385,8 +387,38 @@ class HipEngine:
             pq.sq, pq.sq_ld = pl.SQ.ptr, pl.SQ.ld
             L.check(lib.otvm_preprocess(C.byref(pq), side.cuda_stream), "preprocess (query encoder input)")
             pl.run("segment_a", side.cuda_stream, side)
+            # The memory read is merged from per-chunk partials, so the bank may be visited in any grouping: every slot but
+            # the one the previous frame is about to memorise is resident already -- its partials are computed here, on
+            # the side stream, right behind the query key (i.e. also under the previous frame's alpha network); the launch
+            # stream later adds the one new slot and merges (1/T of the read stays on the critical path).
             ev_q = torch.cuda.Event()
             ev_q.record(side)
+            # ---- second side stream: the DENSE work of this frame that depends on the query encoder only -- the memory read
+            # over the slots that are already resident (the read is merged from per-chunk partials, so the bank may be
+            # visited in any grouping; only the slot the previous frame is about to memorise is missing) and the decoder's
+            # skip branches -- is held back until the previous frame's alpha network has finished (ev_m0) and then runs
+            # NEXT TO Encoder_M of the previous frame: that chain of small launches is on the critical path and cannot
+            # fill 256 CUs, these kernels can.  The launch stream then adds the one new slot, merges, and runs the rest of
+            # the decoder.
+            if self.side2 is None:
+                self.side2 = torch.cuda.Stream(device=dev)
+            side2 = self.side2
+            ev_m0 = torch.cuda.Event()
+            ev_m0.record(main)
+            side2.wait_event(ev_q)
+            side2.wait_event(ev_m0)
+            if self.precision == L.PREC_F16X3:
+                if pend is not None:
+                    nb, _ = bank_update(self.bank, pend["slot"], pend["first_frame"], pend["memorize"], pend["max_memory_num"])
+                    old = [s_ for s_ in nb if s_ is not pend["slot"]]
+                    fresh = [pend["slot"]] if any(s_ is pend["slot"] for s_ in nb) else []
+                else:
+                    old, fresh = list(self.bank), []
+                if old:
+                    split = pl.memory_read_begin(old, fresh, side2.cuda_stream)
+            pl.run("segment_skip", side2.cuda_stream, side2)
+            ev_s2 = torch.cuda.Event()
+            ev_s2.record(side2)
         elif isinstance(inputs_ready, torch.cuda.Event):
             main.wait_event(inputs_ready)
         # ---- deferred memorize of the previous frame (reference order: memorize(t) ends frame t, alpha/model.py:461-493;
@@ -423,13 +455,24 @@ class HipEngine:
                 main.wait_event(ev_q)
             else:
                 pl.run("segment_a", stream)
+                pl.run("segment_skip", stream)
             if not self.bank:
                 raise RuntimeError("otvm_amd: non-first frame with an empty memory bank (call with first_frame=True first)")
             self.last_T_read = len(self.bank)
             if self.prof is not None:                         # bench.py roofline leg: HIP events around the memory read
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            pl.memory_read(self.bank, stream)
+            if split is not None:
+                if len(split["old"]) + len(split["fresh"]) != len(self.bank) or not all(
+                        any(b_ is s_ for b_ in self.bank) for s_ in split["old"] + split["fresh"]):
+                    raise RuntimeError("otvm_amd: the early memory read visited a different bank than the policy produced")
+                pl.memory_read_fresh(split, stream)           # the slot just memorised: needs only the query key (ev_q)
+                main.wait_event(ev_s2)                        # partials of the resident slots + the decoder's skip branches
+                pl.memory_read_merge(split, stream)
+            else:
+                if ev_s2 is not None:
+                    main.wait_event(ev_s2)
+                pl.memory_read(self.bank, stream)
             if self.prof is not None:
                 e1.record()
                 self.prof.append(("memory_read", 1280.0 * len(self.bank) * pl.hw * pl.hw, e0, e1, len(self.bank)))
@@ -757,7 +800,7 @@ class FramePlan:
 
         # split-K workspaces, one per chain that may run concurrently with the others: [0] decoder + alpha network (launch
         # stream), [1] memorize (launch stream, but tuned / timed separately), [2] query encoder (side stream)
-        self.SPLITK_WS = [self.raw("splitk_ws0", 16 << 20), self.raw("splitk_ws1", 16 << 20), self.raw("splitk_ws2", 16 << 20)]
+        self.SPLITK_WS = [self.raw("splitk_ws%d" % i, 16 << 20) for i in range(4)]    # [3]: decoder skip branches (side stream 2)
         self._ws = self.SPLITK_WS[2]
         # ---------------- frame-level buffers
         self.X11 = self.buf("X11", Hp, Wp, 12)          # 0-2 normalised RGB, 3-8 distance encoding, 9-10 soft, 11 zero
@@ -788,18 +831,29 @@ class FramePlan:
         self._ws = self.SPLITK_WS[0]
         S = []
         d = "trimap.model.Decoder."
+        # The skip branches of the two Refine blocks (STM.py:110-113: ResFS(convFS(r3 / r2))) read only the query
+        # encoder's features, not the memory readout: they form their own launch list ("segment_skip", 1.7 of the
+        # decoder's 3.1 ms at 1080p), which the engine runs on a second side stream next to Encoder_M of the previous
+        # frame -- dense kernels filling the CUs that chain of small launches leaves idle.
+        SK = []
+        self._ws = self.SPLITK_WS[3]
+        skips = {}
+        for rf, feat, (h, w) in (("RF3", r3, (H8, W8)), ("RF2", r2, (H4, W4))):
+            s0 = self.buf("d_s0", h, w, 256)
+            self.conv(SK, feat, d + rf + ".convFS", s0, pad=1)
+            s1 = self.buf("d_s1", h, w, 256)
+            self.resblock(SK, s0, d + rf + ".ResFS", s1, "fs%d" % h)
+            skips[rf] = s1
+        self.steps["segment_skip"] = SK
+        self._ws = self.SPLITK_WS[0]
         m = self.buf("d_m4a", H16, W16, 256)
         self.conv(S, self.M4, d + "convFM", m, pad=1)
         m4 = self.buf("d_m4b", H16, W16, 256)
         self.resblock(S, m, d + "ResMM", m4, "d16")
         pm = m4
-        for rf, feat, (h, w) in (("RF3", r3, (H8, W8)), ("RF2", r2, (H4, W4))):
-            s0 = self.buf("d_s0", h, w, 256)
-            self.conv(S, feat, d + rf + ".convFS", s0, pad=1)
-            s1 = self.buf("d_s1", h, w, 256)
-            self.resblock(S, s0, d + rf + ".ResFS", s1, "d%d" % h)
+        for rf, (h, w) in (("RF3", (H8, W8)), ("RF2", (H4, W4))):
             mm = self.buf("d_mm", h, w, 256)
-            self.upsample(S, pm, mm, add=s1)                        # m = s + up2(pm)  (STM.py:115)
+            self.upsample(S, pm, mm, add=skips[rf])                 # m = s + up2(pm)  (STM.py:115)
             mo = self.buf("d_mo", h, w, 256)
             self.resblock(S, mm, d + rf + ".ResMM", mo, "d%d" % h)
             pm = mo
@@ -981,6 +1035,7 @@ class FramePlan:
         T = len(bank)
         need = int(self.lib.otvm_memory_read_ws_bytes(self.hw, T))
         if self.mem_ws is None or self.mem_ws.numel() < need:
+            torch.cuda.synchronize(self.dev)                  # (rare; the side stream may still be using the old one)
             self.mem_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
         out = self.M4.ch(0, 512)
         if self.e.precision == L.PREC_F16X3:
@@ -992,6 +1047,40 @@ class FramePlan:
         vals = (C.c_void_p * T)(*[s["v"].ptr for s in bank])
         L.check(self.lib.otvm_memory_read(self.QK.ptr, self.QK.ld, keys, vals, T, self.hw, out.ptr, out.ld,
                                           self.mem_ws.data_ptr(), stream), "memory_read")
+
+    def memory_read_begin(self, old, fresh, stream):
+        """f16x3 memory read, first step: partials over the slots ``old`` (already resident) on ``stream``; ``fresh`` (the
+        slot being memorised right now, 0 or 1 entries) follows in memory_read_finish."""
+        lib = self.lib
+        np_cap = int(lib.otvm_memory_read_f16x3_partial_count(len(old), self.hw))
+        if fresh:
+            np_cap += int(lib.otvm_memory_read_f16x3_partial_count(len(fresh), self.hw))
+        need = np_cap * self.hw * (512 + 2) * 4
+        if self.mem_ws is None or self.mem_ws.numel() < need:
+            torch.cuda.synchronize(self.dev)                  # (rare: the bank grew; nothing in flight may use the old one)
+            self.mem_ws = torch.empty(max(need, 2 * (0 if self.mem_ws is None else self.mem_ws.numel())), dtype=torch.uint8,
+                                      device=self.dev)
+        arr = (C.c_void_p * len(old))(*[s["packed"].data_ptr() for s in old])
+        end = C.c_int(0)
+        L.check(lib.otvm_memory_read_f16x3_partial(self.QK.ptr, self.QK.ld, arr, len(old), self.hw, self.mem_ws.data_ptr(), np_cap, 0,
+                                                   C.byref(end), stream), "memory_read_f16x3_partial")
+        return dict(old=old, fresh=fresh, np_cap=np_cap, done=end.value, ws=self.mem_ws)
+
+    def memory_read_fresh(self, split, stream):
+        lib, n = self.lib, split["done"]
+        if split["fresh"]:
+            fr = split["fresh"]
+            arr = (C.c_void_p * len(fr))(*[s["packed"].data_ptr() for s in fr])
+            end = C.c_int(0)
+            L.check(lib.otvm_memory_read_f16x3_partial(self.QK.ptr, self.QK.ld, arr, len(fr), self.hw, split["ws"].data_ptr(),
+                                                       split["np_cap"], n, C.byref(end), stream), "memory_read_f16x3_partial")
+            n = end.value
+        split["done"] = n
+
+    def memory_read_merge(self, split, stream):
+        out = self.M4.ch(0, 512)
+        L.check(self.lib.otvm_memory_read_f16x3_combine(split["ws"].data_ptr(), split["np_cap"], split["done"], self.hw, out.ptr,
+                                                        out.ld, stream), "memory_read_f16x3_combine")
 
     def kv_into_slot(self, slot, stream):
         if "kv_steps" not in slot:

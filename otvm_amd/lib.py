@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3 = 0, 1
-ABI_VERSION = 7          # include/otvm_hip.h OTVM_ABI_VERSION
+ABI_VERSION = 8          # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -64,6 +64,9 @@ _PROTOS = {
     "otvm_bank_slot_bytes_f16x3": (i64, [i32]),
     "otvm_bank_pack_f16x3": (i32, [vp, vp, i32, vp, vp]),
     "otvm_memory_read_f16x3": (i32, [vp, i32, C.POINTER(vp), i32, i32, vp, i32, vp, vp]),
+    "otvm_memory_read_f16x3_partial_count": (i32, [i32, i32]),
+    "otvm_memory_read_f16x3_partial": (i32, [vp, i32, C.POINTER(vp), i32, i32, vp, i32, i32, C.POINTER(i32), vp]),
+    "otvm_memory_read_f16x3_combine": (i32, [vp, i32, i32, i32, vp, i32, vp]),
     "otvm_preprocess": (i32, [C.POINTER(PreprocessParams), vp]),
     "otvm_pad_trimap": (i32, [vp, i32, i32, vp, i32, i32, i32, i32, vp]),
     "otvm_upsample4_softmax3": (i32, [vp, i32, i32, i32, vp, vp]),

@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--seed", type=int, default=23)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--ready", type=int, default=0, help="pass _inputs_ready=True to the free-running frames")
     args = ap.parse_args()
     from oracle.otvm_oracle import OtvmOracle
     from otvm_amd import helpers
@@ -43,7 +44,7 @@ def main():
         m = m.cuda().eval()
         for t in range(t_s):
             a, fg, tg = tensors(t)
-            m(a.cuda(), fg.cuda(), fg.cuda(), tri_gt=tg.cuda(), _frame_id=t, **flags(t))
+            m(a.cuda(), fg.cuda(), fg.cuda(), tri_gt=tg.cuda(), _frame_id=t, _inputs_ready=(True if args.ready else None), **flags(t))
         eng = m._engine
         eng.flush()
         torch.cuda.synchronize()
