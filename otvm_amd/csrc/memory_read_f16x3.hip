@@ -29,6 +29,12 @@ constexpr int DK = 128, DV = 512, BQ = 64, BKV = 64;
 constexpr int LDQH = DK + 8;      // halfs per Q row in LDS (272 B: conflict-free b128)
 constexpr int LDPH = BKV + 8;     // halfs per P row (144 B)
 
+// e^x for x <= 0 as one v_exp_f32 (2^y, 1 ulp) on x * log2(e): the product rounds the exponent by |x| * 6e-8, i.e. a
+// relative error below 1e-6 for every term that is not negligible in the softmax sum (x > -17), 1e-7 for the dominant
+// ones; results below 2^-126 flush to zero.  libm's expf spends ~20 instructions per value on the last ulp and on
+// denormal results -- a third of this kernel's VALU work.  e^(-inf) = 0 as before.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+
 __device__ __forceinline__ void split1(float v, _Float16& hi, _Float16& lo) {
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
@@ -141,15 +147,36 @@ __global__ __launch_bounds__(256, 2) void memory_read_f16x3_kernel(const Mem3Arg
 #pragma unroll
         for (int e = 0; e < 16; ++e) { s[e] = 0.f; s2[e] = 0.f; }
         const _Float16* kblk = Kf + ((int64_t)(2 * t + sa) * 8 * 2) * 512 + lane * 8;
+        // all 16 key fragments of the tile are requested before the first MFMA (64 VGPRs that the PV phase below does
+        // not need at the same time): one exposed L2 round trip per tile instead of one per k-step
+        f16x8 kh[8], kl[8];
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
-            const f16x8 kh = *reinterpret_cast<const f16x8*>(kblk + (ks * 2) * 512);
-            const f16x8 kl = *reinterpret_cast<const f16x8*>(kblk + (ks * 2 + 1) * 512);
+            kh[ks] = *reinterpret_cast<const f16x8*>(kblk + (ks * 2) * 512);
+            kl[ks] = *reinterpret_cast<const f16x8*>(kblk + (ks * 2 + 1) * 512);
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
             const f16x8 qh = *reinterpret_cast<const f16x8*>(qhp + 16 * ks);
             const f16x8 ql = *reinterpret_cast<const f16x8*>(qlp + 16 * ks);
-            s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh, s2, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh, s, 0, 0, 0);
-            s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql, s2, 0, 0, 0);
+            s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[ks], qh, s2, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[ks], qh, s, 0, 0, 0);
+            s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[ks], ql, s2, 0, 0, 0);
+        }
+        // (measured, round 2: K up front + V one k-step ahead 1.344 -> 1.274 ms at 1080p / 5 slots; the one-instruction
+        // exponential 1.274 -> 1.229; s_setprio around the MFMA bursts 1.229 -> 1.248, rejected; loading only half of the
+        // value fragments -- wrong results, timing probe -- 1.223 -> 1.149: the kernel is not bound by the CU's 64 B/clk
+        // vector-memory path, so a 128-query workgroup that halves the bank traffic was not built)
+        // the first value fragments of the tile travel under the softmax
+        f16x8 vh[2][4], vl[2][4];
+        {
+            const _Float16* vblk = Vf + (((int64_t)(4 * t) * 16 + wave * 4) * 2) * 512 + lane * 8;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                vh[0][b] = *reinterpret_cast<const f16x8*>(vblk + (b * 2) * 512);
+                vl[0][b] = *reinterpret_cast<const f16x8*>(vblk + (b * 2 + 1) * 512);
+            }
         }
         s += s2;                                         // small terms first, then onto the hi*hi sum
         // ---- online softmax over the memory axis, in registers.  The S^T block keeps a QUERY per lane (column
@@ -173,14 +200,14 @@ __global__ __launch_bounds__(256, 2) void memory_read_f16x3_kernel(const Mem3Arg
         __syncthreads();                                 // (A) tile maxima visible; P / alpha of the last tile consumed
         {
             const float m_new = fmaxf(m_run, fmaxf(red_m[qq], red_m[BQ + qq]));
-            const float al = expf(m_run - m_new);
+            const float al = fast_exp(m_run - m_new);
             float sum = 0.f;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 f16x4 hi, lo;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float e = expf(v[4 * g + j] - m_new);
+                    const float e = fast_exp(v[4 * g + j] - m_new);
                     sum += e;
                     _Float16 h, lw;
                     split1(e, h, lw);
@@ -229,29 +256,32 @@ __global__ __launch_bounds__(256, 2) void memory_read_f16x3_kernel(const Mem3Arg
                 ph[a] = *reinterpret_cast<const f16x8*>(&Ph[(a * 32 + frow) * LDPH + 16 * ks + 8 * fh]);
                 pl[a] = *reinterpret_cast<const f16x8*>(&Pl[(a * 32 + frow) * LDPH + 16 * ks + 8 * fh]);
             }
-            const _Float16* vblk = Vf + (((int64_t)(4 * t + ks) * 16 + wave * 4) * 2) * 512 + lane * 8;
-            f16x8 vh[4], vl[4];
+            if (ks + 1 < 4) {                            // the next k-step's value fragments, a k-step ahead
+                const _Float16* vblk = Vf + (((int64_t)(4 * t + ks + 1) * 16 + wave * 4) * 2) * 512 + lane * 8;
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                vh[b] = *reinterpret_cast<const f16x8*>(vblk + (b * 2) * 512);
-                vl[b] = *reinterpret_cast<const f16x8*>(vblk + (b * 2 + 1) * 512);
+                for (int b = 0; b < 4; ++b) {
+                    vh[(ks + 1) & 1][b] = *reinterpret_cast<const f16x8*>(vblk + (b * 2) * 512);
+                    vl[(ks + 1) & 1][b] = *reinterpret_cast<const f16x8*>(vblk + (b * 2 + 1) * 512);
+                }
+                asm volatile("" ::: "memory");
             }
+            const int vb = ks & 1;
             // three passes over the eight accumulator tiles: consecutive MFMAs never share an accumulator
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl[a], vh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl[a], vh[vb][b], acc[a][b], 0, 0, 0);
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[a], vl[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[a], vl[vb][b], acc[a][b], 0, 0, 0);
 #pragma unroll
             for (int b = 0; b < 4; ++b)
 #pragma unroll
                 for (int a = 0; a < 2; ++a)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[a], vh[b], acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[a], vh[vb][b], acc[a][b], 0, 0, 0);
         }
         // no barrier here: the next tile's red_m writes happen after (B), its P / alpha writes after its own (A),
         // which every wave reaches only after finishing the reads above
