@@ -18,6 +18,9 @@
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 
+#ifndef OTVM_PF_DEPTH
+#define OTVM_PF_DEPTH 3
+#endif
 #ifndef OTVM_BRANCHY_LOADS
 #define OTVM_BRANCHY_LOADS 1
 #endif
@@ -130,10 +133,23 @@ void conv_igemm_f16x3_kernel(const Conv3Args p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
-    f32x4 ra[A_LD];
-    unsigned okmask = 0;            // bit i: ra[i] holds image data (else padding -> zero)
-    f16x8 rbh[B_LD], rbl[B_LD];
-    auto load_chunk = [&](int c) __attribute__((always_inline)) {
+    // register sets of chunks in flight (global -> registers -> LDS).  The 256x128 tile uses ~155 of its 256 VGPRs: three
+    // sets = three chunks of loads under way, because with ONE workgroup per CU a chunk's MFMA time (0.7 us) is well
+    // below the L2-miss latency and the K loop otherwise runs at one memory round trip per chunk
+    constexpr int PF = (DBUF && BN == 128) ? OTVM_PF_DEPTH : 1;
+    struct RegSet {
+        f32x4 ra[A_LD];
+        unsigned okmask;            // bit i: ra[i] holds image data (else padding -> zero)
+        f16x8 rbh[B_LD], rbl[B_LD];
+    };
+    RegSet rs[PF];
+#pragma unroll
+    for (int j = 0; j < PF; ++j) rs[j].okmask = 0;
+    auto load_chunk = [&](int c, RegSet& R) __attribute__((always_inline)) {
+        f32x4 (&ra)[A_LD] = R.ra;
+        unsigned& okmask = R.okmask;
+        f16x8 (&rbh)[B_LD] = R.rbh;
+        f16x8 (&rbl)[B_LD] = R.rbl;
         if (FAST) {
             const int delta = (u_ky * p.dil * p.W + u_kx * p.dil) * p.in_ld + (u_cb << 5);   // scalar
             const unsigned bit = 1u << u_tap;
@@ -180,7 +196,11 @@ void conv_igemm_f16x3_kernel(const Conv3Args p) {
             }
         }
     };
-    auto store_chunk = [&](int buf) __attribute__((always_inline)) {
+    auto store_chunk = [&](int buf, RegSet& R) __attribute__((always_inline)) {
+        f32x4 (&ra)[A_LD] = R.ra;
+        const unsigned okmask = R.okmask;
+        f16x8 (&rbh)[B_LD] = R.rbh;
+        f16x8 (&rbl)[B_LD] = R.rbl;
         _Float16* Ah = smem + buf * STAGE;
         _Float16* Al = Ah + BM * LDH;
         _Float16* Bh = Al + BM * LDH;
@@ -243,32 +263,41 @@ void conv_igemm_f16x3_kernel(const Conv3Args p) {
                 acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bh[b], acc[a][b], 0, 0, 0);
     };
 
-    load_chunk(c_begin);
+    load_chunk(c_begin, rs[0]);
     if (DBUF) {
         // one barrier per chunk: while the MFMAs of chunk c run out of stage c&1, the same wave converts chunk
         // c+1 into the other stage (VALU/LDS work issues in the shadow of the 32-cycle MFMAs) and then launches
-        // the global loads of chunk c+2, which have a whole chunk of MFMA time to land.
-        store_chunk(0);
-        if (c_begin + 1 < c_end) load_chunk(c_begin + 1);
+        // the global loads of chunk c+1+PF, which have PF chunks of MFMA time to land.
+        store_chunk(0, rs[0]);
+#pragma unroll
+        for (int j = 0; j < PF; ++j)
+            if (c_begin + 1 + j < c_end) load_chunk(c_begin + 1 + j, rs[j]);
         __syncthreads();
         // the conversion of chunk c+1 sits between the two k-steps of chunk c in ONE basic block (no branch around
         // it: the last chunk is peeled), so the scheduler can interleave its VALU / LDS writes with the MFMAs
         int c = c_begin, buf = 0;
-        for (; c + 1 < c_end; ++c, buf ^= 1) {
-            compute_ks(buf, 0);
-            store_chunk(buf ^ 1);
-            if (c + 2 < c_end) load_chunk(c + 2);
-            compute_ks(buf, 1);
-            __syncthreads();
+        bool more = c + 1 < c_end;
+        while (more) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {             // chunk c in stage buf, chunk c+1 in register set j
+                compute_ks(buf, 0);
+                store_chunk(buf ^ 1, rs[j]);
+                if (c + 1 + PF < c_end) load_chunk(c + 1 + PF, rs[j]);
+                compute_ks(buf, 1);
+                __syncthreads();
+                ++c;
+                buf ^= 1;
+                if (c + 1 >= c_end) { more = false; break; }
+            }
         }
         compute_ks(buf, 0);
         compute_ks(buf, 1);
     } else {
         for (int c = c_begin; c < c_end; ++c) {
             __syncthreads();
-            store_chunk(0);
+            store_chunk(0, rs[0]);
             __syncthreads();
-            if (c + 1 < c_end) load_chunk(c + 1);
+            if (c + 1 < c_end) load_chunk(c + 1, rs[0]);
             compute_ks(0, 0);
             compute_ks(0, 1);
         }
@@ -483,6 +512,12 @@ extern "C" int otvm_split_conv_weight_f16x3(const float* w_packed, int O, int O_
 
 int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream);    // conv_patch_f16x3.hip, -1 = not eligible
 
+// (measured and rejected, round 2: an "activation-stationary" kernel for the expanding 1x1 layers of the bottlenecks --
+// the 64/128-pixel x Cin tile split once into LDS, every wave streaming its own weight fragments from L2, two or three
+// workgroups per CU -- 64->256 at 272x480 49 vs 51 us, 128->512 at 136x240 35 vs 35, 256->1024 108 vs 89, 512->2048
+// 246 vs 266, and 2x slower with fused GroupNorm sums (four times as many fp64 atomics per group as the 256-row tiles):
+// these layers move 2.4-3.9 TB/s of output + input + residual in either kernel, i.e. they sit within 1.6-2.5x of the HBM
+// bound, not of the MFMA bound.  A deeper register prefetch ring (OTVM_PF_DEPTH) on the 256x128 tile: +-2 %.)
 // ---- dispatch.  A configuration is (tile, S): one of the implicit-GEMM tiles below with the K chunks of every output
 // tile shared by S workgroups (S > 1: partial tiles through the caller's workspace, added in a fixed order by
 // splitk_finish_kernel), or the 3x3 patch kernel.  otvm_conv_params.tune forces one (the host's plan-time autotuner,
