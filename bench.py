@@ -30,8 +30,9 @@ if ROOT not in sys.path:
 # MI355X_MICROARCH.md, dense peaks.  f16x3 issues three f16 MFMAs per fp32-equivalent product, so its
 # roofline for ALGORITHMIC (fp32-equivalent) FLOPs is the f16 peak / 3.
 PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0 / 3.0}
+POWER_LIMITED_PEAK = {"f16x3": 1710.3 / 3.0}       # profiles/r02_mfma_power_ceiling.txt (random hi/lo operands, 256 CUs; 1598 on another box)
 KERNEL_NAME = {"f32": "all otvm_conv2d launches: conv_igemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
-               "f16x3": "all otvm_conv2d launches: conv_igemm_f16x3_kernel + conv_patch_f16x3_kernel (+ split-K finish); "
+               "f16x3": "all otvm_conv2d launches: conv_igemm_f16x3_kernel + conv_patch_f16x3_kernel + conv_stem_f16x3_kernel (+ split-K finish); "
                         "3x v_mfma_f32_32x32x16_f16 per fp32-equivalent MAC"}
 
 
@@ -221,6 +222,12 @@ def main():
             "bound": "mfma", "kernel": KERNEL_NAME[eng.precision_name],
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": traffic,
+            # what the matrix cores of this chip sustain under its power limit with realistic operand values and NO memory
+            # traffic (tools/probes/mfma_probe.hip, profiles/r02_mfma_power_ceiling.txt): 1598 TFLOP/s f16 = 533 f16x3;
+            # informative only, `frac` above is priced against the nominal peak
+            "power_limited_peak": POWER_LIMITED_PEAK.get(eng.precision_name),
+            "frac_of_power_limited_peak": (achieved / POWER_LIMITED_PEAK[eng.precision_name]
+                                           if eng.precision_name in POWER_LIMITED_PEAK else None),
             "algorithmic_bytes_per_launch": tot_by / n,
             "launches_per_frame": n / nrep, "avg_launch_ms": tot_ms / n, "algorithmic_gflop_per_launch": tot_fl / n / 1e9,
             "conv_ms_per_frame": tot_ms / nrep, "conv_share_of_frame": (tot_ms / nrep) / (1000.0 * elapsed / K),

@@ -32,7 +32,7 @@ def main():
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     print("# rocprofv3 --kernel-trace --stats -- %s" % cmd)
     print("# MI355X (gfx950), %d frames in the trace (warm-up included); raw CSV next to this file" % frames)
-    print("# note: the query encoder of frame t+1 runs on a second stream under the alpha network of frame t: the sum of kernel times exceeds wall time\n")
+    print("# note: the query encoder of frame t+1 and the early part of the memory read run on side streams (DESIGN.md 4): the sum of kernel times exceeds wall time\n")
     print("| kernel | calls | total ms | avg us | % of kernel time |")
     print("|---|---:|---:|---:|---:|")
     g = {}
