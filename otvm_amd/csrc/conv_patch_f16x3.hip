@@ -452,7 +452,10 @@ static int patch_run(const otvm_conv_params* p, void* stream, int choice) {
     // <= 32 output channels: 3-tap weight stages (46 KB of LDS instead of 58) and 158 registers -> three workgroups per CU
     // instead of two: 64->32 at 1088x1920 0.316 -> 0.302 ms, 32->16 0.187 -> 0.171.  (64 output channels the same way:
     // spills at 168 registers, 0.591 -> 0.648 ms; 16x32-pixel blocks with 4 waves x 4 rows and 3-tap stages -- half the
-    // fragment reads per MFMA, but 341 registers = one wave per SIMD -- 0.611 -> 0.774 ms.)
+    // fragment reads per MFMA, but 341 registers = one wave per SIMD -- 0.611 -> 0.774 ms.  A persistent form -- resident
+    // workgroups walking several tiles, the next tile's first stage requested under the last MFMAs of the current one --
+    // is worth 4 % on its own code (0.710 -> 0.680 ms) but keeps 60 prefetch registers live across the epilogue: 47 spilled
+    // dwords at two waves per SIMD, against 0.591 ms for this one-tile-per-workgroup kernel.)
     if (p->dil == 1) return p->Cout <= 32 ? launch_patch<8, 32, 4, 1, 3>(a, s) : launch_patch<8, 64, 4, 1>(a, s);
     if (p->dil == 2) return launch_patch<8, 64, 4, 2>(a, s);
     return launch_patch<8, 64, 4, 4>(a, s);
