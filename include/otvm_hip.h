@@ -35,11 +35,11 @@ extern "C" {
 #define OTVM_PREC_F16X3 1
 
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 8    /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
+#define OTVM_ABI_VERSION 9    /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
                                  4: otvm_conv_params.splitk_ws; 5: otvm_preprocess_params.fg_u8/bg_u8/u8_rgb;
                                  6: otvm_conv_params.tune + otvm_conv2d_candidates;
                                  7: folded GroupNorm tables on otvm_gn_apply's residual and otvm_upsample_bilinear's input;
-                                 8: otvm_memory_read_f16x3_partial / _combine / _partial_count */
+                                 8: otvm_memory_read_f16x3_partial / _combine / _partial_count; 9: otvm_ppm_head */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -155,6 +155,17 @@ int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, int in_ld, co
  * fixed-order reduction over the rows of every bin).                                                */
 int64_t otvm_ppm_pool_ws_bytes(int H, int C);
 int otvm_ppm_pool(const float* in, int H, int W, int C, int ld, float* out, void* ws, void* stream);
+
+/* The four PPM heads behind the pooling (FBA/models.py:298-307: L.Conv2d(2048, 256, 1, bias) -> GroupNorm(32) ->
+ * LeakyReLU on each pooled map) in one launch.  pooled = otvm_ppm_pool's output [50][C]; w[i] = packed fp32 weight of
+ * branch i ([>= 256 rows][K_pad], weight standardisation already applied by otvm_pack_conv_weight), bias[i] optional;
+ * out[i] = [s*s][out_ld] (s = 1, 2, 3, 6), normalised and activated -- ready for otvm_upsample_bilinear.           */
+typedef struct otvm_ppm_head_params {
+    const float* pooled; int C, K_pad, Cout;
+    const float* w[4]; const float* bias[4]; const float* gamma[4]; const float* beta[4];
+    float* out[4]; int out_ld, act;
+} otvm_ppm_head_params;
+int otvm_ppm_head(const otvm_ppm_head_params* p, void* stream);
 
 /* ---------------------------------------------------------------- memory read (STM.py:140-163) -
  * mem[q, :] = sum_m softmax_m(K[m,:].Q[q,:] / sqrt(128)) V[m,:], m over T slots x hw positions.

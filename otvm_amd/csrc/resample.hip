@@ -196,3 +196,98 @@ extern "C" int otvm_ppm_pool(const float* in, int H, int W, int C, int ld, float
     OTVM_CHECK_LAUNCH("otvm_ppm_pool");
     return 0;
 }
+
+// ---- the four PPM heads in ONE launch (FBA/models.py:298-307, 357-361): for each pooled map (1x1, 2x2, 3x3, 6x6 = 50
+// pixels of 2048 channels) a 1x1 convolution to 256 channels (+bias), GroupNorm(32) over the map, LeakyReLU.  As separate
+// library calls that is 4 x (split-K conv + reduction + statistics + table) = 16 launches of a few microseconds of work
+// each on a serial chain; here a workgroup owns one GroupNorm group (8 channels) of one map: the 256 threads split the
+// 2048 input channels, keep their slice of the 8 filters in registers, and reduce per (pixel, channel) through lane
+// shuffles and LDS; the group's mean / variance are taken in fp64 over its <= 288 values.  fp32 FMA arithmetic (exact
+// products, fp32 accumulate): the same class as the matrix-core paths.  (First version: 32 lanes per channel, one pixel
+// at a time -- 2304 dependent-latency loads per lane on the 6x6 map, slower than the 16 launches it replaced.)
+namespace {
+
+struct PpmHeadArgs {
+    const float* pooled; int K_pad;
+    const float* w[4]; const float* bias[4]; const float* gamma[4]; const float* beta[4]; float* out[4];
+    int out_ld, act;
+};
+
+__global__ __launch_bounds__(256) void ppm_head_kernel(const PpmHeadArgs p) {
+    constexpr int C = 2048, KT = C / 256, PB = 4;               // k values per thread; pixels per batch
+    const int g = blockIdx.x, br = blockIdx.y;
+    const int s = br == 0 ? 1 : (br == 1 ? 2 : (br == 2 ? 3 : 6));
+    const int base = br == 0 ? 0 : (br == 1 ? 1 : (br == 2 ? 5 : 14));
+    const int P = s * s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ float part[4][36 * 8];                           // per wave: partial dot products [pixel][channel]
+    __shared__ float val[36 * 8];
+    __shared__ float mean_s, rstd_s;
+    // thread t owns k = t, t + 256, ...: the 8 filters' weights at those k stay in registers (64 values); a pooled pixel
+    // costs 8 coalesced loads per thread, used for all 8 channels; 4 pixels (32 loads) are in flight at a time
+    float wr[8][KT];
+#pragma unroll
+    for (int ch = 0; ch < 8; ++ch)
+#pragma unroll
+        for (int j = 0; j < KT; ++j) wr[ch][j] = p.w[br][(int64_t)(g * 8 + ch) * p.K_pad + tid + 256 * j];
+    for (int p0 = 0; p0 < P; p0 += PB) {
+        float xv[PB][KT];
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+            const int px = p0 + q < P ? p0 + q : P - 1;         // tail: re-read the last pixel, results dropped
+            const float* x = p.pooled + (int64_t)(base + px) * C + tid;
+#pragma unroll
+            for (int j = 0; j < KT; ++j) xv[q][j] = x[256 * j];
+        }
+#pragma unroll
+        for (int q = 0; q < PB; ++q) {
+#pragma unroll
+            for (int ch = 0; ch < 8; ++ch) {
+                float a = 0.f;
+#pragma unroll
+                for (int j = 0; j < KT; ++j) a = fmaf(wr[ch][j], xv[q][j], a);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+                if (lane == 0 && p0 + q < P) part[wave][(p0 + q) * 8 + ch] = a;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < P * 8; i += 256) {
+        const int c = g * 8 + (i & 7);
+        val[i] = ((part[0][i] + part[1][i]) + (part[2][i] + part[3][i])) + (p.bias[br] ? p.bias[br][c] : 0.f);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double sm = 0.0, sq = 0.0;
+        for (int i = 0; i < P * 8; ++i) { const double v = val[i]; sm += v; sq += v * v; }
+        const double cnt = (double)(P * 8), mean = sm / cnt;
+        double var = sq / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mean_s = (float)mean;
+        rstd_s = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+    for (int i = tid; i < P * 8; i += 256) {
+        const int px = i >> 3, cc = g * 8 + (i & 7);
+        const float a = rstd_s * p.gamma[br][cc];
+        const float b = p.beta[br][cc] - mean_s * a;
+        p.out[br][(int64_t)px * p.out_ld + cc] = otvm_act(val[i] * a + b, p.act);
+    }
+}
+
+}  // namespace
+
+extern "C" int otvm_ppm_head(const otvm_ppm_head_params* q, void* stream) {
+    OTVM_REQUIRE(q && q->pooled && q->C == 2048 && q->K_pad >= 2048 && q->Cout == 256,
+                 "otvm_ppm_head: built for 2048 -> 256 channels (got %d -> %d)", q ? q->C : 0, q ? q->Cout : 0);
+    PpmHeadArgs a;
+    a.pooled = q->pooled; a.K_pad = q->K_pad; a.out_ld = q->out_ld; a.act = q->act;
+    for (int i = 0; i < 4; ++i) {
+        OTVM_REQUIRE(q->w[i] && q->gamma[i] && q->beta[i] && q->out[i], "otvm_ppm_head: null pointer (branch %d)", i);
+        a.w[i] = q->w[i]; a.bias[i] = q->bias[i]; a.gamma[i] = q->gamma[i]; a.beta[i] = q->beta[i]; a.out[i] = q->out[i];
+    }
+    hipLaunchKernelGGL(ppm_head_kernel, dim3(32, 4), dim3(256), 0, (hipStream_t)stream, a);
+    OTVM_CHECK_LAUNCH("otvm_ppm_head");
+    return 0;
+}

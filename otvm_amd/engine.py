@@ -29,6 +29,7 @@ FUSE_GN_APPLY = os.environ.get("OTVM_FUSE_GN_APPLY", "1") != "0"
 # (1080p 37.6 vs 37.6 fps, 480p 124.9 vs 123.9, IO pipeline 37.0 vs 36.9), the graphs only cut the host time per frame
 # (6.8 -> 0.9 ms at 480p) -- worth switching on when many processes share few host cores.
 USE_GRAPHS = os.environ.get("OTVM_GRAPHS", "0") != "0"
+FUSE_PPM_HEAD = os.environ.get("OTVM_PPM_HEAD", "1") != "0"       # the four PPM heads in one launch (otvm_ppm_head)
 
 
 # Plan-time autotuning of the convolution configurations (f16x3): every distinct layer shape is timed once on the device
@@ -896,13 +897,32 @@ class FramePlan:
         self.POOL_WS = self.raw("ppm_ws", int(lib.otvm_ppm_pool_ws_bytes(H8, 2048)) // 4)
         S.append((lib.otvm_ppm_pool, (conv5.ptr, H8, W8, 2048, conv5.ld, self.POOL.data_ptr(), self.POOL_WS.data_ptr()),
                   "ppm_pool"))
-        base = 0
-        for i, s in enumerate((1, 2, 3, 6)):
-            pin = Act(self.POOL, s, s, 2048, 2048, base * 2048)
-            y = self.buf("ppm_y%d" % i, s, s, 256)
-            cp = self.conv(S, pin, de + "ppm.%d.1" % i, y)
-            self.gn_then_upsample(S, y, de + "ppm.%d.2" % i, LEAKY, cp, self.PPMCAT.ch(2048 + 256 * i, 256))
-            base += s * s
+        if FUSE_PPM_HEAD and self.e.W[de + "ppm.0.1"].I_pad == 2048 and self.e.W[de + "ppm.0.1"].O == 256:
+            # conv + bias + GroupNorm + LeakyReLU of the four pooled maps in ONE launch (16 launches as library calls)
+            sd = self.e.sd
+            hp = L.PpmHeadParams()
+            hp.pooled, hp.C, hp.Cout, hp.act = self.POOL.data_ptr(), 2048, 256, LEAKY
+            ys = []
+            for i, s in enumerate((1, 2, 3, 6)):
+                w = self.e.W[de + "ppm.%d.1" % i]
+                y = self.buf("ppm_y%d" % i, s, s, 256)
+                ys.append(y)
+                hp.K_pad, hp.out_ld = w.K_pad, y.ld
+                hp.w[i], hp.bias[i] = w.w.data_ptr(), 0 if w.bias is None else w.bias.data_ptr()
+                hp.gamma[i], hp.beta[i] = sd[de + "ppm.%d.2.weight" % i].data_ptr(), sd[de + "ppm.%d.2.bias" % i].data_ptr()
+                hp.out[i] = y.ptr
+            self._keep.append(hp)
+            S.append((lib.otvm_ppm_head, (C.byref(hp),), "ppm_head"))
+            for i, y in enumerate(ys):
+                self.upsample(S, y, self.PPMCAT.ch(2048 + 256 * i, 256))
+        else:
+            base = 0
+            for i, s in enumerate((1, 2, 3, 6)):
+                pin = Act(self.POOL, s, s, 2048, 2048, base * 2048)
+                y = self.buf("ppm_y%d" % i, s, s, 256)
+                cp = self.conv(S, pin, de + "ppm.%d.1" % i, y)
+                self.gn_then_upsample(S, y, de + "ppm.%d.2" % i, LEAKY, cp, self.PPMCAT.ch(2048 + 256 * i, 256))
+                base += s * s
         u1 = self.buf("u1a", H8, W8, 256)
         cp = self.conv(S, self.PPMCAT, de + "conv_up1.0", u1, pad=1)
         self.gn(S, u1, de + "conv_up1.1", LEAKY, conv_p=cp)

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3 = 0, 1
-ABI_VERSION = 8          # include/otvm_hip.h OTVM_ABI_VERSION
+ABI_VERSION = 9          # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -40,6 +40,12 @@ class PreprocessParams(C.Structure):
                 ("fg_u8", vp), ("bg_u8", vp), ("u8_rgb", i32)]
 
 
+class PpmHeadParams(C.Structure):
+    _fields_ = [("pooled", vp), ("C", i32), ("K_pad", i32), ("Cout", i32),
+                ("w", vp * 4), ("bias", vp * 4), ("gamma", vp * 4), ("beta", vp * 4), ("out", vp * 4),
+                ("out_ld", i32), ("act", i32)]
+
+
 _PROTOS = {
     "otvm_abi_version": (i32, []),
     "otvm_patch_weight_bytes_f16x3": (i64, [i32, i32]),
@@ -59,6 +65,7 @@ _PROTOS = {
     "otvm_upsample_bilinear": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, vp]),
     "otvm_ppm_pool_ws_bytes": (i64, [i32, i32]),
     "otvm_ppm_pool": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
+    "otvm_ppm_head": (i32, [C.POINTER(PpmHeadParams), vp]),
     "otvm_memory_read_ws_bytes": (i64, [i32, i32]),
     "otvm_memory_read": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp), i32, i32, vp, i32, vp, vp]),
     "otvm_bank_slot_bytes_f16x3": (i64, [i32]),

@@ -729,3 +729,41 @@ def test_conv_every_tunable_configuration(G, Cin, Cout, k, stride, dil, H, W, us
         p.tune = (0 + 1) * 16 + 1                              # 256x256 needs Cout >= 256
         assert lib.otvm_conv2d(C.byref(p), G.stream()) != 0
     torch.cuda.synchronize()
+
+
+def test_ppm_head_matches_conv_groupnorm_leakyrelu(G):
+    """otvm_ppm_head: the four PPM heads (FBA/models.py:298-307) in one launch == 1x1 conv + bias -> GroupNorm(32) ->
+    LeakyReLU of every pooled map, with weight standardisation applied by the packer as for every FBA conv."""
+    from oracle.otvm_oracle import standardise_weight
+    from otvm_amd import lib as L
+    lib = L.load()
+    pooled = rnd(50, 2048, seed=300)
+    hp = L.PpmHeadParams()
+    keep, want, outs = [], [], []
+    base = 0
+    for i, s in enumerate((1, 2, 3, 6)):
+        w = rnd(256, 2048, 1, 1, seed=301 + i, scale=0.05)
+        b = rnd(256, seed=311 + i)
+        gamma, beta = 1.0 + 0.1 * rnd(256, seed=321 + i), 0.1 * rnd(256, seed=331 + i)
+        cw = G.pack_weight(w, ws=True)
+        wstd = standardise_weight(w.double())
+        x = pooled[base:base + s * s].t().reshape(1, 2048, s, s).double()
+        y = F.leaky_relu(F.group_norm(F.conv2d(x, wstd, b.double()), 32, gamma.double(), beta.double(), 1e-5), 0.01)
+        want.append(y[0].permute(1, 2, 0).reshape(s * s, 256))
+        out = torch.full((s * s, 256), float("nan"), device=G.DEV)
+        t = [b.to(G.DEV), gamma.to(G.DEV), beta.to(G.DEV)]
+        keep += [cw, out] + t
+        hp.w[i], hp.bias[i], hp.gamma[i], hp.beta[i], hp.out[i] = cw.w.data_ptr(), t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), out.data_ptr()
+        hp.K_pad = cw.K_pad
+        outs.append(out)
+        base += s * s
+    pd = pooled.to(G.DEV)
+    hp.pooled, hp.C, hp.Cout, hp.out_ld, hp.act = pd.data_ptr(), 2048, 256, 256, 2
+    L.check(lib.otvm_ppm_head(C.byref(hp), G.stream()), "ppm_head")
+    torch.cuda.synchronize()
+    for i in range(4):
+        d = float((outs[i].cpu().double() - want[i]).abs().max())
+        # the 1x1 map normalises 8 values per group: a near-zero variance amplifies rounding, hence the looser bound there
+        assert d <= (2e-3 if i == 0 else 2e-5) * max(1.0, float(want[i].abs().max())), (i, d)
+    hp.C = 1024
+    assert lib.otvm_ppm_head(C.byref(hp), G.stream()) != 0
