@@ -29,6 +29,7 @@ FUSE_GN_APPLY = os.environ.get("OTVM_FUSE_GN_APPLY", "1") != "0"
 # (1080p 37.6 vs 37.6 fps, 480p 124.9 vs 123.9, IO pipeline 37.0 vs 36.9), the graphs only cut the host time per frame
 # (6.8 -> 0.9 ms at 480p) -- worth switching on when many processes share few host cores.
 USE_GRAPHS = os.environ.get("OTVM_GRAPHS", "0") != "0"
+PRE_ON_S2 = os.environ.get("OTVM_PRE_ON_S2", "1") != "0"           # preprocess + statistics clear on the second side stream
 FUSE_PPM_HEAD = os.environ.get("OTVM_PPM_HEAD", "1") != "0"       # the four PPM heads in one launch (otvm_ppm_head)
 
 
@@ -408,6 +409,15 @@ class HipEngine:
             ev_m0.record(main)
             side2.wait_event(ev_q)
             side2.wait_event(ev_m0)
+            # the frame's own preprocess (composite, normalised copies for the alpha network and the next memorize) and the
+            # clearing of the GroupNorm statistics need neither encoder: off the launch stream's serial chain
+            if PRE_ON_S2:
+                for t_ in (a, fg, bg):
+                    t_.record_stream(side2)
+                scaled_imgs.record_stream(side2)
+                with torch.cuda.stream(side2):
+                    pl.stats.zero_()
+                self._preprocess_rest(pl, pp, par, scaled_imgs, False, side2.cuda_stream)
             if self.precision == L.PREC_F16X3:
                 if pend is not None:
                     nb, _ = bank_update(self.bank, pend["slot"], pend["first_frame"], pend["memorize"], pend["max_memory_num"])
@@ -426,15 +436,9 @@ class HipEngine:
         # here it opens frame t+1 on the launch stream, concurrently with the query encoder above)
         if pend is not None:
             self._memorize(pend, stream)
-        pl.stats.zero_()
-        pp.scaled_imgs = scaled_imgs.data_ptr()
-        pp.x11, pp.x11_ld = pl.X11.ptr, pl.X11.ld
-        if not use_side:
-            pp.sq, pp.sq_ld = pl.SQ.ptr, pl.SQ.ld
-        smv = pl.SMs[par].ch(16, 8)
-        pp.sm, pp.sm_ld = smv.ptr, smv.ld
-        pp.d80, pp.d80_ld = pl.D80.ptr, pl.D80.ld
-        L.check(lib.otvm_preprocess(C.byref(pp), stream), "preprocess")
+        if not (use_side and PRE_ON_S2):
+            pl.stats.zero_()
+            self._preprocess_rest(pl, pp, par, scaled_imgs, not use_side, stream)
 
         if tri_gt is not None:
             tri_src = tri_gt.to(dev, f32).contiguous()
@@ -496,6 +500,19 @@ class HipEngine:
             raise FloatingPointError("otvm_amd: non-finite alpha at frame %d -- an activation probably left fp16's range on the "
                                      "f16x3 path; rerun with model.precision = 'f32' (exact-fp32 MFMA)" % frame_id)
         return scaled_imgs, tri_out, tri_gt_out, alpha, a
+
+    def _preprocess_rest(self, pl, pp, par, scaled_imgs, with_sq, stream):
+        """otvm_preprocess for everything but (with_sq False) the query encoder's input: the composite returned to the
+        caller, the alpha network's input channels, the next memorize's image channels, the refinement's image channels."""
+        pm = L.PreprocessParams.from_buffer_copy(pp)
+        pm.scaled_imgs = scaled_imgs.data_ptr()
+        pm.x11, pm.x11_ld = pl.X11.ptr, pl.X11.ld
+        if with_sq:
+            pm.sq, pm.sq_ld = pl.SQ.ptr, pl.SQ.ld
+        smv = pl.SMs[par].ch(16, 8)
+        pm.sm, pm.sm_ld = smv.ptr, smv.ld
+        pm.d80, pm.d80_ld = pl.D80.ptr, pl.D80.ld
+        L.check(self.lib.otvm_preprocess(C.byref(pm), stream), "preprocess")
 
     def _memorize(self, pend, stream, tstream=None):
         """STM.memorize of a finished frame + the bank policy (alpha/model.py:466-493), on ``stream``."""
