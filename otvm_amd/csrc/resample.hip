@@ -1,5 +1,6 @@
 // Pooling / resampling kernels on NHWC fp32 (HBM-bound, 16-byte accesses along channels).
 #include "common.h"
+#include <stdlib.h>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -83,6 +84,64 @@ __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __r
         const int64_t pix = (int64_t)oy * Wo + ox;
         if (add) v += *reinterpret_cast<const f32x4*>(add + pix * add_ld + c);
         *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = v;
+    }
+}
+
+// Exact x2 case (every decoder upsampling): output rows 2y+1 and 2y+2 read the same two input rows y, y+1 (weights
+// 0.75/0.25 and 0.25/0.75), likewise the columns, so a thread that loads the 2x2 input cell (y..y+1, x..x+1) of a channel
+// quad ONCE (and normalises it once) produces the four outputs it feeds (+ output row / column 0 from the first cell):
+// 4 gathers and 4 normalisations per 4 outputs instead of 16 -- the general kernel above moves four times the output
+// bytes through the vector-memory path (2.1 GB for the 544x960x256 map).  Same index / weight expressions and the same
+// blend expression per output as the general kernel: bit-identical results.
+__global__ __launch_bounds__(256) void upsample2x_bilinear_kernel(const float* __restrict__ in, int Hi, int Wi, int C, int in_ld,
+                                                                  const float* __restrict__ in_scale,
+                                                                  const float* __restrict__ in_shift, int in_act,
+                                                                  const float* __restrict__ add, int add_ld,
+                                                                  float* __restrict__ out, int out_ld) {
+    const int Q = C >> 2, Ho = 2 * Hi, Wo = 2 * Wi;
+    const int y = blockIdx.y;
+    const int y1 = y + (y < Hi - 1 ? 1 : 0);
+    const float* r0 = in + (int64_t)y * Wi * in_ld;
+    const float* r1 = in + (int64_t)y1 * Wi * in_ld;
+    const unsigned total = (unsigned)Wi * (unsigned)Q;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int x = (int)(i / (unsigned)Q);
+        const int c = (int)(i - (unsigned)x * (unsigned)Q) * 4;
+        const int x1 = x + (x < Wi - 1 ? 1 : 0);
+        f32x4 v00 = *reinterpret_cast<const f32x4*>(r0 + (int64_t)x * in_ld + c);
+        f32x4 v01 = *reinterpret_cast<const f32x4*>(r0 + (int64_t)x1 * in_ld + c);
+        f32x4 v10 = *reinterpret_cast<const f32x4*>(r1 + (int64_t)x * in_ld + c);
+        f32x4 v11 = *reinterpret_cast<const f32x4*>(r1 + (int64_t)x1 * in_ld + c);
+        if (in_scale) {
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(in_scale + c), sb = *reinterpret_cast<const f32x4*>(in_shift + c);
+            v00 = v00 * sa + sb; v01 = v01 * sa + sb; v10 = v10 * sa + sb; v11 = v11 * sa + sb;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v00[j] = otvm_act(v00[j], in_act); v01[j] = otvm_act(v01[j], in_act);
+                v10[j] = otvm_act(v10[j], in_act); v11[j] = otvm_act(v11[j], in_act);
+            }
+        }
+        // output rows fed by this cell: 2y+1, 2y+2 (and 0 from the first cell), columns likewise
+#pragma unroll
+        for (int ry = 0; ry < 3; ++ry) {
+            const int oy = ry == 2 ? 0 : 2 * y + 1 + ry;
+            if ((ry == 2 && y != 0) || oy >= Ho) continue;
+            float fy = ((float)oy + 0.5f) * 0.5f - 0.5f;
+            fy = fy < 0.f ? 0.f : fy;
+            const float ly = fy - (float)(int)fy, hy = 1.f - ly;
+#pragma unroll
+            for (int rx = 0; rx < 3; ++rx) {
+                const int ox = rx == 2 ? 0 : 2 * x + 1 + rx;
+                if ((rx == 2 && x != 0) || ox >= Wo) continue;
+                float fx = ((float)ox + 0.5f) * 0.5f - 0.5f;
+                fx = fx < 0.f ? 0.f : fx;
+                const float lx = fx - (float)(int)fx, hx = 1.f - lx;
+                f32x4 v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+                const int64_t pix = (int64_t)oy * Wo + ox;
+                if (add) v += *reinterpret_cast<const f32x4*>(add + pix * add_ld + c);
+                *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = v;
+            }
+        }
     }
 }
 
@@ -177,6 +236,15 @@ extern "C" int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, in
                  "otvm_upsample_bilinear: channels must be multiples of 4");
     const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
     OTVM_REQUIRE(Ho <= 65535 && (int64_t)Wo * (C / 4) < (1ll << 31), "otvm_upsample_bilinear: output %dx%d too large", Ho, Wo);
+    static const int x2_on = getenv("OTVM_UPSAMPLE2X") ? atoi(getenv("OTVM_UPSAMPLE2X")) : 1;
+    if (x2_on && Ho == 2 * Hi && Wo == 2 * Wi && Hi >= 2 && Wi >= 2) {
+        int bx2 = otvm_ceil_div(Wi * (C / 4), 256);
+        if (bx2 > 64) bx2 = 64;
+        hipLaunchKernelGGL(upsample2x_bilinear_kernel, dim3(bx2, Hi), dim3(256), 0, (hipStream_t)stream, in, Hi, Wi, C, in_ld,
+                           in_scale, in_shift, in_act, add, add_ld, out, out_ld);
+        OTVM_CHECK_LAUNCH("otvm_upsample_bilinear(x2)");
+        return 0;
+    }
     int bx = otvm_ceil_div(Wo * (C / 4), 256);
     if (bx > 64) bx = 64;
     hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(bx, Ho), dim3(256), 0, (hipStream_t)stream, in, Hi, Wi, C, in_ld,
