@@ -202,13 +202,14 @@ def main():
         tot_by = float(sum(b for _, _, _, _, b in prof))
         n = len(prof)
         per_layer = {}
-        for label, f, e0, e1, _ in prof:
-            d = per_layer.setdefault(label, [0.0, 0.0, 0])
-            d[0] += e0.elapsed_time(e1); d[1] += f; d[2] += 1
+        for label, f, e0, e1, by in prof:
+            d = per_layer.setdefault(label, [0.0, 0.0, 0, 0.0])
+            d[0] += e0.elapsed_time(e1); d[1] += f; d[2] += 1; d[3] += by
         worst = sorted(per_layer.items(), key=lambda kv: -kv[1][0])[:8]
         if args.layer_report:
             rows = [dict(layer=k, ms_per_frame=v[0] / nrep, gflop_per_frame=v[1] / nrep / 1e9, launches_per_frame=v[2] / nrep,
-                         tflops=v[1] / (v[0] * 1e-3) / 1e12) for k, v in sorted(per_layer.items(), key=lambda kv: -kv[1][0])]
+                         tflops=v[1] / (v[0] * 1e-3) / 1e12, gbyte_per_frame=v[3] / nrep / 1e9,
+                         tbyte_per_s=v[3] / (v[0] * 1e-3) / 1e12) for k, v in sorted(per_layer.items(), key=lambda kv: -kv[1][0])]
             json.dump(rows, open(args.layer_report, "w"), indent=0)
         achieved = tot_fl / (tot_ms * 1e-3) / 1e12
         # HBM bytes per conv launch from the committed PMC passes of this same command (profiles/, tools/pmc_traffic.py);

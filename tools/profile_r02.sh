@@ -23,6 +23,8 @@ python tools/kernel_stats_md.py $O/ks480/ks_kernel_stats.csv 50 "python bench.py
 python tools/pmc_mfma.py $O/mfma > $O/mfma_busy_1080p.md 2>&1
 python tools/pmc_traffic.py $O/fetch/f_counter_collection.csv $O/write/w_counter_collection.csv 11 > $O/conv_traffic_1080p.json 2>$O/traffic.err
 python tools/frame_timeline.py $O/ks1080/ks_kernel_trace.csv > $O/timeline_1080p.md 2>&1
+python tools/layer_roofline_md.py $O/layers_1080p.json "1920x1080 (bench.py default run)" > $O/layer_roofline_1080p.md 2>&1
+python tools/layer_roofline_md.py $O/layers_480p.json "832x480" > $O/layer_roofline_480p.md 2>&1
 python tools/frame_trace_dump.py $O/ks1080/ks_kernel_trace.csv 13 60 > $O/frame_trace_1080p.txt 2>&1
 python tools/frame_trace_dump.py $O/ks480/ks_kernel_trace.csv 30 25 > $O/frame_trace_480p.txt 2>&1
 hipcc --offload-arch=gfx950 -O3 -w -o /tmp/mfma_probe tools/probes/mfma_probe.hip && /tmp/mfma_probe > $O/mfma_power_ceiling.txt 2>&1
