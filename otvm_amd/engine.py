@@ -1021,7 +1021,7 @@ class FramePlan:
                 g = self.graphs.get(key)
                 if g is None and self._graph_warm.get(key):
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (the IO pipeline) keep issuing copies
                         cs = torch.cuda.current_stream(self.dev).cuda_stream
                         for st in self.steps[key]:
                             rc = st[0](*st[1], cs)
