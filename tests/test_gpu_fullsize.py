@@ -369,3 +369,41 @@ def test_4k_large_input_runs_and_is_deterministic(synth_sd):
     assert float(r1["alpha"].min()) >= 0.0 and float(r1["alpha"].max()) <= 1.0
     assert torch.equal(r1["alpha"], r2["alpha"]) and torch.equal(r1["alpha_u8"], r2["alpha_u8"])
     assert m.memories["frames"] == [0, 1]
+
+
+def test_1080p_free_running_clip_is_bit_reproducible(synth_sd):
+    """Stream hazards at BASELINE size: a 1080p clip matted with the host running ahead of the device (query encoder of the
+    next frame, resident-slot memory read, decoder skip branches and preprocess on side streams, otvm_amd/engine.py) must
+    reproduce, bit for bit, the same clip matted with a device synchronisation after every frame -- including bench.py's
+    cross-check flow (engine.flush() + sync before a frame, which then reads every slot on the side stream).
+    tools/race_stress.py runs the same check for hundreds of repetitions."""
+    from otvm_amd.synth_data import synthetic_clip
+    H, W, T, t_flush = 1080, 1920, 8, 6
+    frames, tri = synthetic_clip(H, W, T, seed=37)
+    dev = torch.device("cuda:0")
+    fr = [torch.from_numpy(frames[t]).to(dev) for t in range(T)]            # uint8 [H,W,3], resident
+    tri_d = torch.from_numpy(tri)[None, None].to(dev)
+    ones = torch.ones(1, 1, 1, H, W, device=dev)
+    m = _model(synth_sd)
+    torch.cuda.synchronize()
+
+    def matte(ready, sync, flush):
+        outs = []
+        for t in range(T):
+            if flush and t == t_flush:
+                m._engine.flush()
+                torch.cuda.synchronize()
+            o = m(ones, fr[t], fr[t], tri_gt=tri_d, first_frame=(t == 0), last_frame=(t == T - 1), memorize=(t % 5 == 0),
+                  max_memory_num=5, _inputs_ready=ready)
+            outs.append(o[3])
+            if sync:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        return torch.stack(outs)
+    # (a flush changes how the bank is grouped into partial launches -- all slots in one group instead of resident + new --
+    # and with it the fp32 summation order of the read: each flow is compared with its own synchronised run)
+    ref = {False: matte(None, True, False), True: matte(None, True, True)}
+    assert float((ref[True] - ref[False]).abs().max()) <= 1e-4
+    for rep in range(3):
+        for ready, flush in ((True, False), (None, False), (True, True)):
+            assert torch.equal(matte(ready, False, flush), ref[flush]), (rep, ready, flush)
