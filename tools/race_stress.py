@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--frames", type=int, default=14)
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--idle-seconds", type=float, default=0.0, help="host sleeps this long before the --flush-at frame (device idle, clocks down), as bench.py's CPU oracle does")
     ap.add_argument("--flush-at", type=int, default=-1, help="bench.py's cross-check flow: engine.flush() + device sync before this frame")
     args = ap.parse_args()
     from otvm_amd.synth_data import disc_trimap
@@ -36,6 +37,9 @@ def main():
             if t == args.flush_at:
                 model._engine.flush()
                 torch.cuda.synchronize()
+                if args.idle_seconds > 0 and not sync:
+                    import time
+                    time.sleep(args.idle_seconds)
             o = model(a, frames[t], frames[t], tri=None, tri_gt=tri, large_input=False,
                       _inputs_ready=(None if t == args.flush_at else ready), **bench.frame_kwargs(t, T, 5, 5))
             outs.append((o[3], o[1]))
