@@ -67,7 +67,12 @@ def build_model(dev, dilate_kernel=12, precision=None):
     return m.to(dev).eval(), sd
 
 
-def frame_kwargs(t, T, skip, max_num):
+def frame_kwargs(t, T, skip, max_num, stress_bank=False):
+    if stress_bank:
+        # BASELINE configs[4] as written ("mem-every-1, growing KV bank"): every frame is memorised and nothing is evicted.
+        # The reference's own rule turns `skip <= 2` into memorize=False (eval.py:188-189) and caps the bank at
+        # MEMORY_MAX_NUM, so this is a stress knob of the build (max_memory_num = T), not reference semantics.
+        return dict(first_frame=(t == 0), last_frame=(t == T - 1), memorize=True, max_memory_num=T)
     return dict(first_frame=(t == 0), last_frame=(t == T - 1), memorize=(t % skip == 0) if skip > 2 else False,
                 max_memory_num=max_num)
 
@@ -85,6 +90,10 @@ def main():
                     help="conv arithmetic: f16x3 = split-fp16 MFMA with fp32-class accuracy (default), f32 = exact-fp32 MFMA")
     ap.add_argument("--layer-report", default=None, help="write the per-layer conv timing table (JSON) to this path")
     ap.add_argument("--tune-report", default=None, help="write the plan-time autotuner's choices (JSON) to this path")
+    ap.add_argument("--stress-bank", action="store_true",
+                    help="BASELINE configs[4] stress variant: memorise EVERY frame, never evict (max_memory_num = T)")
+    ap.add_argument("--per-frame-report", default=None,
+                    help="write per-frame device time (HIP events between frames) and slots read (JSON) to this path")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -105,30 +114,49 @@ def main():
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    dist = None
+    dist, affinity = None, None
     if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run (also exercised with 1 rank)
         import torch.distributed as dist
+        from otvm_amd.dist import init_process_group, pin_rank_affinity
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        init_process_group(dev, rank=rank, world_size=world)      # RCCL ("nccl"); OTVM_DIST_BACKEND=gloo for one-GPU rehearsals
+        affinity = pin_rank_affinity(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
 
     H, W, K, Wm = args.height, args.width, args.steps, args.warmup
     T = Wm + K                                              # frames of the clip: warm-up then timed
     from otvm_amd.synth_data import disc_trimap
     model, sd = build_model(dev, precision=args.precision)
+    if dist is not None and world > 1:
+        # every rank launches rank 0's kernel configurations (identical fp32 summation orders on all ranks): rank 0 builds
+        # and times its plan first, the others adopt its choices before building theirs
+        from otvm_amd.engine import share_tune_cache
+        if rank == 0:
+            model._get_engine().plan(H, W)
+            torch.cuda.synchronize(dev)
+        share_tune_cache(0)
     frames = device_clip(H, W, T, seed=2000 + rank, dev=dev)
     tri = torch.from_numpy(disc_trimap(H, W))[None, None].to(dev)
     a = torch.ones(1, 1, 1, H, W, device=dev)
 
     t_read = {}                                             # frame -> memory slots its segment step read
+    host_issue = [0.0]                                      # seconds the host spent inside model() (launching), all frames
+    frame_ev = {}                                           # frame -> event recorded behind it (--per-frame-report)
+
+    def fkw(t):
+        return frame_kwargs(t, T, args.skip, args.max_num, args.stress_bank)
 
     def run_frames(t0, t1, sink=None):
         for t in range(t0, t1):
             # _inputs_ready: the clip is resident in HBM and complete before the timed region starts (the bench contract),
             # so the query encoder of frame t may start while frame t-1's alpha network is still executing
-            out = model(a, frames[t], frames[t], tri=None, tri_gt=tri, large_input=False, _inputs_ready=True,
-                        **frame_kwargs(t, T, args.skip, args.max_num))
+            h0 = time.perf_counter()
+            out = model(a, frames[t], frames[t], tri=None, tri_gt=tri, large_input=False, _inputs_ready=True, **fkw(t))
+            host_issue[0] += time.perf_counter() - h0
             t_read[t] = model._engine.last_T_read
+            if args.per_frame_report:
+                frame_ev[t] = torch.cuda.Event(enable_timing=True)
+                frame_ev[t].record()
             if sink is not None:
                 sink.append(out[3])
         return out
@@ -142,17 +170,28 @@ def main():
     # ---- warm-up (first frame: plan build, allocations; then W-1 steady frames)
     run_frames(0, Wm)
     sync_all()
+    host_issue[0] = 0.0
     t_start = time.perf_counter()
     out = run_frames(Wm, T)
     sync_all()
     elapsed = time.perf_counter() - t_start
     alpha_last = out[3]
+    host_issue_s = host_issue[0]
 
+    per_rank = None
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        # per-rank view (diagnosis of a scaling run): each rank's own time and the host time it spent issuing launches
+        from otvm_amd.dist import reduce_device
+        rdev = reduce_device(dev)
+        mine = torch.tensor([elapsed, host_issue_s], dtype=torch.float64, device=rdev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [dict(rank=i, seconds=float(v[0]), frames_per_sec=K / float(v[0]), host_issue_ms_per_frame=1000.0 * float(v[1]) / K)
+                    for i, v in enumerate(allr)]
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
-        frames_total = torch.tensor([float(K), 1.0], dtype=torch.float64, device=dev)
+        frames_total = torch.tensor([float(K), 1.0], dtype=torch.float64, device=rdev)
         dist.all_reduce(frames_total, op=dist.ReduceOp.SUM)
         total_frames, ranks_seen = float(frames_total[0]), int(frames_total[1])
     else:
@@ -176,17 +215,30 @@ def main():
         "steps": K, "warmup": Wm, "ms_per_step": 1000.0 * elapsed / K, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "f32" if eng.precision_name == "f32" else "f16x3 (fp32 operands split into fp16 hi+lo, fp32 accumulate)",
         "data": "synthetic",
-        "config": {"workload": "synthetic %dx%d clip, T=%d frames (warmup %d + timed %d), memory every %d, max %d slots, "
-                               "trimap propagation + alpha + memorize per frame, one sequence per GPU" %
-                               (W, H, T, Wm, K, args.skip, args.max_num),
+        "config": {"workload": ("synthetic %dx%d clip, T=%d frames (warmup %d + timed %d), %s, "
+                                "trimap propagation + alpha + memorize per frame, one sequence per GPU" %
+                                (W, H, T, Wm, K, "EVERY frame memorised, no eviction (growing bank: build stress knob, "
+                                 "BASELINE configs[4])" if args.stress_bank else
+                                 "memory every %d, max %d slots" % (args.skip, args.max_num))),
                    "padded": [Hp, Wp], "weights": "synthetic (otvm_amd.synth_weights seed 0)",
                    "parallelism": "sequence-per-gpu x%d" % world,
                    "T_read_timed_frames": {"mean": sum(timed_T) / float(K), "histogram": hist}},
         "ranks_seen": ranks_seen,
+        "host_issue_ms_per_frame": 1000.0 * host_issue_s / K,
+        "graphs": bool(__import__("otvm_amd.engine", fromlist=["graphs_wanted"]).graphs_wanted(model._engine.use_graphs, Hp * Wp)),
         "algorithmic_tflop_per_frame": flops_frame / 1e12,
         "achieved_tflops_whole_frame": flops_frame / 1e12 / (elapsed / K),
         "alpha_checksum": float(alpha_last.double().mean()),
     }
+
+    if per_rank is not None:
+        result["per_rank"] = per_rank
+        result["cpu_affinity_rank0"] = affinity
+    if args.per_frame_report and rank == 0:
+        ts = sorted(frame_ev)
+        rows = [dict(frame=t, slots_read=t_read[t], ms=frame_ev[ts[i - 1]].elapsed_time(frame_ev[t]))
+                for i, t in enumerate(ts) if i > 0 and t >= Wm]
+        json.dump(dict(workload=result["config"]["workload"], padded=[Hp, Wp], hw=hw, frames=rows), open(args.per_frame_report, "w"), indent=0)
 
     if rank == 0 and not args.no_roofline:          # (N > 1: the other ranks wait in the final barrier)
         # instrumented replay of a window of steady-state frames: HIP events around each conv launch
@@ -263,7 +315,7 @@ def main():
                      s["v"].t.reshape(hw, 512).t().reshape(512, Hp // 16, Wp // 16).cpu().contiguous(), s["frame"])
                     for s in eng.bank]
         fa, ff, ft = a.cpu(), frames[t_s].cpu(), tri.cpu()
-        kw_s = frame_kwargs(t_s, T, args.skip, args.max_num)
+        kw_s = fkw(t_s)
         bank_before, cap = list(orc.bank), {}
         c0 = time.perf_counter()
         ref = orc.frame(fa, ff, ff.clone(), tri_gt=ft, frame_id=t_s, capture=cap, **kw_s)
@@ -277,11 +329,15 @@ def main():
         cls_h = pl.CLS.reshape(pl.Hp, pl.Wp).cpu().long()
         flips = cls_h != cap["cls"]
         ties, gap = int(flips.sum()), 0.0
+        TIE_TOL = 2e-3                                      # the parity tests' near-tie bound (tests/test_gpu_fullsize.py)
         if ties:
             top2 = torch.sort(cap["tri_in"][0], dim=0, descending=True)[0]
             gap = float((top2[0] - top2[1])[flips].max())
-            orc.bank = bank_before
-            ref = orc.frame(fa, ff, ff.clone(), tri_gt=ft, frame_id=t_s, class_override=cls_h, **kw_s)
+            if gap <= TIE_TOL:
+                orc.bank = bank_before
+                ref = orc.frame(fa, ff, ff.clone(), tri_gt=ft, frame_id=t_s, class_override=cls_h, **kw_s)
+            # else: a class flipped at a pixel that is NOT a near-tie in the oracle -- a genuine trimap / argmax error on the
+            # device must not be aligned away: the raw difference stays the reported value
         diag = None
         if float((hip[3].cpu() - ref[3]).abs().max()) > 1e-3 or os.environ.get("OTVM_BENCH_FORCE_DIAG"):
             # should never happen (tests/ assert <= 1e-3 on this very flow): leave the per-stage differences in the record
@@ -308,6 +364,7 @@ def main():
             "seconds_per_frame": cpu_s,
             "alpha_maxabs_hip_vs_cpu_same_frame": float((hip[3].cpu() - ref[3]).abs().max()),
             "trimap_argmax_tie_breaks": ties, "tie_break_top2_gap_max": gap,
+            "tie_breaks_aligned": bool(ties and gap <= TIE_TOL), "tie_gap_bound": TIE_TOL,
             "alpha_maxabs_before_tie_alignment": d_raw,
         }
         if diag is not None:

@@ -35,11 +35,12 @@ extern "C" {
 #define OTVM_PREC_F16X3 1
 
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 9    /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
+#define OTVM_ABI_VERSION 10   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
                                  4: otvm_conv_params.splitk_ws; 5: otvm_preprocess_params.fg_u8/bg_u8/u8_rgb;
                                  6: otvm_conv_params.tune + otvm_conv2d_candidates;
                                  7: folded GroupNorm tables on otvm_gn_apply's residual and otvm_upsample_bilinear's input;
-                                 8: otvm_memory_read_f16x3_partial / _combine / _partial_count; 9: otvm_ppm_head */
+                                 8: otvm_memory_read_f16x3_partial / _combine / _partial_count; 9: otvm_ppm_head;
+                                 10: otvm_finite_guard, otvm_clear */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -267,6 +268,16 @@ int otvm_onehot_argmax3(const float* tri, int64_t P, float* out, void* stream);
  * caller-zeroed) accumulates  sum|p-t|m, sum(p-t)^2 m, sum m, sum((p-p')-(t-t'))^2 m', sum m'  -- integer-exact. */
 int otvm_matting_metrics(const uint8_t* pred, const uint8_t* target, const uint8_t* mask, const uint8_t* prev_pred,
                          const uint8_t* prev_target, const uint8_t* prev_mask, int64_t n, double* acc, void* stream);
+
+/* ---------------------------------------------------------------- range guard / clear -----------
+ * f16x3 splits fp32 operands into fp16 halves: |x| >= 65504 loses accuracy, >= 131008 becomes inf.
+ * otvm_finite_guard scans an NHWC view [P, C] (ld) and stores min(*flag, tag) when any element fails |x| < limit
+ * (NaN fails too); *flag is initialised to INT32_MAX by the caller and read by the host when it synchronises.  The
+ * engine runs it on everything that survives a frame: the memorised key / value maps (STM.py:201-228), the hidden
+ * state and the propagated trimap logits (alpha/model.py:432-471).                                               */
+int otvm_finite_guard(const float* x, int64_t P, int C, int ld, float limit, int tag, int* flag, void* stream);
+/* stream-ordered zero fill (hipMemsetAsync) -- the GroupNorm statistics arena is cleared once per frame           */
+int otvm_clear(void* p, int64_t bytes, void* stream);
 
 #ifdef __cplusplus
 }

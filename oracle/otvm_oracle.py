@@ -108,15 +108,35 @@ def up(x, scale=None, size=None):
     return F.interpolate(x, scale_factor=scale, size=size, mode="bilinear", align_corners=False)
 
 
-def memory_read(keys, vals, q_key, q_val):
-    """STM.py:144-163.  keys [128, T, h, w], vals [512, T, h, w], q_key [128, h, w], q_val [512, h, w]."""
-    De = keys.shape[0]
-    mi = torch.transpose(keys.reshape(1, De, -1), 1, 2)  # [1, THW, De]
-    qi = q_key.reshape(1, De, -1)                        # [1, De, HW]
-    p = torch.bmm(mi, qi) / math.sqrt(De)
-    p = F.softmax(p, dim=1)                              # over the memory axis
-    mo = vals.reshape(1, vals.shape[0], -1)              # [1, Do, THW]
-    mem = torch.bmm(mo, p).reshape(vals.shape[0], *q_val.shape[1:])
+def memory_read(keys, vals, q_key, q_val, dtype=None, max_bytes=1 << 30):
+    """STM.py:144-163.  keys [128, T, h, w], vals [512, T, h, w], q_key [128, h, w], q_val [512, h, w].
+
+    The reference materialises p = softmax(K^T Q / sqrt(128)) over the memory axis as one [T*h*w, h*w] matrix.  Every
+    query column of that matrix is independent (the softmax runs over dim 1, the memory axis), so when the matrix would
+    exceed ``max_bytes`` the same expression is evaluated for blocks of query columns -- identical arithmetic per column,
+    bounded memory (a 4K frame with three slots is 12.8 GB in fp32, several live copies; 200 slots do not fit anywhere).
+    dtype (e.g. torch.float64): evaluate this stage in that precision and return the inputs' dtype -- the tests use it at
+    sizes where the fp32 bmm + softmax over ~1e5 memory positions is itself ~1e-3 away from the exact value."""
+    De, Do = keys.shape[0], vals.shape[0]
+    out_dtype = vals.dtype
+    cd = out_dtype if dtype is None else dtype
+    mi = torch.transpose(keys.reshape(1, De, -1), 1, 2).to(cd)   # [1, THW, De]
+    qi = q_key.reshape(1, De, -1).to(cd)                          # [1, De, HW]
+    mo = vals.reshape(1, Do, -1).to(cd)                           # [1, Do, THW]
+    thw, hw = mi.shape[1], qi.shape[2]
+    esz = torch.empty((), dtype=cd).element_size()
+    if thw * hw * esz <= max_bytes:
+        p = torch.bmm(mi, qi) / math.sqrt(De)
+        p = F.softmax(p, dim=1)                                   # over the memory axis
+        mem = torch.bmm(mo, p)
+    else:
+        step = max(64, int(max_bytes // (thw * esz)) // 64 * 64)
+        mem = torch.empty((1, Do, hw), dtype=cd)
+        for c0 in range(0, hw, step):
+            p = torch.bmm(mi, qi[:, :, c0:c0 + step]) / math.sqrt(De)
+            p = F.softmax(p, dim=1)
+            mem[:, :, c0:c0 + step] = torch.bmm(mo, p)
+    mem = mem.reshape(Do, *q_val.shape[1:]).to(out_dtype)
     return torch.cat([mem, q_val], dim=0)
 
 
@@ -141,7 +161,7 @@ def bank_update(bank, new, first_frame, memorize, max_memory_num):
 
 # --------------------------------------------------------------------------- the model
 class OtvmOracle:
-    def __init__(self, state_dict, dilate_kernel=None, threads=None, dtype=torch.float32):
+    def __init__(self, state_dict, dilate_kernel=None, threads=None, dtype=torch.float32, read_dtype=None):
         """dtype=torch.float64 evaluates the SAME operations in double precision (the distance encoding keeps the
         reference's float32 arithmetic, it is part of the definition): the tests use it to measure how far the
         reference's own fp32 forward is from the exact value of its algorithm on a given frame -- the summation-order
@@ -149,6 +169,10 @@ class OtvmOracle:
         if threads:
             torch.set_num_threads(threads)
         self.dtype = dtype
+        # read_dtype=torch.float64: only Memory.forward (the softmax over T*h*w memory positions, the one stage whose fp32
+        # CPU evaluation drifts ~1e-3 from the exact value at 1080p / 4K bank sizes) is evaluated in double precision; every
+        # other stage stays in ``dtype``.  A full float64 frame costs 4x the CPU time, this costs a few seconds.
+        self.read_dtype = read_dtype
         self.p = {k: v.detach().to(dtype) if v.is_floating_point() else v.detach() for k, v in state_dict.items()}
         self.dilate_kernel = dilate_kernel
         self.ws = {}
@@ -310,7 +334,7 @@ class OtvmOracle:
         v4 = self.conv(r4, "trimap.model.KV_Q_r4.Value", 1, 1)
         keys = torch.stack([b[0] for b in bank], dim=1)
         vals = torch.stack([b[1] for b in bank], dim=1)
-        m4 = memory_read(keys, vals, k4[0], v4[0])[None]
+        m4 = memory_read(keys, vals, k4[0], v4[0], dtype=self.read_dtype)[None]
         logits = self.stm_decoder(m4, r3, r2)
         if capture is not None:
             capture.update(r4=r4, r3=r3, r2=r2, k4=k4, v4=v4, m4=m4, seg_logits=logits)

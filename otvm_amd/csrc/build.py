@@ -23,6 +23,7 @@ SOURCES = [
     ("memory_read.hip", []),
     ("memory_read_f16x3.hip", []),
     ("metrics.hip", []),
+    ("guard.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -34,6 +34,50 @@ def self_launch_command(n_gpus, env, device_count, script, argv, python=None, po
             "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
 
 
+def dist_backend():
+    """"nccl" (= RCCL over xGMI on ROCm) unless OTVM_DIST_BACKEND says otherwise.  "gloo" exists for rehearsing the
+    multi-rank path where RCCL cannot run: several ranks sharing ONE GPU (RCCL refuses two ranks on a device) or CPU
+    tests.  The only collectives of the path are the final metric reductions (tens of bytes), so the backend does not
+    matter for throughput."""
+    import os
+    return os.environ.get("OTVM_DIST_BACKEND", "nccl")
+
+
+def init_process_group(device=None, **kw):
+    import torch.distributed as dist
+    backend = dist_backend()
+    if backend == "nccl" and device is not None:
+        kw.setdefault("device_id", device)
+    dist.init_process_group(backend, **kw)
+    return backend
+
+
+def reduce_device(device):
+    """Where the metric accumulators live for the all-reduce: the rank's GPU under RCCL, the host under gloo."""
+    return device if dist_backend() == "nccl" else "cpu"
+
+
+def pin_rank_affinity(local_rank, local_world, cpus=None):
+    """Give this rank (and every thread it starts afterwards: the IO pipeline's decode / encode pools, torch's intra-op pool)
+    its own contiguous share of the node's cores.  Eight ranks of a node each issue ~320 launches per frame from one Python
+    thread next to 8 IO threads; unpinned they migrate across sockets and contend for the same cores.  Returns the cpu list
+    (None when the platform has no sched_setaffinity or there are fewer cores than ranks)."""
+    import os
+    if local_world <= 1 or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = sorted(os.sched_getaffinity(0)) if cpus is None else sorted(cpus)
+    share = len(cpus) // local_world
+    if share < 1:
+        return None
+    mine = cpus[local_rank * share:(local_rank + 1) * share]
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return None
+    torch.set_num_threads(max(1, min(share, torch.get_num_threads())))
+    return mine
+
+
 def shard_sequences(n_sequences, rank, world, lengths=None):
     """Indices of the sequences rank ``rank`` processes.  With ``lengths`` (frames per sequence) the split is
     longest-first greedy (balanced frame counts); otherwise round-robin."""
@@ -83,7 +127,7 @@ def run_sharded(sequences, matte_fn, rank=0, world=1, device="cpu", reference_fn
                 d = (out["alpha"].float().cpu() - ref.float().cpu()).abs()
                 sad += float(d.sum()) / 1000.0                      # utils/tmp/metric.py:177-182
                 maxabs = max(maxabs, float(d.max()))
-    if torch.cuda.is_available() and str(device).startswith("cuda"):
+    if torch.cuda.is_available():                               # (device may be "cpu" when the reduction runs over gloo)
         torch.cuda.synchronize()
     secs = time.perf_counter() - t0
     # ground-truth metrics accumulated on the device by video.ClipMetrics (sequences run with gt_alpha_u8)
@@ -107,6 +151,14 @@ def run_sharded(sequences, matte_fn, rank=0, world=1, device="cpu", reference_fn
     sad_g, frames_g, secs_sum = red[:3]
     summary = dict(sad=sad_g, frames=frames_g, gpu_seconds=secs_sum, wall_seconds=wall_g, max_abs=maxabs_g,
                    fps=frames_g / wall_g if wall_g > 0 else 0.0, sequences=mine, outputs=outputs)
+    # who matted what (rank -> sequence indices), identical on every rank: the partition is part of the report
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        shards = [None] * dist.get_world_size()
+        dist.all_gather_object(shards, mine)
+        summary["shards"] = shards
+    else:
+        summary["shards"] = [mine]
     g = dict(zip(keys, red[3:]))
     if g["frames"] > 0:
         # per-frame means as utils/tmp/metric.py reports them (SAD /1000 per frame; MSE over evaluated pixels)

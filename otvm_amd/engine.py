@@ -21,6 +21,8 @@ import torch
 from . import lib as L
 
 NONE, RELU, LEAKY = 0, 1, 2
+GUARD_CLEAR = 2 ** 31 - 1      # value of the range-guard flag while nothing was flagged (otvm_finite_guard keeps the minimum tag)
+F16_LIMIT = 65504.0
 FUSE_GN_STATS = True       # GroupNorm statistics accumulated in the producing conv's epilogue
 # GroupNorm apply folded into the staging of the ONLY consumer when that is a patch conv (the normalised tensor is never
 # written: refinement BasicBlocks at full resolution, FBA layer1); OTVM_FUSE_GN_APPLY=0 keeps the separate pass
@@ -28,7 +30,21 @@ FUSE_GN_APPLY = os.environ.get("OTVM_FUSE_GN_APPLY", "1") != "0"
 # OTVM_GRAPHS=1: static launch lists replayed as hipGraphs.  Off by default: every configuration measured is GPU-bound
 # (1080p 37.6 vs 37.6 fps, 480p 124.9 vs 123.9, IO pipeline 37.0 vs 36.9), the graphs only cut the host time per frame
 # (6.8 -> 0.9 ms at 480p) -- worth switching on when many processes share few host cores.
-USE_GRAPHS = os.environ.get("OTVM_GRAPHS", "0") != "0"
+# Round 3: "auto" (OTVM_GRAPHS unset) replays graphs when the host is the scarce resource -- several ranks share this node's
+# cores (WORLD_SIZE > 1: eight ranks issuing ~320 launches per frame each from Python), or the frame is so small that the
+# host's issue time (6-7 ms) is of the order of the device time (padded frame below 2^20 pixels: 480p runs 7 ms frames).
+_GRAPHS_ENV = os.environ.get("OTVM_GRAPHS")
+USE_GRAPHS = None if _GRAPHS_ENV in (None, "", "auto") else (_GRAPHS_ENV != "0")
+GRAPH_AUTO_PIXELS = 1 << 20
+
+
+def graphs_wanted(setting, padded_pixels):
+    """Resolve engine.use_graphs (True / False / None = auto) for a plan of ``padded_pixels``."""
+    if setting is not None:
+        return bool(setting)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return True
+    return padded_pixels < GRAPH_AUTO_PIXELS
 PRE_ON_S2 = os.environ.get("OTVM_PRE_ON_S2", "1") != "0"           # preprocess + statistics clear on the second side stream
 FUSE_PPM_HEAD = os.environ.get("OTVM_PPM_HEAD", "1") != "0"       # the four PPM heads in one launch (otvm_ppm_head)
 
@@ -44,22 +60,61 @@ TUNE_LOG = []           # (signature, chosen code, {code: ms}) of every shape ti
 # OTVM_TUNE_FILE=path: choices are loaded from / saved to a JSON file, so a later process (a profiler run, a service
 # restart) launches the tuned configurations without timing anything.
 TUNE_FILE = os.environ.get("OTVM_TUNE_FILE")
+_TUNE_FILE_LOADED = False
+
+
+def _tune_file_tag():
+    """What a tune file is valid for: the chip and the library ABI (choices timed on another chip, or for another set of
+    kernels, must not be applied silently)."""
+    name = torch.cuda.get_device_name(torch.cuda.current_device()) if torch.cuda.is_available() else "none"
+    return {"device": name, "abi": L.ABI_VERSION}
 
 
 def _load_tune_file():
-    if TUNE_FILE and os.path.exists(TUNE_FILE):
-        import json
-        for k, v in json.load(open(TUNE_FILE)).items():
+    """Never raises: a missing, truncated or foreign file is ignored with a warning (the shapes are timed again)."""
+    if not (TUNE_FILE and os.path.exists(TUNE_FILE)):
+        return
+    import json
+    import warnings
+    try:
+        doc = json.load(open(TUNE_FILE))
+        if not isinstance(doc, dict) or "choices" not in doc:
+            raise ValueError("no 'choices' table (file written by an older build)")
+        tag = _tune_file_tag()
+        if doc.get("abi") != tag["abi"] or (tag["device"] != "none" and doc.get("device") != tag["device"]):
+            raise ValueError("tuned for %r / ABI %r, this process runs %r / ABI %r"
+                             % (doc.get("device"), doc.get("abi"), tag["device"], tag["abi"]))
+        for k, v in doc["choices"].items():
             _TUNE_CACHE[tuple(json.loads(k))] = int(v)
+    except Exception as e:                                       # noqa: BLE001 -- any defect of the file means "not usable"
+        warnings.warn("otvm_amd: ignoring OTVM_TUNE_FILE=%s (%s)" % (TUNE_FILE, e))
 
 
 def _save_tune_file():
-    if TUNE_FILE:
-        import json
-        json.dump({json.dumps([int(x) for x in k]): v for k, v in _TUNE_CACHE.items()}, open(TUNE_FILE, "w"), indent=0)
+    """Atomic (temp file + rename): ranks of one --gpus N run share the environment and may save concurrently."""
+    if not TUNE_FILE:
+        return
+    import json
+    doc = dict(_tune_file_tag())
+    doc["choices"] = {json.dumps([int(x) for x in k]): v for k, v in _TUNE_CACHE.items()}
+    tmp = "%s.%d.tmp" % (TUNE_FILE, os.getpid())
+    with open(tmp, "w") as f:
+        json.dump(doc, f, indent=0)
+    os.replace(tmp, TUNE_FILE)
 
 
-_load_tune_file()
+def share_tune_cache(src=0):
+    """Multi-rank runs: every rank adopts rank ``src``'s choices (broadcast over the initialised process group), so all
+    ranks launch identical kernel configurations -- identical fp32 summation orders -- and a clip's alpha does not depend
+    on the rank that matted it.  Call it after ``src`` has built the plans of the resolutions in play (bench.py, eval_cli)
+    and before the other ranks build theirs.  No-op without a process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    obj = [dict(_TUNE_CACHE) if dist.get_rank() == src else None]
+    dist.broadcast_object_list(obj, src=src)
+    if dist.get_rank() != src:
+        _TUNE_CACHE.update(obj[0])
 
 
 def _rup(x, m):
@@ -216,8 +271,24 @@ class HipEngine:
         # f16x3 splits fp32 operands into fp16 halves: an activation beyond fp16's range (|x| >= 65504) becomes inf and
         # then NaN, silently, and would live on in the recurrent memory bank.  OTVM_CHECK_FINITE=1 checks every frame's
         # alpha (one device sync per frame) and raises; meant for the first run of a new checkpoint.
-        self.check_finite = os.environ.get("OTVM_CHECK_FINITE", "0") != "0"
+        # Round 3: the guard is ON by default in its cheap form (level 1): otvm_finite_guard scans what survives a frame --
+        # the key / value maps entering the bank, the hidden state, the propagated trimap logits -- with |x| < 65504 and
+        # records the first offending frame in a device flag; the host looks at the flag when it synchronises anyway
+        # (last_frame, flush) and through a non-blocking copy every few frames.  Level 2 also synchronises and checks alpha
+        # after every frame; level 3 additionally scans the input and output of every convolution (first run of a new
+        # checkpoint); 0 switches everything off.
+        self.check_level = int(os.environ.get("OTVM_CHECK_FINITE", "1") or 0)
+        self.check_finite = self.check_level >= 2
+        self.guard_flag = torch.full((1,), GUARD_CLEAR, dtype=torch.int32, device=self.dev)
+        self._guard_host = torch.full((1,), GUARD_CLEAR, dtype=torch.int32).pin_memory()
+        self._guard_ev = None
+        self._guard_what = {}
         self.use_graphs = USE_GRAPHS
+        global _TUNE_FILE_LOADED
+        if not _TUNE_FILE_LOADED:
+            _TUNE_FILE_LOADED = True
+            with torch.cuda.device(self.dev):
+                _load_tune_file()
         self._pack_all()
 
     # ------------------------------------------------------------------ weights
@@ -275,6 +346,47 @@ class HipEngine:
         self._pack(e + "stem", wcat, scale=scale, bias=bias, i_pad=24)
         torch.cuda.synchronize(self.dev)
 
+    # ------------------------------------------------------------------ range guard (f16x3 operands must stay in fp16 range)
+    def guard(self, act, what, stream, tag=None):
+        """Enqueue a scan of the NHWC view ``act`` (|x| < 65504, NaN fails) on ``stream``; level 0 = nothing."""
+        if self.check_level <= 0:
+            return
+        tag = self.frame_counter - 1 if tag is None else tag
+        # the exact-fp32 path has no range limit: only inf / NaN fail there
+        limit = F16_LIMIT if self.precision == L.PREC_F16X3 else float("inf")
+        L.check(self.lib.otvm_finite_guard(act.ptr, act.P, act.C, act.ld, limit, max(int(tag), 0),
+                                           self.guard_flag.data_ptr(), stream), "finite_guard " + what)
+
+    def _guard_raise(self, frame):
+        self.guard_flag.fill_(GUARD_CLEAR)
+        self._guard_host.fill_(GUARD_CLEAR)
+        self._guard_ev = None
+        raise FloatingPointError(
+            "otvm_amd: a value outside fp16's range (|x| >= 65504, inf or NaN) reached the recurrent state (memorised key / "
+            "value, hidden state or propagated trimap logits) at frame %d of the sequence: the f16x3 path splits fp32 operands "
+            "into fp16 halves and cannot represent it.  Everything from that frame on is invalid.  Rerun with "
+            "model.precision = 'f32' (exact-fp32 MFMA, no range limit), or OTVM_CHECK_FINITE=3 to find the layer." % frame)
+
+    def guard_check(self, sync):
+        """sync: read the flag now (one device synchronisation; the caller is about to synchronise anyway).  Otherwise look
+        at the last non-blocking copy, if it has landed, and start a new one every 8 frames."""
+        if self.check_level <= 0:
+            return
+        if sync:
+            v = int(self.guard_flag.item())
+            if v != GUARD_CLEAR:
+                self._guard_raise(v)
+            return
+        if self._guard_ev is not None and self._guard_ev.query():
+            self._guard_ev = None
+            v = int(self._guard_host[0])
+            if v != GUARD_CLEAR:
+                self._guard_raise(v)
+        if self._guard_ev is None and self.frame_counter % 8 == 0:
+            self._guard_host.copy_(self.guard_flag, non_blocking=True)
+            self._guard_ev = torch.cuda.Event()
+            self._guard_ev.record(torch.cuda.current_stream(self.dev))
+
     # ------------------------------------------------------------------ plans
     def plan(self, H, W):
         key = (H, W)
@@ -308,6 +420,10 @@ class HipEngine:
         Returns the reference's 5-tuple (scaled_imgs, preds_trimap, tri_gt, preds_alpha, scaled_gts)."""
         dev, lib = self.dev, self.lib
         f32 = torch.float32
+        main = torch.cuda.current_stream(dev)
+        if isinstance(inputs_ready, torch.cuda.Event):
+            main.wait_event(inputs_ready)                     # before anything below (a conversion, too) reads the inputs
+        a_in, fg_in, bg_in = a, fg, bg
         a = a.to(dev, f32).contiguous()
         u8 = fg.dtype == torch.uint8
         if u8:
@@ -322,6 +438,11 @@ class HipEngine:
             fg = fg.to(dev, f32).contiguous()
             bg = bg.to(dev, f32).contiguous()
             H, W = int(fg.shape[-2]), int(fg.shape[-1])
+        if inputs_ready is not None and (a is not a_in or fg is not fg_in or bg is not bg_in):
+            # an input was converted / copied just now BY THE LAUNCH STREAM (host tensor, other dtype, non-contiguous): the
+            # caller's promise covers the tensor it passed, not this copy -- the side streams must order themselves behind
+            # the launch stream (the conservative path), or the query encoder would read the copy before it is written
+            inputs_ready = None
         if a.dim() != 5 or a.shape[0] != 1 or a.shape[1] != 1 or tuple(a.shape[-2:]) != (H, W):
             raise ValueError("otvm_amd: inputs must be [1,1,C,H,W] (batch 1, one frame), got a %s for %dx%d frames"
                              % (tuple(a.shape), H, W))
@@ -344,13 +465,13 @@ class HipEngine:
         if frame_id is None:                                  # position in the sequence since the last first_frame
             frame_id = self.frame_counter
         self.frame_counter += 1
+        self.guard_check(sync=False)
         pend, self.pending = self.pending, None
         if pend is not None and pend["plan"] is not pl:
             self._memorize(pend, stream)                      # resolution changed: finish it in order
             pend = None
         par = self.parity
         self.parity ^= 1
-        main = torch.cuda.current_stream(dev)
         pp = L.PreprocessParams()
         pp.a = a.data_ptr()
         if u8:
@@ -377,8 +498,7 @@ class HipEngine:
             if self.ev_dec is not None:
                 side.wait_event(self.ev_dec)
             if isinstance(inputs_ready, torch.cuda.Event):
-                side.wait_event(inputs_ready)
-                main.wait_event(inputs_ready)
+                side.wait_event(inputs_ready)                # (the launch stream waited at the top of the call)
             elif inputs_ready is not True:                   # unknown producer: everything issued so far on the launch stream
                 ev_in = torch.cuda.Event()
                 ev_in.record(main)
@@ -415,8 +535,7 @@ class HipEngine:
                 for t_ in (a, fg, bg):
                     t_.record_stream(side2)
                 scaled_imgs.record_stream(side2)
-                with torch.cuda.stream(side2):
-                    pl.stats.zero_()
+                pl.clear_stats(side2.cuda_stream)
                 self._preprocess_rest(pl, pp, par, scaled_imgs, False, side2.cuda_stream)
             if self.precision == L.PREC_F16X3:
                 if pend is not None:
@@ -430,14 +549,12 @@ class HipEngine:
             pl.run("segment_skip", side2.cuda_stream, side2)
             ev_s2 = torch.cuda.Event()
             ev_s2.record(side2)
-        elif isinstance(inputs_ready, torch.cuda.Event):
-            main.wait_event(inputs_ready)
         # ---- deferred memorize of the previous frame (reference order: memorize(t) ends frame t, alpha/model.py:461-493;
         # here it opens frame t+1 on the launch stream, concurrently with the query encoder above)
         if pend is not None:
             self._memorize(pend, stream)
         if not (use_side and PRE_ON_S2):
-            pl.stats.zero_()
+            pl.clear_stats(stream)
             self._preprocess_rest(pl, pp, par, scaled_imgs, not use_side, stream)
 
         if tri_gt is not None:
@@ -455,6 +572,10 @@ class HipEngine:
         if first_frame:
             L.check(lib.otvm_pad_trimap(tri_src.data_ptr(), H, W, pl.PROBS.data_ptr(), pl.Hp, pl.Wp, pl.lh, pl.lw, stream),
                     "pad_trimap")
+            # frame 1's query encoder (side stream) is ordered behind everything the launch stream was handed up to here:
+            # loop-invariant inputs the caller created for this clip (the trimap flow's constant alpha) are complete
+            self.ev_dec = torch.cuda.Event()
+            self.ev_dec.record(main)
         else:
             if ev_q is not None:
                 main.wait_event(ev_q)
@@ -482,11 +603,13 @@ class HipEngine:
                 e1.record()
                 self.prof.append(("memory_read", 1280.0 * len(self.bank) * pl.hw * pl.hw, e0, e1, len(self.bank)))
             pl.run("segment_b", stream)
+            self.guard(pl.L4, "propagated trimap logits", stream, frame_id)
             self.ev_dec = torch.cuda.Event()                  # the query encoder's buffers are free again
             self.ev_dec.record(main)
         pl.encode(stream, cls_override)
         pl.run("fba", stream)
         pl.run("fba_tail%d" % par, stream)
+        self.guard(pl.SMs[par].ch(0, 16), "hidden state", stream, frame_id)
         if not last_frame:
             slot = pl.new_slot()
             slot["frame"] = frame_id
@@ -499,6 +622,10 @@ class HipEngine:
         if self.check_finite and not bool(torch.isfinite(alpha).all()):
             raise FloatingPointError("otvm_amd: non-finite alpha at frame %d -- an activation probably left fp16's range on the "
                                      "f16x3 path; rerun with model.precision = 'f32' (exact-fp32 MFMA)" % frame_id)
+        if last_frame or self.check_finite:
+            # end of the clip: the caller synchronises to collect its results -- the guard's verdict for the whole clip is
+            # read here (the reference's loop synchronises after every frame, eval.py:195-197)
+            self.guard_check(sync=True)
         return scaled_imgs, tri_out, tri_gt_out, alpha, a
 
     def _preprocess_rest(self, pl, pp, par, scaled_imgs, with_sq, stream):
@@ -537,6 +664,7 @@ class HipEngine:
         if pend is not None:
             with torch.cuda.device(self.dev):
                 self._memorize(pend, self._stream())
+                self.guard_check(sync=True)
 
     def _consts(self, key):
         c = getattr(self, "_const_cache", None)
@@ -623,12 +751,14 @@ class FramePlan:
             return
         # realistic operand values while timing (zero-filled operands run the matrix cores at an unrepresentative power)
         filled = []
+        gen = torch.Generator(device=self.dev)                 # a private generator: the caller's global RNG stream is not consumed
+        gen.manual_seed(0x07F3)
         for b in self._bufs.values():
             t = b.t if isinstance(b, Act) else b
             if not t.is_floating_point():
                 continue
             if t.dtype == torch.float32:
-                t.normal_()
+                t.normal_(generator=gen)
             else:
                 continue
             filled.append(t)
@@ -647,6 +777,10 @@ class FramePlan:
             t.zero_()
         self.stats.zero_()
         torch.cuda.synchronize(self.dev)
+
+    def clear_stats(self, stream):
+        """Zero the GroupNorm statistics arena for the coming frame (library call on ``stream``, no ATen launch)."""
+        L.check(self.lib.otvm_clear(self.stats.data_ptr(), self.stats.numel() * 8, stream), "clear GroupNorm statistics")
 
     # ---- buffers
     def buf(self, name, H, W, C):
@@ -674,7 +808,7 @@ class FramePlan:
         flops = 2 * Ho * Wo * w.O * w.kh * w.kw * w.I           # algorithmic (un-padded) 2*MAC
         # algorithmic bytes: read the input once, the weights once, write the output once (+ residual read), fp32
         abytes = 4 * (x.H * x.W * w.I + w.O * w.I * w.kh * w.kw + Ho * Wo * w.O * (2 if residual is not None else 1))
-        S.append((self.lib.otvm_conv2d, (C.byref(p),), "conv " + wname, flops, abytes))
+        S.append((self.lib.otvm_conv2d, (C.byref(p),), "conv " + wname, flops, abytes, (x, out.ch(0, _rup(w.O, 4)) if out.C >= _rup(w.O, 4) else out)))
         return p
 
     def gn(self, S, x, name, act, out=None, residual=None, conv_p=None, res_norm=None):
@@ -1016,8 +1150,23 @@ class FramePlan:
         frame become a handful of graph launches (host time per frame 6.8 -> 0.9 ms at 480p; no throughput change, every
         measured configuration is GPU-bound).  Opt-in: OTVM_GRAPHS=1 or engine.use_graphs = True."""
         prof = self.e.prof
+        if prof is None and self.e.check_level >= 3:
+            # first run of a new checkpoint: scan the input and the output of every convolution
+            for st in self.steps[key]:
+                if st[2].startswith("conv "):
+                    self.e.guard(st[5][0], "input of " + st[2], stream)
+                rc = st[0](*st[1], stream)
+                if rc != 0:
+                    L.check(rc, st[2])
+                if st[2].startswith("conv "):
+                    self.e.guard(st[5][1], "output of " + st[2], stream)
+                    v = int(self.e.guard_flag.item())
+                    if v != GUARD_CLEAR:
+                        self.e.guard_flag.fill_(GUARD_CLEAR)
+                        raise FloatingPointError("otvm_amd: |x| >= 65504 (or inf / NaN) at the %s, frame %d" % (st[2], v))
+            return
         if prof is None:
-            if self.e.use_graphs:
+            if graphs_wanted(self.e.use_graphs, self.P):
                 g = self.graphs.get(key)
                 if g is None and self._graph_warm.get(key):
                     g = torch.cuda.CUDAGraph()
@@ -1136,6 +1285,8 @@ class FramePlan:
             if prof is not None:
                 e1.record()
                 prof.append((st[2], st[3], e0, e1, st[4]))
+        self.e.guard(slot["k"], "memorised key", stream, slot["frame"])
+        self.e.guard(slot["v"], "memorised value", stream, slot["frame"])
         if "packed" in slot:
             L.check(self.lib.otvm_bank_pack_f16x3(slot["k"].ptr, slot["v"].ptr, self.hw, slot["packed"].data_ptr(), stream),
                     "bank_pack")

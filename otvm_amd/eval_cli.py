@@ -37,6 +37,7 @@ def main(argv=None):
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3"])
     ap.add_argument("--gpus", type=int, default=None, help="start this many ranks, one per GPU (default: the launcher's)")
     ap.add_argument("--sync-io", action="store_true", help="write PNGs synchronously in the frame loop (as eval.py does)")
+    ap.add_argument("--summary-json", default=None, help="rank 0 writes the reduced summary (frames, fps, metrics, shards) here")
     args = ap.parse_args(argv)
     from PIL import Image
     from . import helpers
@@ -52,11 +53,18 @@ def main(argv=None):
         raise SystemExit(subprocess.call(cmd))
 
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
-    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("OTVM_DIST_BACKEND", "nccl") != "nccl":
+        local_rank %= max(1, torch.cuda.device_count())     # gloo rehearsal: more ranks than GPUs share the devices round-robin
+    dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        # one process per GPU, RCCL for the final metric reduction; OTVM_DIST_BACKEND=gloo rehearses the multi-rank path with
+        # several ranks on ONE GPU (RCCL refuses that).  Each rank -- its launch thread and the IO pools it starts -- gets
+        # its own share of the node's cores.
+        from .dist import init_process_group, pin_rank_affinity
+        init_process_group(dev)
+        pin_rank_affinity(int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("LOCAL_WORLD_SIZE", world)))
     dk = {"narrow": 5, "medium": 12, "wide": 20}[args.trimap]              # eval.py:67-72
     cfg = helpers.default_cfg()
     model = helpers.get_model_alpha(cfg, helpers.get_model_trimap(cfg, "Test", dk), "Test", dk)
@@ -76,6 +84,22 @@ def main(argv=None):
     items = list(ds)
     seqs = [dict(name=it[6], frames=it[2][:args.max_frames], item=it) for it in items]   # paths: sharding by length
     root_out = os.path.join(args.out, "alpha", "test", helpers.get_model_name(cfg))
+    if world > 1:
+        # every rank must launch the same kernel configurations, or a clip's alpha (fp32 summation order) would depend on
+        # the rank that got it: rank 0 builds -- and times -- the plans of all resolutions in the data set, the others adopt
+        # its choices (engine.share_tune_cache) before they build theirs
+        from .engine import share_tune_cache
+        if rank == 0:
+            sizes = set()
+            for sq in seqs:
+                if sq["frames"]:
+                    with Image.open(os.path.join(sq["item"][1], sq["frames"][0])) as im:
+                        sizes.add((im.height, im.width))
+            eng = model.module._get_engine()
+            for (h_, w_) in sorted(sizes):
+                eng.plan(h_, w_)
+            torch.cuda.synchronize(dev)
+        share_tune_cache(0)
 
     def matte(seq):
         demo = seq["item"][0] == "demo"
@@ -115,7 +139,15 @@ def main(argv=None):
                                os.path.join(args.out, "viz", "test", helpers.get_model_name(cfg), "viz",
                                             seq["name"].replace("/", "_") + ".mp4"))
         return res
-    summary = run_sharded(seqs, matte, rank=rank, world=world, device=dev)
+    from .dist import reduce_device
+    summary = run_sharded(seqs, matte, rank=rank, world=world, device=reduce_device(dev) if world > 1 else dev)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and args.summary_json:
+        import json
+        json.dump({k: v for k, v in summary.items() if k != "outputs"}, open(args.summary_json, "w"), indent=0)
     if rank == 0:
         print("done | %d frames | %.2f frames/s over %d GPU(s)" % (summary["frames"], summary["fps"], world))
         if "gt_metrics" in summary:

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3 = 0, 1
-ABI_VERSION = 9          # include/otvm_hip.h OTVM_ABI_VERSION
+ABI_VERSION = 10         # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -84,6 +84,8 @@ _PROTOS = {
     "otvm_trimap_from_alpha": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "otvm_onehot_argmax3": (i32, [vp, i64, vp, vp]),
     "otvm_matting_metrics": (i32, [vp, vp, vp, vp, vp, vp, i64, vp, vp]),
+    "otvm_finite_guard": (i32, [vp, i64, i32, i32, f32, i32, vp, vp]),
+    "otvm_clear": (i32, [vp, i64, vp]),
 }
 
 EXPORTED = sorted(list(_PROTOS) + ["otvm_last_error"])

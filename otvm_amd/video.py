@@ -86,10 +86,20 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
             ready = getattr(f, "_otvm_ready", None)           # upload event of the IO pipeline's prefetcher
             fg = f.to(dev, non_blocking=True)
             bg = fg if b is None else b.to(dev, non_blocking=True)
+            if b is not None and getattr(b, "_otvm_ready", None) is not None:
+                torch.cuda.current_stream(dev).wait_event(b._otvm_ready)
             H, W = fg.shape[:2]
             extra["_frames_rgb"] = bool(frames_are_rgb)
-            if ready is not None and b is None and fg is f:
-                extra["_inputs_ready"] = ready
+            if ready is not None:
+                # the upload event may only travel to the model (whose query-encoder stream then starts on it, ahead of the
+                # launch stream) when EVERYTHING the preprocess reads is covered by it or loop-invariant: the frame itself
+                # (no copy made here), no separately uploaded background, and the trimap flow's constant alpha -- a per-frame
+                # alpha is written by the launch stream just below.  Otherwise the launch stream waits for the upload
+                # and the model orders its side streams behind the launch stream.
+                if b is None and fg is f and trimap is not None:
+                    extra["_inputs_ready"] = ready
+                else:
+                    torch.cuda.current_stream(dev).wait_event(ready)
         else:
             f = f.to(dev).float()
             if frames_are_rgb:

@@ -104,17 +104,23 @@ def test_1080p_two_frames_vs_oracle(synth_sd):
         assert m.memories["frames"] == [b[2] for b in orc.bank]
 
 
-def test_1080p_steady_state_frame_vs_oracle(synth_sd):
+@pytest.mark.parametrize("seed,full_f64", [(23, True), (41, False), (59, False)], ids=["seed23-f64", "seed41", "seed59"])
+def test_1080p_steady_state_frame_vs_oracle(synth_sd, seed, full_f64):
     """BASELINE configs[2] in its steady state (memory every 5, max 5 slots): the HIP path free-runs frames 0..20 -- all
     five slots filled, one eviction done (bank read by frame 21 = [0, 9, 14, 19, 20]) -- then frame 21 is
     compared with the oracle, whose bank is seeded from the device slots (a CPU frame is ~30 s at this size, so the
     oracle cannot free-run 21 of them).  Checks alpha (<= 1e-3 against the float64 evaluation of the reference algorithm,
     <= 1e-3 + the fp32 oracle's own rounding distance against the fp32 oracle), the propagated trimap, T_read = 5 and the
-    bank after the frame's own update."""
+    bank after the frame's own update.
+
+    Three clip seeds (VERDICT r2: the margin under 1e-3 was measured on one).  Seed 23 keeps the full float64 arbitration;
+    the other two compare with the fp32 oracle whose Memory.forward alone is evaluated in float64 (``read_dtype``: the
+    softmax over 40 800 memory positions is the stage whose fp32 CPU evaluation is ~1e-3 from its exact value) and assert
+    the plain 1e-3 bound with no slack."""
     from oracle.otvm_oracle import OtvmOracle
     from otvm_amd.synth_data import synthetic_clip
     H, W, T, t_s = 1080, 1920, 24, 21
-    frames, tri = synthetic_clip(H, W, t_s + 1, seed=23)
+    frames, tri = synthetic_clip(H, W, t_s + 1, seed=seed)
     m = _model(synth_sd)
     flags = lambda t: dict(first_frame=(t == 0), last_frame=(t == T - 1), memorize=(t % 5 == 0), max_memory_num=5)
     for t in range(t_s):
@@ -126,14 +132,18 @@ def test_1080p_steady_state_frame_vs_oracle(synth_sd):
     assert [s["frame"] for s in eng.bank] == [0, 9, 14, 19, 20]
     pl = eng.last_plan
     hw, h16, w16 = pl.hw, pl.Hp // 16, pl.Wp // 16
-    orc = OtvmOracle(synth_sd, dilate_kernel=12)
+    orc = OtvmOracle(synth_sd, dilate_kernel=12, read_dtype=None if full_f64 else torch.float64)
     orc.bank = [(s["k"].t.reshape(hw, 128).t().reshape(128, h16, w16).cpu().contiguous(),
                  s["v"].t.reshape(hw, 512).t().reshape(512, h16, w16).cpu().contiguous(), s["frame"]) for s in eng.bank]
-    import torch as _t
-    orc64 = OtvmOracle(synth_sd, dilate_kernel=12, dtype=_t.float64)
-    orc64.bank = [(k.double(), v.double(), f) for k, v, f in orc.bank]
+    orc64 = None
+    if full_f64:
+        orc64 = OtvmOracle(synth_sd, dilate_kernel=12, dtype=torch.float64)
+        orc64.bank = [(k.double(), v.double(), f) for k, v, f in orc.bank]
     a, fg, tg = _clip_tensors(frames, tri, t_s, H, W)
-    out, ref, d, ties = _frame_vs_oracle(m, orc, a, fg, tg, t_s, flags(t_s), "1080p steady state (T_read=5)", orc64=orc64)
+    out, ref, d, ties = _frame_vs_oracle(m, orc, a, fg, tg, t_s, flags(t_s),
+                                         "1080p steady state (T_read=5, seed %d%s)" % (seed, "" if full_f64 else ", float64 memory read in the oracle"),
+                                         orc64=orc64)
+    print("1080p steady state seed %d: margin under the 1e-3 bound %.3e" % (seed, 1e-3 - d))
     assert m.memories["frames"] == [b[2] for b in orc.bank] == [0, 9, 14, 19, 21]
 
 
@@ -313,16 +323,14 @@ def test_distance_encoding_properties_1080p(G):
 def test_4k_growing_bank_frame_vs_oracle(synth_sd):
     """BASELINE configs[4], the unbounded-bank stress variant (memory every frame, no eviction) at 3840x2160: the HIP path
     free-runs frames 0..2 (three memorised 2176x3840 slots, 97 920 memory positions), the oracle's bank is seeded from the
-    device slots and frame 3 is compared (alpha <= 1e-3, tie-break protocol, bank ids).  The oracle materialises the
-    [97 920, 32 640] affinity matrix (12.8 GB, several live copies) and takes minutes, so the test runs only when asked for
-    (OTVM_TEST_4K_ORACLE=1) on a host with >= 150 GB of free memory; profiles/r02_4k_growing_bank_vs_oracle.log holds the
-    last run."""
+    device slots and frame 3 is compared (alpha <= 1e-3, tie-break protocol, bank ids).
+
+    Round 3: runs in the default suite.  The oracle's Memory.forward evaluates the [97 920, 32 640] affinity matrix in
+    blocks of query columns (oracle.memory_read: same arithmetic per column, < 1 GB live instead of 12.8 GB x several
+    copies) and in float64 (``read_dtype``): with ~1e5 memory positions the fp32 bmm + softmax of the CPU evaluation is
+    itself 1.6e-3 away from the exact value (profiles/r02_4k_growing_bank_vs_oracle.log), every other stage stays fp32.
+    The bound against it is the plain 1e-3.  OTVM_TEST_4K_ORACLE=1 adds the full-float64 frame (~8 minutes of CPU)."""
     import os
-    import psutil
-    if os.environ.get("OTVM_TEST_4K_ORACLE", "0") == "0":
-        pytest.skip("set OTVM_TEST_4K_ORACLE=1 (several minutes of CPU oracle, ~100 GB of host memory)")
-    if psutil.virtual_memory().available < 150 * (1 << 30):
-        pytest.skip("needs >= 150 GB of free host memory for the oracle's affinity matrix")
     from oracle.otvm_oracle import OtvmOracle
     from otvm_amd.synth_data import synthetic_clip
     H, W, T, t_s = 2160, 3840, 6, 3
@@ -339,15 +347,15 @@ def test_4k_growing_bank_frame_vs_oracle(synth_sd):
     pl = eng.last_plan
     hw, h16, w16 = pl.hw, pl.Hp // 16, pl.Wp // 16
     assert (pl.Hp, pl.Wp, hw) == (2176, 3840, 32640)
-    orc = OtvmOracle(synth_sd, dilate_kernel=12)
+    orc = OtvmOracle(synth_sd, dilate_kernel=12, read_dtype=torch.float64)
     orc.bank = [(s["k"].t.reshape(hw, 128).t().reshape(128, h16, w16).cpu().contiguous(),
                  s["v"].t.reshape(hw, 512).t().reshape(512, h16, w16).cpu().contiguous(), s["frame"]) for s in eng.bank]
-    # the float64 evaluation arbitrates, as in the 1080p steady-state test: with 97 920 memory positions the fp32 CPU
-    # evaluation is itself ~1e-3 away from the exact value
-    orc64 = OtvmOracle(synth_sd, dilate_kernel=12, dtype=torch.float64)
-    orc64.bank = [(k.double(), v.double(), f) for k, v, f in orc.bank]
+    orc64 = None
+    if os.environ.get("OTVM_TEST_4K_ORACLE", "0") != "0":
+        orc64 = OtvmOracle(synth_sd, dilate_kernel=12, dtype=torch.float64)
+        orc64.bank = [(k.double(), v.double(), f) for k, v, f in orc.bank]
     a, fg, tg = _clip_tensors(frames, tri, t_s, H, W)
-    _frame_vs_oracle(m, orc, a, fg, tg, t_s, flags(t_s), "4K growing bank (T_read=3)", orc64=orc64)
+    _frame_vs_oracle(m, orc, a, fg, tg, t_s, flags(t_s), "4K growing bank (T_read=3, float64 memory read in the oracle)", orc64=orc64)
     assert m.memories["frames"] == [b[2] for b in orc.bank] == [0, 1, 2, 3]
 
 

@@ -1,0 +1,96 @@
+"""GPU (-m gpu): the sharded multi-rank path EXECUTED on a GPU (BASELINE configs[3] in miniature).
+
+configs[3] shards VideoMatting108's 48 validation sequences over the 8 GPUs of a node, one process per GPU, RCCL for the
+final metric all-reduce (otvm_amd/dist.py, reference eval.py:42,80 runs one device per process).  The builder's GPU box
+has ONE GPU and RCCL refuses two ranks on a device, so the same code path is rehearsed with the collective backend
+switched to gloo (OTVM_DIST_BACKEND=gloo: the only collectives are the final metric reductions and the tune-cache
+broadcast) and both ranks on cuda:0: `torch.distributed.run --nproc-per-node 2 -m otvm_amd.eval_cli` over a small
+V108-layout tree.  Checked: the shard partition (longest-first greedy), every rank's PNGs are byte-for-byte the PNGs of a
+single-rank run of the same command, and the reduced ground-truth metrics equal the single-rank ones.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _v108_tree(root, lengths, H=64, W=96):
+    from PIL import Image
+    from otvm_amd.synth_data import soft_alpha, synthetic_clip
+    v = os.path.join(root, "VideoMatting108")
+    os.makedirs(v)
+    corr, names = {}, []
+    for i, T in enumerate(lengths):
+        fg, _ = synthetic_clip(H, W, T, seed=100 + i)
+        bg, _ = synthetic_clip(H, W, T, seed=200 + i)
+        clip = "vid%d/clip_0" % i
+        names.append(clip)
+        for t in range(T):
+            a = np.rint(soft_alpha(H, W, t + i) * 255).astype(np.uint8)
+            k = "%s/%05d.png" % (clip, t)
+            corr[k] = "bgs%d/%05d.jpg" % (i, t)
+            os.makedirs(os.path.dirname(os.path.join(v, "FG_done", k)), exist_ok=True)
+            Image.fromarray(np.concatenate([fg[t][..., ::-1], a[..., None]], -1)).save(os.path.join(v, "FG_done", k))
+            os.makedirs(os.path.join(v, "BG_done2", "bgs%d" % i), exist_ok=True)
+            Image.fromarray(bg[t][..., ::-1].copy()).save(os.path.join(v, "BG_done2", "bgs%d" % i, "%05d.png" % t))
+    json.dump(corr, open(os.path.join(v, "frame_corr.json"), "w"))
+    open(os.path.join(v, "val_videos.txt"), "w").write("\n".join(names) + "\n")
+    return names
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_ranks_on_one_gpu_through_eval_cli(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from PIL import Image
+    from otvm_amd.dist import shard_sequences
+    lengths = [4, 2, 3]
+    root = os.path.join(str(tmp_path), "data")
+    os.makedirs(root)
+    names = _v108_tree(root, lengths)
+    env = dict(os.environ)
+    env["OTVM_TUNE_FILE"] = os.path.join(str(tmp_path), "tune.json")   # both runs launch the same kernel configurations
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    common = ["--data", root, "--synthetic-weights", "--skip", "3", "--trimap", "narrow"]
+    out1, out2 = os.path.join(str(tmp_path), "out1"), os.path.join(str(tmp_path), "out2")
+    j1, j2 = os.path.join(str(tmp_path), "s1.json"), os.path.join(str(tmp_path), "s2.json")
+    r = subprocess.run([sys.executable, "-m", "otvm_amd.eval_cli"] + common + ["--out", out1, "--summary-json", j1],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    env2 = dict(env)
+    env2["OTVM_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), "-m", "otvm_amd.eval_cli"] + common +
+                       ["--out", out2, "--summary-json", j2], cwd=ROOT, env=env2, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    s1, s2 = json.load(open(j1)), json.load(open(j2))
+    # the partition: longest-first greedy over frame counts (dist.shard_sequences), every sequence exactly once
+    assert s2["shards"] == [shard_sequences(3, 0, 2, lengths), shard_sequences(3, 1, 2, lengths)] == [[0], [1, 2]]
+    assert s1["shards"] == [[0, 1, 2]]
+    assert s1["frames"] == s2["frames"] == sum(lengths)
+    # every rank's PNGs == the single-rank run's
+    for clip, T in zip(names, lengths):
+        for t in range(T):
+            rel = os.path.join("alpha", "test", "s4_OTVM", "pred", clip, "%05d.png" % t)
+            a1, a2 = np.asarray(Image.open(os.path.join(out1, rel))), np.asarray(Image.open(os.path.join(out2, rel)))
+            assert a1.shape == (64, 96) and np.array_equal(a1, a2), rel
+    # reduced ground-truth metrics (integer-exact fp64 sums on the device, SUM all-reduce over the ranks) == single rank
+    g1, g2 = s1["gt_metrics"], s2["gt_metrics"]
+    assert g1["frames"] == g2["frames"] == sum(lengths)
+    for k in ("sad", "mse", "mse_mean", "dtssd_mean", "dtssd_sum_err2", "dtssd_mask_sum"):
+        assert abs(g1[k] - g2[k]) <= 1e-12 * max(1.0, abs(g1[k])), (k, g1[k], g2[k])
+    assert s2["fps"] > 0

@@ -338,3 +338,57 @@ def test_viz_panels_match_reference_write_image():
         grid_ref = make_grid_u8(ref, nrow=2)
         assert int(np.abs(grid.astype(np.int32) - grid_ref.astype(np.int32)).max()) <= 1     # 1e-6 around a rounding edge
         assert (grid != grid_ref).mean() < 1e-3
+
+
+def test_tune_file_is_robust_and_tagged(tmp_path, monkeypatch):
+    """OTVM_TUNE_FILE: a truncated or foreign file is ignored with a warning instead of making the package
+    unimportable, saves are atomic (temp + rename) and carry the device / ABI they were timed for."""
+    import json
+    import warnings
+    from otvm_amd import engine, lib
+    path = str(tmp_path / "tune.json")
+    monkeypatch.setattr(engine, "TUNE_FILE", path)
+    monkeypatch.setattr(engine, "_TUNE_CACHE", {})
+    open(path, "w").write('{"choices": {"[1, 2')                     # truncated by a concurrent writer
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        engine._load_tune_file()
+    assert engine._TUNE_CACHE == {} and any("ignoring OTVM_TUNE_FILE" in str(x.message) for x in w)
+    engine._TUNE_CACHE[(1, 2, 3)] = 35
+    engine._save_tune_file()
+    doc = json.load(open(path))
+    assert doc["abi"] == lib.ABI_VERSION and "device" in doc and doc["choices"] == {"[1, 2, 3]": 35}
+    assert [f for f in os.listdir(str(tmp_path)) if f.endswith(".tmp")] == []
+    engine._TUNE_CACHE.clear()
+    engine._load_tune_file()
+    assert engine._TUNE_CACHE == {(1, 2, 3): 35}
+    doc["abi"] = lib.ABI_VERSION - 1                                  # timed for another set of kernels
+    json.dump(doc, open(path, "w"))
+    engine._TUNE_CACHE.clear()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        engine._load_tune_file()
+    assert engine._TUNE_CACHE == {} and any("ignoring OTVM_TUNE_FILE" in str(x.message) for x in w)
+
+
+def test_rank_affinity_and_graph_policy(monkeypatch):
+    """8-rank readiness: each rank gets a contiguous share of the cores; hipGraph replay switches itself
+    on when several ranks share the host or the frame is small, unless OTVM_GRAPHS decides."""
+    from otvm_amd import dist as D
+    from otvm_amd import engine
+    calls = []
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: calls.append(list(cpus)), raising=False)
+    cpus = list(range(4, 36))                                        # 32 cores visible to the job
+    assert D.pin_rank_affinity(0, 8, cpus) == [4, 5, 6, 7] and D.pin_rank_affinity(7, 8, cpus) == [32, 33, 34, 35]
+    assert calls == [[4, 5, 6, 7], [32, 33, 34, 35]]
+    assert D.pin_rank_affinity(0, 1, cpus) is None                   # single rank: untouched
+    assert D.pin_rank_affinity(3, 64, cpus) is None                  # fewer cores than ranks: untouched
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    assert engine.graphs_wanted(None, 1088 * 1920) is False and engine.graphs_wanted(None, 480 * 832) is True
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    assert engine.graphs_wanted(None, 1088 * 1920) is True
+    assert engine.graphs_wanted(False, 480 * 832) is False and engine.graphs_wanted(True, 1088 * 1920) is True
+    monkeypatch.delenv("OTVM_DIST_BACKEND", raising=False)
+    assert D.dist_backend() == "nccl" and D.reduce_device("cuda:3") == "cuda:3"
+    monkeypatch.setenv("OTVM_DIST_BACKEND", "gloo")
+    assert D.dist_backend() == "gloo" and D.reduce_device("cuda:3") == "cpu"

@@ -141,3 +141,21 @@ def test_metrics_oracle_vs_reference(ops):
     e, n = M.dtssd(p, t, m)
     np.testing.assert_allclose(e.numpy(), ops["met_dt_err"], rtol=1e-6)
     np.testing.assert_allclose(n.numpy(), ops["met_dt_num"], rtol=0)
+
+
+def test_memory_read_query_blocks_equal_one_matrix():
+    """oracle.memory_read in blocks of query columns (used when the [T*hw, hw] matrix would not fit: 4K banks) is the same
+    function as the one-matrix evaluation of STM.py:144-163, and its float64 variant agrees with fp32 to fp32 rounding."""
+    import torch
+    from oracle.otvm_oracle import memory_read
+    g = torch.Generator().manual_seed(5)
+    T, h, w = 3, 9, 23
+    keys, vals = torch.randn(128, T, h, w, generator=g), torch.randn(512, T, h, w, generator=g)
+    qk, qv = torch.randn(128, h, w, generator=g), torch.randn(512, h, w, generator=g)
+    one = memory_read(keys, vals, qk, qv)
+    blk = memory_read(keys, vals, qk, qv, max_bytes=64 * T * h * w * 4)          # 64 query columns per block
+    assert one.shape == blk.shape == (1024, h, w)
+    assert float((one - blk).abs().max()) <= 2e-6
+    f64 = memory_read(keys, vals, qk, qv, dtype=torch.float64, max_bytes=64 * T * h * w * 8)
+    assert f64.dtype == torch.float32 and float((one - f64).abs().max()) <= 2e-5
+    assert torch.equal(one[512:], qv) and torch.equal(f64[512:], qv)
