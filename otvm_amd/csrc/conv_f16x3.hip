@@ -21,6 +21,15 @@
 #ifndef OTVM_PF_DEPTH
 #define OTVM_PF_DEPTH 3
 #endif
+#ifndef OTVM_PFS_SMALL
+#define OTVM_PFS_SMALL 6
+#endif
+#ifndef OTVM_PFS_MID
+#define OTVM_PFS_MID 4
+#endif
+#ifndef OTVM_PFS_LARGE
+#define OTVM_PFS_LARGE 3
+#endif
 #ifndef OTVM_BRANCHY_LOADS
 #define OTVM_BRANCHY_LOADS 1
 #endif
@@ -136,7 +145,16 @@ void conv_igemm_f16x3_kernel(const Conv3Args p) {
     // register sets of chunks in flight (global -> registers -> LDS).  The 256x128 tile uses ~155 of its 256 VGPRs: three
     // sets = three chunks of loads under way, because with ONE workgroup per CU a chunk's MFMA time (0.7 us) is well
     // below the L2-miss latency and the K loop otherwise runs at one memory round trip per chunk
-    constexpr int PF = (DBUF && BN == 128) ? OTVM_PF_DEPTH : 1;
+    // Round 3: the single-stage tiles (small maps: OS8 / OS16 layers, the whole 480p frame) ran their K loop at ONE memory
+    // round trip per chunk -- the next chunk's loads were issued behind the store of the current one, and with one or two
+    // workgroups of 4 waves on a CU nothing else hides an L2 / HBM access (25 us launches for 1.8 GFLOP).  They now keep a
+    // ring of register sets as well: the loads of chunk c + PF are issued while chunk c is computed.  A set is small here
+    // (64x64: 16 VGPRs, 128x64: 24, 128x128: 32, 256x64: 40), the accumulators are 16-64 VGPRs.
+    constexpr int SETREGS = 4 * A_LD + 8 * B_LD;
+    constexpr int PFS = (BM * BN == 32768 && WM * WN == 4) ? 1 :                  // 4-wave 256x128 / 128x256: 128 VGPRs, no room
+                        (SETREGS <= 16 ? OTVM_PFS_SMALL : SETREGS <= 24 ? OTVM_PFS_MID : SETREGS <= 32 ? OTVM_PFS_LARGE : 2);
+    constexpr int PF = DBUF ? (BN == 128 ? OTVM_PF_DEPTH : 1) : PFS;
+    constexpr bool BRANCHY = OTVM_BRANCHY_LOADS && (DBUF || PFS == 1);
     struct RegSet {
         f32x4 ra[A_LD];
         unsigned okmask;            // bit i: ra[i] holds image data (else padding -> zero)
@@ -145,7 +163,9 @@ void conv_igemm_f16x3_kernel(const Conv3Args p) {
     RegSet rs[PF];
 #pragma unroll
     for (int j = 0; j < PF; ++j) rs[j].okmask = 0;
-    auto load_chunk = [&](int c, RegSet& R) __attribute__((always_inline)) {
+    // valid == false (ring tiles past the last chunk): the same loads are issued against harmless addresses -- element 0 of
+    // the input, the last weight chunk -- so that EVERY path through the K loop issues the same number of loads per step
+    auto load_chunk = [&](int c, RegSet& R, const bool valid = true) __attribute__((always_inline)) {
         f32x4 (&ra)[A_LD] = R.ra;
         unsigned& okmask = R.okmask;
         f16x8 (&rbh)[B_LD] = R.rbh;
@@ -160,12 +180,16 @@ void conv_igemm_f16x3_kernel(const Conv3Args p) {
                 // vmcnt(0) in the middle of the pipeline (guide 5, trap (c)).
                 // The zeroing (and the optional ReLU) happen in store_chunk, NOT here: touching the loaded value
                 // now would put the s_waitcnt in front of the MFMAs and serialise load latency with compute.
-                const bool ok = (tapmask[i] & bit) != 0;
-#if OTVM_BRANCHY_LOADS
-                if (ok) ra[i] = *reinterpret_cast<const f32x4*>(p.in + (int64_t)(rowoff[i] + delta));
-#else
-                ra[i] = *reinterpret_cast<const f32x4*>(p.in + (int64_t)(ok ? rowoff[i] + delta : 0));
-#endif
+                const bool ok = valid && (tapmask[i] & bit) != 0;
+                // The big double-buffered tiles skip the load of a padding lane (exec-masked load: the unconditional
+                // form cost 40 % on the full-resolution layers).  The ring-prefetch tiles must NOT: a branch around a load
+                // makes the number of loads in flight unknown to the compiler's waitcnt pass, which then drains vmcnt(0)
+                // once per turn of the ring instead of waiting for the one set it stores (seen in the ISA).
+                if (BRANCHY) {
+                    if (ok) ra[i] = *reinterpret_cast<const f32x4*>(p.in + (int64_t)(rowoff[i] + delta));
+                } else {
+                    ra[i] = *reinterpret_cast<const f32x4*>(p.in + (int64_t)(ok ? rowoff[i] + delta : 0));
+                }
                 okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));
             }
             // K order of the split weights in the fast path: channel-block major, taps inner, so the taps of one
@@ -179,7 +203,7 @@ void conv_igemm_f16x3_kernel(const Conv3Args p) {
             const int ci = kk - tap * p.Cin;
             const int ky = tap / p.kw, kx = tap - ky * p.kw;
             const int dy = ky * p.dil, dx = kx * p.dil;
-            const bool tap_ok = tap < p.taps;
+            const bool tap_ok = valid && tap < p.taps;
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) {
                 const int iy = iy0[i] + dy, ix = ix0[i] + dx;
@@ -188,11 +212,12 @@ void conv_igemm_f16x3_kernel(const Conv3Args p) {
                 okmask = ok ? (okmask | (1u << i)) : (okmask & ~(1u << i));
             }
         }
+        const int cw = valid ? c : c_end - 1;
 #pragma unroll
         for (int i = 0; i < B_LD; ++i) {
             if (BN % B_ROWS == 0 || brow + B_ROWS * i < BN) {
-                rbh[i] = *reinterpret_cast<const f16x8*>(p.wh + woff0 + i * wstep + c * BK);
-                rbl[i] = *reinterpret_cast<const f16x8*>(p.wl + woff0 + i * wstep + c * BK);
+                rbh[i] = *reinterpret_cast<const f16x8*>(p.wh + woff0 + i * wstep + cw * BK);
+                rbl[i] = *reinterpret_cast<const f16x8*>(p.wl + woff0 + i * wstep + cw * BK);
             }
         }
     };
@@ -293,13 +318,23 @@ void conv_igemm_f16x3_kernel(const Conv3Args p) {
         compute_ks(buf, 0);
         compute_ks(buf, 1);
     } else {
-        for (int c = c_begin; c < c_end; ++c) {
-            __syncthreads();
-            store_chunk(0, rs[0]);
-            __syncthreads();
-            if (c + 1 < c_end) load_chunk(c + 1, rs[0]);
-            compute_ks(0, 0);
-            compute_ks(0, 1);
+        // one LDS stage, PF chunks of global loads in flight: chunk c sits in register set (c - c_begin) % PF.  No branch
+        // surrounds a load (chunks past the end are loaded as dummies): with conditional prologue / tail loads the
+        // compiler's waitcnt pass has to merge paths in which a set's load is the newest one in flight and paths in which
+        // PF - 1 sets follow it, and falls back to draining everything once per turn of the ring (seen in the ISA).
+#pragma unroll
+        for (int j = 1; j < PF; ++j) load_chunk(c_begin + j, rs[j], c_begin + j < c_end);
+        for (int c = c_begin; c < c_end; c += PF) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                if (j > 0 && c + j >= c_end) break;
+                __syncthreads();
+                store_chunk(0, rs[j]);
+                __syncthreads();
+                load_chunk(c + j + PF, rs[j], c + j + PF < c_end);
+                compute_ks(0, 0);
+                compute_ks(0, 1);
+            }
         }
     }
 
