@@ -104,7 +104,7 @@ def test_1080p_two_frames_vs_oracle(synth_sd):
         assert m.memories["frames"] == [b[2] for b in orc.bank]
 
 
-@pytest.mark.parametrize("seed,full_f64", [(23, True), (41, False), (59, False)], ids=["seed23-f64", "seed41", "seed59"])
+@pytest.mark.parametrize("seed,full_f64", [(23, None), (41, False), (59, False)], ids=["seed23", "seed41", "seed59"])
 def test_1080p_steady_state_frame_vs_oracle(synth_sd, seed, full_f64):
     """BASELINE configs[2] in its steady state (memory every 5, max 5 slots): the HIP path free-runs frames 0..20 -- all
     five slots filled, one eviction done (bank read by frame 21 = [0, 9, 14, 19, 20]) -- then frame 21 is
@@ -113,12 +113,17 @@ def test_1080p_steady_state_frame_vs_oracle(synth_sd, seed, full_f64):
     <= 1e-3 + the fp32 oracle's own rounding distance against the fp32 oracle), the propagated trimap, T_read = 5 and the
     bank after the frame's own update.
 
-    Three clip seeds (VERDICT r2: the margin under 1e-3 was measured on one).  Seed 23 keeps the full float64 arbitration;
-    the other two compare with the fp32 oracle whose Memory.forward alone is evaluated in float64 (``read_dtype``: the
+    Three clip seeds (the margin under 1e-3 was measured on one).  All three compare with the fp32 oracle whose
+    Memory.forward alone is evaluated in float64; OTVM_TEST_FULL_F64=1 adds round 2's full float64 arbitration on seed 23
+    (measured then: HIP 1.08e-4 from the float64 frame, the all-fp32 oracle 9.1e-4 from it).  The mixed evaluation:
+    the fp32 oracle whose Memory.forward alone is evaluated in float64 (``read_dtype``: the
     softmax over 40 800 memory positions is the stage whose fp32 CPU evaluation is ~1e-3 from its exact value) and assert
     the plain 1e-3 bound with no slack."""
     from oracle.otvm_oracle import OtvmOracle
     from otvm_amd.synth_data import synthetic_clip
+    import os
+    if full_f64 is None:
+        full_f64 = os.environ.get("OTVM_TEST_FULL_F64", "0") != "0"
     H, W, T, t_s = 1080, 1920, 24, 21
     frames, tri = synthetic_clip(H, W, t_s + 1, seed=seed)
     m = _model(synth_sd)
