@@ -21,14 +21,15 @@
 #ifndef OTVM_PF_DEPTH
 #define OTVM_PF_DEPTH 3
 #endif
+// ring depth of the single-stage tiles (see PFS below): measured neutral, default = 1 (no ring)
 #ifndef OTVM_PFS_SMALL
-#define OTVM_PFS_SMALL 6
+#define OTVM_PFS_SMALL 1
 #endif
 #ifndef OTVM_PFS_MID
-#define OTVM_PFS_MID 4
+#define OTVM_PFS_MID 1
 #endif
 #ifndef OTVM_PFS_LARGE
-#define OTVM_PFS_LARGE 3
+#define OTVM_PFS_LARGE 1
 #endif
 #ifndef OTVM_BRANCHY_LOADS
 #define OTVM_BRANCHY_LOADS 1
@@ -145,14 +146,18 @@ void conv_igemm_f16x3_kernel(const Conv3Args p) {
     // register sets of chunks in flight (global -> registers -> LDS).  The 256x128 tile uses ~155 of its 256 VGPRs: three
     // sets = three chunks of loads under way, because with ONE workgroup per CU a chunk's MFMA time (0.7 us) is well
     // below the L2-miss latency and the K loop otherwise runs at one memory round trip per chunk
-    // Round 3: the single-stage tiles (small maps: OS8 / OS16 layers, the whole 480p frame) ran their K loop at ONE memory
-    // round trip per chunk -- the next chunk's loads were issued behind the store of the current one, and with one or two
-    // workgroups of 4 waves on a CU nothing else hides an L2 / HBM access (25 us launches for 1.8 GFLOP).  They now keep a
-    // ring of register sets as well: the loads of chunk c + PF are issued while chunk c is computed.  A set is small here
-    // (64x64: 16 VGPRs, 128x64: 24, 128x128: 32, 256x64: 40), the accumulators are 16-64 VGPRs.
+    // Round 3, measured and rejected: a register-set ring on the single-stage tiles too (the loads of chunk c + PF issued
+    // while chunk c is computed; hypothesis: the small-map layers -- 25 us launches for 1.8 GFLOP at 480p -- run their K
+    // loop at one exposed memory round trip per chunk).  Built branch-free so that the compiler waits with exact
+    // vmcnt(4 (PF - 1)) counts (ISA checked: vmcnt 20..23 at depth 6), timed at depths 1 / 3 / 6 / 8 on 19 OS4..OS16 layer
+    // shapes and on the whole frame (profiles/r03_ring_prefetch_ab.txt): no layer moved by more than the noise, the short-K
+    // expanding 1x1 convs lost 20-60 % to the longer prologue, 480p 132.7 (depth 1) / 134.0 / 134.5 / 133.8 frames/s, 1080p
+    // 39.4 / 38.9 / 38.6 / 38.8.  These tiles are not latency-bound: a 64x64 tile moves 48 KB through LDS per 32-deep chunk
+    // for 6 MFMAs per wave (LDS time 2x the MFMA time), and below ~12 us a launch is its fixed cost (dispatch, prologue,
+    // epilogue), whatever K is.  The code stays (OTVM_PFS_* > 1 switches it on).
     constexpr int SETREGS = 4 * A_LD + 8 * B_LD;
     constexpr int PFS = (BM * BN == 32768 && WM * WN == 4) ? 1 :                  // 4-wave 256x128 / 128x256: 128 VGPRs, no room
-                        (SETREGS <= 16 ? OTVM_PFS_SMALL : SETREGS <= 24 ? OTVM_PFS_MID : SETREGS <= 32 ? OTVM_PFS_LARGE : 2);
+                        (SETREGS <= 16 ? OTVM_PFS_SMALL : SETREGS <= 24 ? OTVM_PFS_MID : SETREGS <= 32 ? OTVM_PFS_LARGE : 1);
     constexpr int PF = DBUF ? (BN == 128 ? OTVM_PF_DEPTH : 1) : PFS;
     constexpr bool BRANCHY = OTVM_BRANCHY_LOADS && (DBUF || PFS == 1);
     struct RegSet {
@@ -317,6 +322,15 @@ void conv_igemm_f16x3_kernel(const Conv3Args p) {
         }
         compute_ks(buf, 0);
         compute_ks(buf, 1);
+    } else if (PF == 1) {
+        for (int c = c_begin; c < c_end; ++c) {
+            __syncthreads();
+            store_chunk(0, rs[0]);
+            __syncthreads();
+            if (c + 1 < c_end) load_chunk(c + 1, rs[0]);
+            compute_ks(0, 0);
+            compute_ks(0, 1);
+        }
     } else {
         // one LDS stage, PF chunks of global loads in flight: chunk c sits in register set (c - c_begin) % PF.  No branch
         // surrounds a load (chunks past the end are loaded as dummies): with conditional prologue / tail loads the
