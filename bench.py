@@ -90,6 +90,9 @@ def main():
                     help="conv arithmetic: f16x3 = split-fp16 MFMA with fp32-class accuracy (default), f32 = exact-fp32 MFMA")
     ap.add_argument("--layer-report", default=None, help="write the per-layer conv timing table (JSON) to this path")
     ap.add_argument("--tune-report", default=None, help="write the plan-time autotuner's choices (JSON) to this path")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="sequences stepped in lock-step per GPU (one launch per layer over the B images, per-sequence banks); "
+                         "value then counts the frames of all of them.  The BASELINE headline is --batch 1")
     ap.add_argument("--stress-bank", action="store_true",
                     help="BASELINE configs[4] stress variant: memorise EVERY frame, never evict (max_memory_num = T)")
     ap.add_argument("--per-frame-report", default=None,
@@ -135,7 +138,9 @@ def main():
             model._get_engine().plan(H, W)
             torch.cuda.synchronize(dev)
         share_tune_cache(0)
-    frames = device_clip(H, W, T, seed=2000 + rank, dev=dev)
+    NB = max(1, args.batch)
+    clips = [device_clip(H, W, T, seed=2000 + rank + 100 * b, dev=dev) for b in range(NB)]
+    frames = clips[0]
     tri = torch.from_numpy(disc_trimap(H, W))[None, None].to(dev)
     a = torch.ones(1, 1, 1, H, W, device=dev)
 
@@ -151,7 +156,11 @@ def main():
             # _inputs_ready: the clip is resident in HBM and complete before the timed region starts (the bench contract),
             # so the query encoder of frame t may start while frame t-1's alpha network is still executing
             h0 = time.perf_counter()
-            out = model(a, frames[t], frames[t], tri=None, tri_gt=tri, large_input=False, _inputs_ready=True, **fkw(t))
+            if NB == 1:
+                out = model(a, frames[t], frames[t], tri=None, tri_gt=tri, large_input=False, _inputs_ready=True, **fkw(t))
+            else:
+                fr = [c[t] for c in clips]
+                out = model.forward_batch([a] * NB, fr, fr, [tri] * NB, large_input=False, _inputs_ready=True, **fkw(t))[0]
             if not (t == T - 1):          # (the clip's last frame ends with the range guard's synchronising read: not issue time)
                 host_issue[0] += time.perf_counter() - h0
                 host_issue[1] += 1
@@ -193,11 +202,11 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])
-        frames_total = torch.tensor([float(K), 1.0], dtype=torch.float64, device=rdev)
+        frames_total = torch.tensor([float(K * NB), 1.0], dtype=torch.float64, device=rdev)
         dist.all_reduce(frames_total, op=dist.ReduceOp.SUM)
         total_frames, ranks_seen = float(frames_total[0]), int(frames_total[1])
     else:
-        total_frames, ranks_seen = float(K), 1
+        total_frames, ranks_seen = float(K * NB), 1
     if ranks_seen != args.gpus:
         raise SystemExit("bench.py: --gpus %d but %d rank(s) took part in the run" % (args.gpus, ranks_seen))
 
@@ -208,7 +217,7 @@ def main():
     # algorithmic FLOPs of the timed frames: convs 2.6195 MFLOP per padded pixel + the memory read
     # with the number of slots each frame ACTUALLY read (short clips spend their first 16 frames below 5 slots)
     timed_T = [t_read[t] for t in range(Wm, T)]
-    flops_frame = 2.6195e6 * Hp * Wp + 1280.0 * (sum(timed_T) / float(K)) * hw * hw
+    flops_frame = (2.6195e6 * Hp * Wp + 1280.0 * (sum(timed_T) / float(K)) * hw * hw) * NB     # per STEP (NB frames)
     hist = {}
     for n_ in timed_T:
         hist[str(n_)] = hist.get(str(n_), 0) + 1
@@ -223,7 +232,8 @@ def main():
                                  "BASELINE configs[4])" if args.stress_bank else
                                  "memory every %d, max %d slots" % (args.skip, args.max_num))),
                    "padded": [Hp, Wp], "weights": "synthetic (otvm_amd.synth_weights seed 0)",
-                   "parallelism": "sequence-per-gpu x%d" % world,
+                   "parallelism": "sequence-per-gpu x%d" % world if NB == 1 else "%d sequences in lock-step per gpu x%d gpus" % (NB, world),
+                   "batch": NB,
                    "T_read_timed_frames": {"mean": sum(timed_T) / float(K), "histogram": hist}},
         "ranks_seen": ranks_seen,
         "host_issue_ms_per_frame": 1000.0 * host_issue_s / K,
@@ -303,7 +313,7 @@ def main():
                                      "note": "frac = share of the MFMA peak spent on ALGORITHMIC flops; the kernel also "
                                              "issues the softmax rescale and padded tiles, see profiles/ for MFMA-busy"}
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and NB == 1 and not args.no_cpu_baseline:
         # CPU baseline: the oracle (port of the reference algorithm) on the host cores, ONE steady-state frame of the
         # same clip at full resolution; its bank is seeded from the device bank so no CPU warm-up frames are needed.
         from oracle.otvm_oracle import OtvmOracle

@@ -35,12 +35,14 @@ extern "C" {
 #define OTVM_PREC_F16X3 1
 
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 10   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
+#define OTVM_ABI_VERSION 11   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
                                  4: otvm_conv_params.splitk_ws; 5: otvm_preprocess_params.fg_u8/bg_u8/u8_rgb;
                                  6: otvm_conv_params.tune + otvm_conv2d_candidates;
                                  7: folded GroupNorm tables on otvm_gn_apply's residual and otvm_upsample_bilinear's input;
                                  8: otvm_memory_read_f16x3_partial / _combine / _partial_count; 9: otvm_ppm_head;
-                                 10: otvm_finite_guard, otvm_clear */
+                                 10: otvm_finite_guard, otvm_clear;
+                                 11: batch of images per launch (otvm_conv_params.batch ..., otvm_gn_*_b, otvm_upsample_bilinear_b,
+                                     otvm_maxpool3x3s2_b) */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -107,6 +109,14 @@ typedef struct {
                                                        the chip split K over up to 8 workgroups per tile and reduce the
                                                        partial tiles in a fixed order (deterministic); NULL = never split.
                                                        One workspace per stream that runs convs concurrently.          */
+    /* ---- batch (ABI 11): the same layer applied to `batch` images in ONE launch (independent video sequences stepped
+     * in lock-step share the weights; small maps cannot fill 256 CUs from one image).  Image b of a tensor lives `*_bs`
+     * ELEMENTS behind image 0; every image is computed exactly as a batch-1 launch computes it (same tiles, same
+     * summation order).  batch <= 1: a single image, the strides are ignored.                                      */
+    int batch;
+    int64_t in_bs, out_bs, res_bs;                  /* floats between consecutive images of in / out / residual        */
+    int gn_bs;                                      /* doubles between the images' [32][2] statistics blocks (gn_stats) */
+    int norm_bs;                                    /* floats between the images' in_scale / in_shift tables            */
 } otvm_conv_params;
 int otvm_conv2d(const otvm_conv_params* p, void* stream);
 /* The legal kernel configurations of a layer (f16x3): the patch kernel where the shape allows it, and the implicit-GEMM
@@ -141,6 +151,20 @@ int otvm_gn_apply(const float* x, int64_t P, int C, int ld, const double* stats,
                   const float* beta, const float* residual, int res_ld, const float* res_scale, const float* res_shift,
                   int res_act, int act, float* out, int out_ld, void* stream);
 
+/* Batched forms (ABI 11): the same normalisation applied to `batch` images in one launch -- per-image statistics
+ * (GroupNorm is per sample), shared gamma / beta.  Image b of x / out / residual lives *_bs floats behind image 0, its
+ * [32][2] statistics block stats_bs doubles, its scale / shift tables norm_bs floats.  batch = 1 == the calls above. */
+int otvm_gn_stats_b(const float* x, int64_t P, int C, int ld, double* stats, int batch, int64_t x_bs, int stats_bs, void* stream);
+int otvm_gn_table_b(const double* stats, int64_t P, int C, const float* gamma, const float* beta, float* scale, float* shift,
+                    int batch, int stats_bs, int norm_bs, void* stream);
+typedef struct {
+    const float* x; int64_t P; int C, ld; const double* stats; const float* gamma; const float* beta;
+    const float* residual; int res_ld; const float* res_scale; const float* res_shift; int res_act, act;
+    float* out; int out_ld;
+    int batch; int64_t x_bs, res_bs, out_bs; int stats_bs, norm_bs;
+} otvm_gn_apply_params;
+int otvm_gn_apply_b(const otvm_gn_apply_params* p, void* stream);
+
 /* ---------------------------------------------------------------- pooling / resampling ---------*/
 /* F.max_pool2d(3, 2, 1) (resnet_GN_WS.py:98, torchvision resnet maxpool in STM.py:47,83) */
 int otvm_maxpool3x3s2(const float* in, int H, int W, int C, int ld, float* out, int out_ld, void* stream);
@@ -150,6 +174,12 @@ int otvm_maxpool3x3s2(const float* in, int H, int W, int C, int ld, float* out, 
  * in' = in_act(in * in_scale[c] + in_shift[c]) per source pixel (FBA/models.py:364-376: GN + LeakyReLU, then interpolate). */
 int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, int in_ld, const float* in_scale, const float* in_shift,
                            int in_act, const float* add, int add_ld, float* out, int Ho, int Wo, int out_ld, void* stream);
+/* batched forms (ABI 11): `batch` images per launch, image b lives *_bs floats behind image 0 (norm_bs: the tables) */
+int otvm_maxpool3x3s2_b(const float* in, int H, int W, int C, int ld, float* out, int out_ld, int batch, int64_t in_bs,
+                        int64_t out_bs, void* stream);
+int otvm_upsample_bilinear_b(const float* in, int Hi, int Wi, int C, int in_ld, const float* in_scale, const float* in_shift,
+                             int in_act, const float* add, int add_ld, float* out, int Ho, int Wo, int out_ld, int batch,
+                             int64_t in_bs, int64_t add_bs, int64_t out_bs, int norm_bs, void* stream);
 /* nn.AdaptiveAvgPool2d(s) for s in {1,2,3,6} in one launch (FBA/models.py:300-306);
  * out = 50 bins x C, bins ordered scale-major then row-major.
  * ws >= otvm_ppm_pool_ws_bytes(H, C): per-row sums of the 12 column bins (one pass over the map, then a

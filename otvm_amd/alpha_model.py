@@ -67,3 +67,18 @@ class EvalModel(nn.Module):
                         frames_rgb=bool(_frames_rgb), inputs_ready=_inputs_ready)
         self.memory_update = memorize
         return out
+
+    @torch.no_grad()
+    def forward_batch(self, a, fg, bg, tri_gt, first_frame=False, last_frame=False, memorize=False, max_memory_num=2,
+                      large_input=False, _frames_rgb=False, _inputs_ready=None, _cls_override=None):
+        """Round 3 extension (not part of the reference surface): the same frame step for B independent sequences stepped in
+        LOCK-STEP -- ``a``, ``fg``, ``bg``, ``tri_gt`` are lists of B per-sequence inputs shaped as ``forward`` takes them
+        (one resolution, one memory schedule; every sequence keeps its own memory bank).  Every layer runs as one launch
+        over the B images, which fills the chip on the small maps a single sequence leaves mostly idle.  Returns a list of
+        B 5-tuples; each equals what ``forward`` returns for that sequence run alone with the same kernel configurations."""
+        eng = self._get_engine()
+        out = eng.frame_batch(list(a), list(fg), list(bg), list(tri_gt), first_frame=bool(first_frame), last_frame=bool(last_frame),
+                              memorize=bool(memorize), max_memory_num=int(max_memory_num), dilate_kernel=self.DILATION_KERNEL,
+                              cls_override=_cls_override, frames_rgb=bool(_frames_rgb), inputs_ready=_inputs_ready)
+        self.memory_update = memorize
+        return out

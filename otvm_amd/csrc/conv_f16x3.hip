@@ -53,6 +53,9 @@ struct Conv3Args {
     // range of the K chunks and writes its un-biased partial tile to out + blockIdx.y * split_stride (the host points
     // `out` at the workspace and clears bias / residual / act / gn_stats); splitk_finish_kernel adds them up in order
     int64_t split_stride;
+    // batch: image blockIdx.z of every tensor lives *_bs elements behind image 0 (split-K: each image owns gridDim.y
+    // partial tiles of the workspace, out_bs = gridDim.y * split_stride)
+    int64_t in_bs, out_bs, res_bs; int gn_bs;
 };
 
 constexpr int BK = 32;
@@ -77,7 +80,15 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
 template <int BM, int BN, int WM, int WN, bool FAST, bool RELU_IN>
 __global__ __launch_bounds__(WM* WN * 64)
 __attribute__((amdgpu_waves_per_eu((BM * BN == 32768 && WM * WN == 4) ? 2 : 1, (BM * BN == 32768 && WM * WN == 4) ? 2 : 10)))
-void conv_igemm_f16x3_kernel(const Conv3Args p) {
+void conv_igemm_f16x3_kernel(const Conv3Args pa) {
+    Conv3Args p = pa;
+    {   // image of this workgroup (scalar pointer arithmetic; a batch-1 launch has gridDim.z == 1)
+        const int zb = blockIdx.z;
+        p.in += zb * p.in_bs;
+        p.out += zb * p.out_bs;
+        if (p.residual) p.residual += zb * p.res_bs;
+        if (p.gn_stats) p.gn_stats += zb * p.gn_bs;
+    }
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_ROWS = NT / 8, A_LD = BM / A_ROWS;        // 8 float4 per 32-wide row
@@ -472,7 +483,10 @@ void conv_igemm_f16x3_kernel(const Conv3Args p) {
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int S, int64_t stride, int64_t M,
                                                             int Cout, int ldp, const float* __restrict__ bias,
                                                             const float* __restrict__ residual, int res_ld, int act,
-                                                            float* __restrict__ out, int out_ld) {
+                                                            float* __restrict__ out, int out_ld, int64_t out_bs, int64_t res_bs) {
+    part += (int64_t)blockIdx.y * S * stride;                   // image blockIdx.y
+    out += blockIdx.y * out_bs;
+    if (residual) residual += blockIdx.y * res_bs;
     const unsigned Q = (unsigned)ldp >> 2;
     const unsigned total = (unsigned)M * Q;                     // split layers are small: M * ldp / 4 < 2^32 (host check)
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -491,11 +505,15 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
     }
 }
 
+// the host keeps the batch count in an otherwise unused field of the argument block while dispatching
+static thread_local int g_batch = 1;
+static inline int a_batch(const Conv3Args&) { return g_batch; }
+
 template <int BM, int BN, int WM, int WN>
 int launch3(Conv3Args& a, hipStream_t s, int ksplit = 1) {
     a.tiles_m = otvm_ceil_div(a.M, BM);
     a.tiles_n = otvm_ceil_div(a.Cout, BN);
-    const dim3 grid(a.tiles_m * a.tiles_n, ksplit), block(WM * WN * 64);
+    const dim3 grid(a.tiles_m * a.tiles_n, ksplit, a_batch(a)), block(WM * WN * 64);
     // int32 element offsets in the fast path: the whole input view must stay below 2^31 elements
     // (the split weights of such layers are stored channel-block major: the generic decode cannot read them)
     const bool fast = f16x3_fast_layout(a.taps, a.Cin);
@@ -609,7 +627,8 @@ static bool config_ok(const otvm_conv_params* p, int tile, int S) {
         const int nchunks = p->K_pad / 32;
         const int ldp = (p->Cout + 3) & ~3;
         if (!p->splitk_ws || nchunks / S < 4) return false;
-        if ((int64_t)S * M * ldp * (int64_t)sizeof(float) > p->splitk_ws_bytes || M * (ldp / 4) >= (1ll << 32)) return false;
+        const int64_t nb = p->batch > 1 ? p->batch : 1;
+        if (nb * S * M * ldp * (int64_t)sizeof(float) > p->splitk_ws_bytes || M * (ldp / 4) >= (1ll << 32)) return false;
     }
     return true;
 }
@@ -619,17 +638,18 @@ static int run_config(const otvm_conv_params* p, Conv3Args& a, int tile, int S, 
     const int64_t M = a.M;
     const int ldp = (p->Cout + 3) & ~3;
     Conv3Args b = a;
-    b.out = (float*)p->splitk_ws; b.out_ld = ldp; b.split_stride = M * ldp;
+    b.out = (float*)p->splitk_ws; b.out_ld = ldp; b.split_stride = M * ldp; b.out_bs = (int64_t)S * M * ldp;
     b.bias = nullptr; b.residual = nullptr; b.act = OTVM_ACT_NONE; b.gn_stats = nullptr;
     const int rc = launch_tile(tile, b, s, S);
     if (rc) return rc;
     int64_t blocks = (M * (ldp / 4) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)blocks), dim3(256), 0, s, (const float*)p->splitk_ws, S,
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)blocks, g_batch), dim3(256), 0, s, (const float*)p->splitk_ws, S,
                        (int64_t)M * ldp, M, p->Cout, ldp, p->bias, p->residual, p->res_ld, p->act, p->out,
-                       p->out_ld);
+                       p->out_ld, a.out_bs, a.res_bs);
     OTVM_CHECK_LAUNCH("otvm_conv2d(split-K finish)");
-    if (p->gn_stats) return otvm_gn_stats(p->out, M, p->Cout, p->out_ld, p->gn_stats, (void*)s);
+    if (p->gn_stats)
+        return otvm_gn_stats_b(p->out, M, p->Cout, p->out_ld, p->gn_stats, g_batch, a.out_bs, a.gn_bs, (void*)s);
     return 0;
 }
 
@@ -690,6 +710,9 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     a.in_relu = p->in_relu; a.act = p->act;
     a.M = p->Ho * p->Wo; a.taps = p->kh * p->kw; a.nchunks = p->K_pad / 32;
     a.split_stride = 0;
+    g_batch = p->batch > 1 ? p->batch : 1;
+    a.in_bs = g_batch > 1 ? p->in_bs : 0; a.out_bs = g_batch > 1 ? p->out_bs : 0; a.res_bs = g_batch > 1 ? p->res_bs : 0;
+    a.gn_bs = g_batch > 1 ? p->gn_bs : 0;
     hipStream_t s = (hipStream_t)stream;
     const int64_t M = a.M;
     if (p->tune) {

@@ -23,13 +23,22 @@ struct ConvArgs {
     int H, W, Cin, in_ld, K_pad, res_ld, Ho, Wo, Cout, out_ld;
     int kh, kw, stride, pad, dil, in_relu, act;
     int M, taps, nchunks, tiles_m, tiles_n;
+    int64_t in_bs, out_bs, res_bs; int gn_bs, batch;     // batch: image blockIdx.y lives *_bs elements behind image 0
 };
 
 constexpr int BK = 32;
 constexpr int LDK = 36;
 
 template <int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvArgs pa) {
+    ConvArgs p = pa;
+    {
+        const int zb = blockIdx.y;
+        p.in += zb * p.in_bs;
+        p.out += zb * p.out_bs;
+        if (p.residual) p.residual += zb * p.res_bs;
+        if (p.gn_stats) p.gn_stats += zb * p.gn_bs;
+    }
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_LD = BM / 32, B_LD = BN / 32;
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -206,7 +215,7 @@ int launch(ConvArgs& a, hipStream_t s) {
     a.tiles_m = otvm_ceil_div(a.M, BM);
     a.tiles_n = otvm_ceil_div(a.Cout, BN);
     const int grid = a.tiles_m * a.tiles_n;
-    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN>), dim3(grid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_f32_kernel<BM, BN, WM, WN>), dim3(grid, a.batch), dim3(256), 0, s, a);
     OTVM_CHECK_LAUNCH("otvm_conv2d");
     return 0;
 }
@@ -323,6 +332,9 @@ extern "C" int otvm_conv2d(const otvm_conv_params* p, void* stream) {
     a.kh = p->kh; a.kw = p->kw; a.stride = p->stride; a.pad = p->pad; a.dil = p->dil;
     a.in_relu = p->in_relu; a.act = p->act;
     a.M = p->Ho * p->Wo; a.taps = p->kh * p->kw; a.nchunks = p->K_pad / 32;
+    a.batch = p->batch > 1 ? p->batch : 1;
+    a.in_bs = a.batch > 1 ? p->in_bs : 0; a.out_bs = a.batch > 1 ? p->out_bs : 0; a.res_bs = a.batch > 1 ? p->res_bs : 0;
+    a.gn_bs = a.batch > 1 ? p->gn_bs : 0;
     hipStream_t s = (hipStream_t)stream;
     // Tile choice: weights are padded to 128 output rows, so any BN <= 128 is legal.  Prefer the big
     // tile; fall back to smaller ones when the launch would not fill 256 CUs or Cout is narrow.

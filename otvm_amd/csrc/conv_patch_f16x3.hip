@@ -33,6 +33,8 @@ struct PatchArgs {
     // fused input normalisation (GroupNorm apply of the producer folded into the staging): x' = in_act(x * in_scale[c]
     // + in_shift[c]) for pixels inside the image, 0 for the conv's zero padding; nullptr = plain input
     const float* in_scale; const float* in_shift; int in_act;
+    // batch: image blockIdx.y of every tensor lives *_bs elements behind image 0
+    int64_t in_bs, out_bs, res_bs; int gn_bs, norm_bs, batch;
 };
 
 constexpr int CB = 16;           // channels per stage = one MFMA k-step
@@ -56,7 +58,16 @@ __device__ __forceinline__ void split4p(const f32x4 v, f16x4& hi, f16x4& lo) {
 template <int TH, int BN, int NW, int DIL, int TAPG>
 __global__ __launch_bounds__(NW * 64)
 __attribute__((amdgpu_waves_per_eu((TAPG == 3 && BN <= 32) ? 3 : 1, (TAPG == 3 && BN <= 32) ? 3 : 10)))
-void conv_patch_f16x3_kernel(const PatchArgs p) {
+void conv_patch_f16x3_kernel(const PatchArgs pa) {
+    PatchArgs p = pa;
+    {
+        const int zb = blockIdx.y;
+        p.in += zb * p.in_bs;
+        p.out += zb * p.out_bs;
+        if (p.residual) p.residual += zb * p.res_bs;
+        if (p.gn_stats) p.gn_stats += zb * p.gn_bs;
+        if (p.in_scale) { p.in_scale += zb * p.norm_bs; p.in_shift += zb * p.norm_bs; }
+    }
     constexpr int NT = NW * 64;
     constexpr int TM = TH / NW, TN = BN / 32;
     constexpr int PW = 32 + 2 * DIL, PH = TH + 2 * DIL, NPIX = PH * PW;
@@ -376,7 +387,7 @@ int launch_patch(PatchArgs& a, hipStream_t s) {
     a.tiles_x = otvm_ceil_div(a.W, 32);
     a.tiles_y = otvm_ceil_div(a.H, TH);
     a.tiles_n = otvm_ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL, TAPG>), dim3(a.tiles_x * a.tiles_y * a.tiles_n), dim3(NW * 64), 0, s, a);
+    hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL, TAPG>), dim3(a.tiles_x * a.tiles_y * a.tiles_n, a.batch), dim3(NW * 64), 0, s, a);
     OTVM_CHECK_LAUNCH("otvm_conv2d(patch f16x3)");
     return 0;
 }
@@ -439,6 +450,9 @@ static int patch_run(const otvm_conv_params* p, void* stream, int choice) {
     a.n_pad32 = (p->Cout + 31) / 32 * 32; a.in_relu = p->in_relu; a.act = p->act;
     hipStream_t s = (hipStream_t)stream;
     a.in_scale = p->in_scale; a.in_shift = p->in_shift; a.in_act = p->in_act;
+    a.batch = p->batch > 1 ? p->batch : 1;
+    a.in_bs = a.batch > 1 ? p->in_bs : 0; a.out_bs = a.batch > 1 ? p->out_bs : 0; a.res_bs = a.batch > 1 ? p->res_bs : 0;
+    a.gn_bs = a.batch > 1 ? p->gn_bs : 0; a.norm_bs = a.batch > 1 ? p->norm_bs : 0;
     if (is_wide) {
         if (p->dil == 1) return launch_patch<8, 256, 8, 1, 3>(a, s);
         if (p->dil == 2) return launch_patch<8, 256, 8, 2, 3>(a, s);

@@ -27,6 +27,7 @@ struct StemArgs {
     const float* in; const _Float16* wf; const float* wscale; const float* bias; float* out; double* gn_stats;
     int H, W, Cin, in_ld, Ho, Wo, Cout, out_ld, act, groups;
     int tiles_x, tiles_y;
+    int64_t in_bs, out_bs; int gn_bs;     // batch: image blockIdx.y lives *_bs elements behind image 0
 };
 
 constexpr int TH = 8, TW = 32, NW = 4, NT = NW * 64;
@@ -45,7 +46,14 @@ __device__ __forceinline__ void split4s(const f32x4 v, f16x4& hi, f16x4& lo) {
                (_Float16)(v.w - (float)h23.y)};
 }
 
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_stem_f16x3_kernel(const StemArgs p) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv_stem_f16x3_kernel(const StemArgs pa) {
+    StemArgs p = pa;
+    {
+        const int zb = blockIdx.y;
+        p.in += zb * p.in_bs;
+        p.out += zb * p.out_bs;
+        if (p.gn_stats) p.gn_stats += zb * p.gn_bs;
+    }
     constexpr int PATCH_HALFS = 2 * NPIX * 8;                            // hi[NPIX][8] + lo[NPIX][8]
     constexpr int EPI_HALFS = NW * 32 * 36 * 2;
     constexpr int SM_HALFS = PATCH_HALFS > EPI_HALFS ? PATCH_HALFS : EPI_HALFS;
@@ -312,7 +320,9 @@ int otvm_conv2d_stem_f16x3(const otvm_conv_params* p, void* stream) {
     a.out_ld = p->out_ld; a.act = p->act; a.groups = (p->Cin + 7) / 8;
     a.tiles_x = otvm_ceil_div(p->Wo, TW);
     a.tiles_y = otvm_ceil_div(p->Ho, TH);
-    hipLaunchKernelGGL(conv_stem_f16x3_kernel, dim3(a.tiles_x * a.tiles_y), dim3(NT), 0, (hipStream_t)stream, a);
+    const int batch = p->batch > 1 ? p->batch : 1;
+    a.in_bs = batch > 1 ? p->in_bs : 0; a.out_bs = batch > 1 ? p->out_bs : 0; a.gn_bs = batch > 1 ? p->gn_bs : 0;
+    hipLaunchKernelGGL(conv_stem_f16x3_kernel, dim3(a.tiles_x * a.tiles_y, batch), dim3(NT), 0, (hipStream_t)stream, a);
     OTVM_CHECK_LAUNCH("otvm_conv2d(stem f16x3)");
     return 0;
 }

@@ -12,7 +12,10 @@ namespace {
 
 constexpr int G = 32;
 
-__global__ void gn_stats_kernel(const float* __restrict__ x, int64_t P, int C, int ld, double* __restrict__ stats) {
+__global__ void gn_stats_kernel(const float* __restrict__ x, int64_t P, int C, int ld, double* __restrict__ stats,
+                                int64_t x_bs, int stats_bs) {
+    x += blockIdx.y * x_bs;                       // image blockIdx.y
+    stats += blockIdx.y * stats_bs;
     __shared__ double red[G * 2];
     const int Q = C >> 2;                         // float4 columns per pixel
     const int rows = blockDim.x / Q;              // pixels covered per block iteration
@@ -57,7 +60,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ beta, const float* __restrict__ residual,
                                                        int res_ld, const float* __restrict__ res_scale,
                                                        const float* __restrict__ res_shift, int res_act, int act,
-                                                       float* __restrict__ out, int out_ld) {
+                                                       float* __restrict__ out, int out_ld, int64_t x_bs, int64_t res_bs,
+                                                       int64_t out_bs, int stats_bs, int norm_bs) {
+    {   // image blockIdx.y
+        const int zb = blockIdx.y;
+        x += zb * x_bs;
+        out += zb * out_bs;
+        stats += zb * stats_bs;
+        if (residual) residual += zb * res_bs;
+        if (res_scale) { res_scale += zb * norm_bs; res_shift += zb * norm_bs; }
+    }
     __shared__ float mean_s[G], rstd_s[G];
     const int cg = C / G;
     if (threadIdx.x < G) {
@@ -105,7 +117,11 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 }
 
 __global__ void gn_table_kernel(const double* __restrict__ stats, int64_t P, int C, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift) {
+                                const float* __restrict__ beta, float* __restrict__ scale, float* __restrict__ shift,
+                                int stats_bs, int norm_bs) {
+    stats += blockIdx.x * stats_bs;               // image blockIdx.x
+    scale += blockIdx.x * norm_bs;
+    shift += blockIdx.x * norm_bs;
     __shared__ float mean_s[G], rstd_s[G];
     const int cg = C / G;
     if (threadIdx.x < G) {
@@ -127,35 +143,52 @@ __global__ void gn_table_kernel(const double* __restrict__ stats, int64_t P, int
 
 }  // namespace
 
-extern "C" int otvm_gn_table(const double* stats, int64_t P, int C, const float* gamma, const float* beta, float* scale,
-                             float* shift, void* stream) {
-    OTVM_REQUIRE(stats && gamma && beta && scale && shift && C % 32 == 0 && C <= 4096, "otvm_gn_table: bad arguments (C=%d)", C);
-    hipLaunchKernelGGL(gn_table_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, P, C, gamma, beta, scale, shift);
+extern "C" int otvm_gn_table_b(const double* stats, int64_t P, int C, const float* gamma, const float* beta, float* scale,
+                               float* shift, int batch, int stats_bs, int norm_bs, void* stream) {
+    OTVM_REQUIRE(stats && gamma && beta && scale && shift && C % 32 == 0 && C <= 4096 && batch >= 1,
+                 "otvm_gn_table: bad arguments (C=%d)", C);
+    hipLaunchKernelGGL(gn_table_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, stats, P, C, gamma, beta, scale, shift,
+                       stats_bs, norm_bs);
     OTVM_CHECK_LAUNCH("otvm_gn_table");
     return 0;
 }
 
-extern "C" int otvm_gn_stats(const float* x, int64_t P, int C, int ld, double* stats, void* stream) {
+extern "C" int otvm_gn_table(const double* stats, int64_t P, int C, const float* gamma, const float* beta, float* scale,
+                             float* shift, void* stream) {
+    return otvm_gn_table_b(stats, P, C, gamma, beta, scale, shift, 1, 0, 0, stream);
+}
+
+extern "C" int otvm_gn_stats_b(const float* x, int64_t P, int C, int ld, double* stats, int batch, int64_t x_bs, int stats_bs,
+                               void* stream) {
     OTVM_REQUIRE(C % 64 == 0 && C <= 2048, "otvm_gn_stats: C=%d unsupported (need multiple of 64, <= 2048)", C);
-    OTVM_REQUIRE(ld % 4 == 0 && ((uintptr_t)x & 15) == 0, "otvm_gn_stats: unaligned view");
+    OTVM_REQUIRE(ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && x_bs % 4 == 0 && batch >= 1, "otvm_gn_stats: unaligned view");
     const int Q = C / 4;
     const int threads = Q <= 256 ? 256 : 512;
     const int rows = threads / Q;
     int64_t blocks = (P + rows - 1) / rows;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(gn_stats_kernel, dim3((int)blocks), dim3(threads), 0, (hipStream_t)stream, x, P, C, ld, stats);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3((int)blocks, batch), dim3(threads), 0, (hipStream_t)stream, x, P, C, ld, stats, x_bs,
+                       stats_bs);
     OTVM_CHECK_LAUNCH("otvm_gn_stats");
     return 0;
 }
 
-extern "C" int otvm_gn_apply(const float* x, int64_t P, int C, int ld, const double* stats, const float* gamma,
-                             const float* beta, const float* residual, int res_ld, const float* res_scale,
-                             const float* res_shift, int res_act, int act, float* out, int out_ld, void* stream) {
+extern "C" int otvm_gn_stats(const float* x, int64_t P, int C, int ld, double* stats, void* stream) {
+    return otvm_gn_stats_b(x, P, C, ld, stats, 1, 0, 0, stream);
+}
+
+extern "C" int otvm_gn_apply_b(const otvm_gn_apply_params* q, void* stream) {
+    OTVM_REQUIRE(q && q->x && q->out && q->stats && q->gamma && q->beta, "otvm_gn_apply: null pointer");
+    const int C = q->C;
     OTVM_REQUIRE(C % 64 == 0 && C <= 2048, "otvm_gn_apply: C=%d unsupported", C);
-    OTVM_REQUIRE(!res_scale == !res_shift && (!res_scale || residual), "otvm_gn_apply: res_scale / res_shift go together, with a residual");
-    OTVM_REQUIRE(ld % 4 == 0 && out_ld % 4 == 0 && (!residual || res_ld % 4 == 0), "otvm_gn_apply: unaligned view");
+    OTVM_REQUIRE(!q->res_scale == !q->res_shift && (!q->res_scale || q->residual),
+                 "otvm_gn_apply: res_scale / res_shift go together, with a residual");
+    OTVM_REQUIRE(q->ld % 4 == 0 && q->out_ld % 4 == 0 && (!q->residual || q->res_ld % 4 == 0), "otvm_gn_apply: unaligned view");
+    const int batch = q->batch > 1 ? q->batch : 1;
+    OTVM_REQUIRE(batch == 1 || (q->x_bs % 4 == 0 && q->out_bs % 4 == 0 && q->res_bs % 4 == 0 && q->norm_bs % 4 == 0),
+                 "otvm_gn_apply: batch strides must be multiples of 4 elements");
     const int Q = C / 4;
-    const int64_t total = P * Q;
+    const int64_t total = q->P * Q;
     int64_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     // the grid stride must be a multiple of Q (the kernel keeps one channel quad per thread): Q | blocks * 256
@@ -163,8 +196,20 @@ extern "C" int otvm_gn_apply(const float* x, int64_t P, int C, int ld, const dou
     while (r) { const int t = gcd % r; gcd = r; r = t; }
     const int m = Q / gcd;                                   // smallest m with Q | 256 m
     blocks = (blocks + m - 1) / m * m;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, P, C, ld, stats, gamma, beta,
-                       residual, res_ld, res_scale, res_shift, res_act, act, out, out_ld);
+    const bool b = batch > 1;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((int)blocks, batch), dim3(256), 0, (hipStream_t)stream, q->x, q->P, C, q->ld, q->stats,
+                       q->gamma, q->beta, q->residual, q->res_ld, q->res_scale, q->res_shift, q->res_act, q->act, q->out, q->out_ld,
+                       b ? q->x_bs : 0, b ? q->res_bs : 0, b ? q->out_bs : 0, b ? q->stats_bs : 0, b ? q->norm_bs : 0);
     OTVM_CHECK_LAUNCH("otvm_gn_apply");
     return 0;
+}
+
+extern "C" int otvm_gn_apply(const float* x, int64_t P, int C, int ld, const double* stats, const float* gamma,
+                             const float* beta, const float* residual, int res_ld, const float* res_scale,
+                             const float* res_shift, int res_act, int act, float* out, int out_ld, void* stream) {
+    otvm_gn_apply_params q;
+    q.x = x; q.P = P; q.C = C; q.ld = ld; q.stats = stats; q.gamma = gamma; q.beta = beta; q.residual = residual; q.res_ld = res_ld;
+    q.res_scale = res_scale; q.res_shift = res_shift; q.res_act = res_act; q.act = act; q.out = out; q.out_ld = out_ld;
+    q.batch = 1; q.x_bs = q.res_bs = q.out_bs = 0; q.stats_bs = q.norm_bs = 0;
+    return otvm_gn_apply_b(&q, stream);
 }

@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void finite_guard_kernel(const float* __restri
         const int c = (int)(i - m * Q) * 4;
         const f32x4 v = *reinterpret_cast<const f32x4*>(x + m * ld + c);
         // !(|v| < limit) is true for NaN as well
-        bad |= !(fabsf(v.x) < limit) | !(fabsf(v.y) < limit) | !(fabsf(v.z) < limit) | !(fabsf(v.w) < limit);
+        bad = bad || !(fabsf(v.x) < limit) || !(fabsf(v.y) < limit) || !(fabsf(v.z) < limit) || !(fabsf(v.w) < limit);
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicMin(flag, tag);
 }

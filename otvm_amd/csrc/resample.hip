@@ -13,7 +13,9 @@ __device__ __forceinline__ f32x4 vmax(f32x4 a, f32x4 b) {
 
 // F.max_pool2d(kernel 3, stride 2, padding 1): padding acts as -inf
 __global__ void maxpool3x3s2_kernel(const float* __restrict__ in, int H, int W, int C, int ld, float* __restrict__ out,
-                                    int Ho, int Wo, int out_ld) {
+                                    int Ho, int Wo, int out_ld, int64_t in_bs, int64_t out_bs) {
+    in += blockIdx.y * in_bs;                     // image blockIdx.y
+    out += blockIdx.y * out_bs;
     const int Q = C >> 2;
     const int64_t total = (int64_t)Ho * Wo * Q;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -48,7 +50,15 @@ __global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __r
                                                                 const float* __restrict__ in_shift, int in_act,
                                                                 const float* __restrict__ add, int add_ld,
                                                                 float* __restrict__ out, int Ho, int Wo, int out_ld, float sy,
-                                                                float sx) {
+                                                                float sx, int64_t in_bs, int64_t add_bs, int64_t out_bs,
+                                                                int norm_bs) {
+    {   // image blockIdx.z
+        const int zb = blockIdx.z;
+        in += zb * in_bs;
+        out += zb * out_bs;
+        if (add) add += zb * add_bs;
+        if (in_scale) { in_scale += zb * norm_bs; in_shift += zb * norm_bs; }
+    }
     const int Q = C >> 2;
     const int oy = blockIdx.y;
     float fy = ((float)oy + 0.5f) * sy - 0.5f;
@@ -97,7 +107,15 @@ __global__ __launch_bounds__(256) void upsample2x_bilinear_kernel(const float* _
                                                                   const float* __restrict__ in_scale,
                                                                   const float* __restrict__ in_shift, int in_act,
                                                                   const float* __restrict__ add, int add_ld,
-                                                                  float* __restrict__ out, int out_ld) {
+                                                                  float* __restrict__ out, int out_ld, int64_t in_bs,
+                                                                  int64_t add_bs, int64_t out_bs, int norm_bs) {
+    {   // image blockIdx.z
+        const int zb = blockIdx.z;
+        in += zb * in_bs;
+        out += zb * out_bs;
+        if (add) add += zb * add_bs;
+        if (in_scale) { in_scale += zb * norm_bs; in_shift += zb * norm_bs; }
+    }
     const int Q = C >> 2, Ho = 2 * Hi, Wo = 2 * Wi;
     const int y = blockIdx.y;
     const int y1 = y + (y < Hi - 1 ? 1 : 0);
@@ -219,38 +237,54 @@ static int grid_for(int64_t total) {
     return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
 }
 
-extern "C" int otvm_maxpool3x3s2(const float* in, int H, int W, int C, int ld, float* out, int out_ld, void* stream) {
+extern "C" int otvm_maxpool3x3s2_b(const float* in, int H, int W, int C, int ld, float* out, int out_ld, int batch, int64_t in_bs,
+                                   int64_t out_bs, void* stream) {
     OTVM_REQUIRE(C % 4 == 0 && ld % 4 == 0 && out_ld % 4 == 0, "otvm_maxpool3x3s2: channels must be multiples of 4");
+    OTVM_REQUIRE(batch >= 1 && in_bs % 4 == 0 && out_bs % 4 == 0, "otvm_maxpool3x3s2: bad batch arguments");
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for((int64_t)Ho * Wo * (C / 4))), dim3(256), 0, (hipStream_t)stream,
-                       in, H, W, C, ld, out, Ho, Wo, out_ld);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for((int64_t)Ho * Wo * (C / 4)), batch), dim3(256), 0, (hipStream_t)stream,
+                       in, H, W, C, ld, out, Ho, Wo, out_ld, in_bs, out_bs);
     OTVM_CHECK_LAUNCH("otvm_maxpool3x3s2");
     return 0;
 }
 
-extern "C" int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, int in_ld, const float* in_scale,
-                                      const float* in_shift, int in_act, const float* add, int add_ld,
-                                      float* out, int Ho, int Wo, int out_ld, void* stream) {
+extern "C" int otvm_maxpool3x3s2(const float* in, int H, int W, int C, int ld, float* out, int out_ld, void* stream) {
+    return otvm_maxpool3x3s2_b(in, H, W, C, ld, out, out_ld, 1, 0, 0, stream);
+}
+
+extern "C" int otvm_upsample_bilinear_b(const float* in, int Hi, int Wi, int C, int in_ld, const float* in_scale,
+                                        const float* in_shift, int in_act, const float* add, int add_ld,
+                                        float* out, int Ho, int Wo, int out_ld, int batch, int64_t in_bs, int64_t add_bs,
+                                        int64_t out_bs, int norm_bs, void* stream) {
     OTVM_REQUIRE(!in_scale == !in_shift, "otvm_upsample_bilinear: in_scale and in_shift go together");
     OTVM_REQUIRE(C % 4 == 0 && in_ld % 4 == 0 && out_ld % 4 == 0 && (!add || add_ld % 4 == 0),
                  "otvm_upsample_bilinear: channels must be multiples of 4");
+    OTVM_REQUIRE(batch >= 1 && in_bs % 4 == 0 && add_bs % 4 == 0 && out_bs % 4 == 0 && norm_bs % 4 == 0,
+                 "otvm_upsample_bilinear: bad batch arguments");
     const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
     OTVM_REQUIRE(Ho <= 65535 && (int64_t)Wo * (C / 4) < (1ll << 31), "otvm_upsample_bilinear: output %dx%d too large", Ho, Wo);
     static const int x2_on = getenv("OTVM_UPSAMPLE2X") ? atoi(getenv("OTVM_UPSAMPLE2X")) : 1;
     if (x2_on && Ho == 2 * Hi && Wo == 2 * Wi && Hi >= 2 && Wi >= 2) {
         int bx2 = otvm_ceil_div(Wi * (C / 4), 256);
         if (bx2 > 64) bx2 = 64;
-        hipLaunchKernelGGL(upsample2x_bilinear_kernel, dim3(bx2, Hi), dim3(256), 0, (hipStream_t)stream, in, Hi, Wi, C, in_ld,
-                           in_scale, in_shift, in_act, add, add_ld, out, out_ld);
+        hipLaunchKernelGGL(upsample2x_bilinear_kernel, dim3(bx2, Hi, batch), dim3(256), 0, (hipStream_t)stream, in, Hi, Wi, C, in_ld,
+                           in_scale, in_shift, in_act, add, add_ld, out, out_ld, in_bs, add_bs, out_bs, norm_bs);
         OTVM_CHECK_LAUNCH("otvm_upsample_bilinear(x2)");
         return 0;
     }
     int bx = otvm_ceil_div(Wo * (C / 4), 256);
     if (bx > 64) bx = 64;
-    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(bx, Ho), dim3(256), 0, (hipStream_t)stream, in, Hi, Wi, C, in_ld,
-                       in_scale, in_shift, in_act, add, add_ld, out, Ho, Wo, out_ld, sy, sx);
+    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(bx, Ho, batch), dim3(256), 0, (hipStream_t)stream, in, Hi, Wi, C, in_ld,
+                       in_scale, in_shift, in_act, add, add_ld, out, Ho, Wo, out_ld, sy, sx, in_bs, add_bs, out_bs, norm_bs);
     OTVM_CHECK_LAUNCH("otvm_upsample_bilinear");
     return 0;
+}
+
+extern "C" int otvm_upsample_bilinear(const float* in, int Hi, int Wi, int C, int in_ld, const float* in_scale,
+                                      const float* in_shift, int in_act, const float* add, int add_ld,
+                                      float* out, int Ho, int Wo, int out_ld, void* stream) {
+    return otvm_upsample_bilinear_b(in, Hi, Wi, C, in_ld, in_scale, in_shift, in_act, add, add_ld, out, Ho, Wo, out_ld, 1, 0, 0, 0,
+                                    0, stream);
 }
 
 extern "C" int64_t otvm_ppm_pool_ws_bytes(int H, int C) { return (int64_t)H * PPM_XBINS * C * sizeof(float); }

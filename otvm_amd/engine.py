@@ -122,13 +122,15 @@ def _rup(x, m):
 
 
 class Act:
-    """A [H, W, C] fp32 NHWC view with pixel stride ``ld`` inside a flat device buffer."""
-    __slots__ = ("t", "H", "W", "C", "ld", "off")
+    """A [H, W, C] fp32 NHWC view with pixel stride ``ld`` inside a flat device buffer -- or a batch of ``B`` such views,
+    image b lying ``bs`` elements behind image 0 (independent sequences stepped in lock-step, one launch per layer)."""
+    __slots__ = ("t", "H", "W", "C", "ld", "off", "B", "bs")
 
-    def __init__(self, t, H, W, C, ld=None, off=0):
+    def __init__(self, t, H, W, C, ld=None, off=0, B=1, bs=0):
         self.t, self.H, self.W, self.C = t, H, W, C
         self.ld = C if ld is None else ld
         self.off = off
+        self.B, self.bs = B, (bs if B > 1 else 0)
 
     @property
     def ptr(self):
@@ -139,11 +141,15 @@ class Act:
         return self.H * self.W
 
     def ch(self, c0, c):
-        return Act(self.t, self.H, self.W, c, self.ld, self.off + c0)
+        return Act(self.t, self.H, self.W, c, self.ld, self.off + c0, self.B, self.bs)
 
-    def torch(self):
-        """[H, W, C] strided torch view (tests / debugging only)."""
-        return torch.as_strided(self.t, (self.H, self.W, self.C), (self.W * self.ld, self.ld, 1), self.off)
+    def img(self, b):
+        """Image b of the batch as a single-image view."""
+        return Act(self.t, self.H, self.W, self.C, self.ld, self.off + b * self.bs)
+
+    def torch(self, b=0):
+        """[H, W, C] strided torch view of image b (tests / debugging only)."""
+        return torch.as_strided(self.t, (self.H, self.W, self.C), (self.W * self.ld, self.ld, 1), self.off + b * self.bs)
 
 
 class ConvW:
@@ -221,7 +227,8 @@ def pack_conv_weight(lib, dev, w, ws=False, scale=None, i_pad=None, split=True, 
 
 def conv_params(x, cw, out, bias=None, stride=1, pad=0, dil=1, act=NONE, in_relu=0, residual=None, precision=L.PREC_F32,
                 in_norm=None, splitk_ws=None):
-    """in_norm = (scale_ptr, shift_ptr, act): fused normalisation of the input (otvm_conv_params.in_scale);
+    """in_norm = (scale_ptr, shift_ptr, act[, floats between the images' tables]): fused normalisation of the input
+    (otvm_conv_params.in_scale); a batched input (x.B > 1) makes the launch a batched one;
     splitk_ws = float tensor the library may use for split-K partial tiles (one per concurrently used stream)."""
     Ho = (x.H + 2 * pad - dil * (cw.kh - 1) - 1) // stride + 1
     Wo = (x.W + 2 * pad - dil * (cw.kw - 1) - 1) // stride + 1
@@ -237,7 +244,9 @@ def conv_params(x, cw, out, bias=None, stride=1, pad=0, dil=1, act=NONE, in_relu
                         0 if in_norm is None else in_norm[0], 0 if in_norm is None else in_norm[1],
                         0 if in_norm is None else in_norm[2], 0,
                         0 if splitk_ws is None else splitk_ws.data_ptr(),
-                        0 if splitk_ws is None else splitk_ws.numel() * splitk_ws.element_size())
+                        0 if splitk_ws is None else splitk_ws.numel() * splitk_ws.element_size(),
+                        x.B, x.bs, out.bs, 0 if residual is None else residual.bs, 0,
+                        0 if in_norm is None or len(in_norm) < 4 else in_norm[3])
 
 
 class HipEngine:
@@ -354,8 +363,10 @@ class HipEngine:
         tag = self.frame_counter - 1 if tag is None else tag
         # the exact-fp32 path has no range limit: only inf / NaN fail there
         limit = F16_LIMIT if self.precision == L.PREC_F16X3 else float("inf")
-        L.check(self.lib.otvm_finite_guard(act.ptr, act.P, act.C, act.ld, limit, max(int(tag), 0),
-                                           self.guard_flag.data_ptr(), stream), "finite_guard " + what)
+        for b in range(act.B):
+            v = act.img(b) if act.B > 1 else act
+            L.check(self.lib.otvm_finite_guard(v.ptr, v.P, v.C, v.ld, limit, max(int(tag), 0), self.guard_flag.data_ptr(), stream),
+                    "finite_guard " + what)
 
     def _guard_raise(self, frame):
         self.guard_flag.fill_(GUARD_CLEAR)
@@ -388,10 +399,10 @@ class HipEngine:
             self._guard_ev.record(torch.cuda.current_stream(self.dev))
 
     # ------------------------------------------------------------------ plans
-    def plan(self, H, W):
-        key = (H, W)
+    def plan(self, H, W, B=1):
+        key = (H, W) if B == 1 else (H, W, B)
         if key not in self.plans:
-            self.plans[key] = FramePlan(self, H, W)
+            self.plans[key] = FramePlan(self, H, W, B)
         return self.plans[key]
 
     def reset(self):
@@ -407,6 +418,10 @@ class HipEngine:
         with torch.cuda.device(self.dev):
             return self._frame(*args, **kw)
 
+    def frame_batch(self, *args, **kw):
+        with torch.cuda.device(self.dev):
+            return self._frame_batch(*args, **kw)
+
     def _frame(self, a, fg, bg, tri_gt=None, first_frame=False, last_frame=False, memorize=False, max_memory_num=2,
                dilate_kernel=None, frame_id=None, cls_override=None, frames_rgb=False, inputs_ready=None):
         """One call of EvalModel.forward (reference models/alpha/model.py:391-512) on the HIP path.
@@ -418,41 +433,64 @@ class HipEngine:
         them); a torch.cuda.Event = complete once that event has fired; None = unknown (ordered after everything issued on
         the launch stream so far).  Only matters for how early the query encoder may start.
         Returns the reference's 5-tuple (scaled_imgs, preds_trimap, tri_gt, preds_alpha, scaled_gts)."""
+        return self._frame_batch([a], [fg], [bg], [tri_gt], first_frame, last_frame, memorize, max_memory_num, dilate_kernel,
+                                 frame_id, None if cls_override is None else [cls_override], frames_rgb, inputs_ready)[0]
+
+    def _frame_batch(self, a_l, fg_l, bg_l, tri_gt_l, first_frame=False, last_frame=False, memorize=False, max_memory_num=2,
+                     dilate_kernel=None, frame_id=None, cls_override=None, frames_rgb=False, inputs_ready=None):
+        """The same frame step for B independent sequences in LOCK-STEP (round 3): lists of B inputs of one resolution, one
+        memory schedule (first_frame / last_frame / memorize / max_memory_num apply to all), per-sequence banks.  Every
+        layer is ONE launch over the B images (otvm_conv_params.batch, otvm_gn_*_b, ...): the weights are read once, and
+        the small maps of the encoders -- too few tiles for 256 CUs from one image -- fill the chip.  Each image is computed
+        exactly as a batch-1 call computes it (same tiles, same summation order).  Returns a list of B 5-tuples."""
         dev, lib = self.dev, self.lib
         f32 = torch.float32
+        B = len(a_l)
+        if not (len(fg_l) == len(bg_l) == len(tri_gt_l) == B) or B < 1:
+            raise ValueError("otvm_amd: a / fg / bg / tri_gt lists must have the same length")
         main = torch.cuda.current_stream(dev)
         if isinstance(inputs_ready, torch.cuda.Event):
             main.wait_event(inputs_ready)                     # before anything below (a conversion, too) reads the inputs
-        a_in, fg_in, bg_in = a, fg, bg
-        a = a.to(dev, f32).contiguous()
-        u8 = fg.dtype == torch.uint8
-        if u8:
-            if bg.dtype != torch.uint8 or fg.dim() != 3 or fg.shape[-1] != 3 or bg.shape != fg.shape:
-                raise ValueError("otvm_amd: uint8 frames must be [H,W,3] for both fg and bg, got %s / %s"
-                                 % (tuple(fg.shape), tuple(bg.shape)))
-            fg, bg = fg.to(dev).contiguous(), bg.to(dev).contiguous()
-            H, W = int(fg.shape[0]), int(fg.shape[1])
-        else:
-            if frames_rgb:
-                raise ValueError("otvm_amd: frames_rgb applies to uint8 [H,W,3] frames only (fp32 input is BGR planar)")
-            fg = fg.to(dev, f32).contiguous()
-            bg = bg.to(dev, f32).contiguous()
-            H, W = int(fg.shape[-2]), int(fg.shape[-1])
-        if inputs_ready is not None and (a is not a_in or fg is not fg_in or bg is not bg_in):
+        ins, H, W, converted = [], None, None, False
+        u8 = fg_l[0].dtype == torch.uint8
+        for a, fg, bg in zip(a_l, fg_l, bg_l):
+            a_in, fg_in, bg_in = a, fg, bg
+            a = a.to(dev, f32).contiguous()
+            if (fg.dtype == torch.uint8) != u8:
+                raise ValueError("otvm_amd: the frames of a batch must share one dtype")
+            if u8:
+                if bg.dtype != torch.uint8 or fg.dim() != 3 or fg.shape[-1] != 3 or bg.shape != fg.shape:
+                    raise ValueError("otvm_amd: uint8 frames must be [H,W,3] for both fg and bg, got %s / %s"
+                                     % (tuple(fg.shape), tuple(bg.shape)))
+                fg, bg = fg.to(dev).contiguous(), bg.to(dev).contiguous()
+                h_, w_ = int(fg.shape[0]), int(fg.shape[1])
+            else:
+                if frames_rgb:
+                    raise ValueError("otvm_amd: frames_rgb applies to uint8 [H,W,3] frames only (fp32 input is BGR planar)")
+                fg = fg.to(dev, f32).contiguous()
+                bg = bg.to(dev, f32).contiguous()
+                h_, w_ = int(fg.shape[-2]), int(fg.shape[-1])
+            if H is None:
+                H, W = h_, w_
+            elif (h_, w_) != (H, W):
+                raise ValueError("otvm_amd: the sequences of a batch must share one resolution (%dx%d vs %dx%d)" % (w_, h_, W, H))
+            converted = converted or a is not a_in or fg is not fg_in or bg is not bg_in
+            if a.dim() != 5 or a.shape[0] != 1 or a.shape[1] != 1 or tuple(a.shape[-2:]) != (H, W):
+                raise ValueError("otvm_amd: inputs must be [1,1,C,H,W] (batch 1, one frame), got a %s for %dx%d frames"
+                                 % (tuple(a.shape), H, W))
+            ins.append((a, fg, bg))
+        if inputs_ready is not None and converted:
             # an input was converted / copied just now BY THE LAUNCH STREAM (host tensor, other dtype, non-contiguous): the
             # caller's promise covers the tensor it passed, not this copy -- the side streams must order themselves behind
             # the launch stream (the conservative path), or the query encoder would read the copy before it is written
             inputs_ready = None
-        if a.dim() != 5 or a.shape[0] != 1 or a.shape[1] != 1 or tuple(a.shape[-2:]) != (H, W):
-            raise ValueError("otvm_amd: inputs must be [1,1,C,H,W] (batch 1, one frame), got a %s for %dx%d frames"
-                             % (tuple(a.shape), H, W))
-        pl = self.plan(H, W)
+        pl = self.plan(H, W, B)
         stream = self._stream()
-        scaled_imgs = torch.empty((1, 1, 3, H, W), dtype=f32, device=dev)
-        alpha = torch.empty((1, 1, 1, H, W), dtype=f32, device=dev)
-        alpha_u8 = torch.empty((H, W), dtype=torch.uint8, device=dev)
-        tri_out = torch.empty((1, 1, 3, H, W), dtype=f32, device=dev)
-        tri_gt_out = torch.empty((1, 1, 3, H, W), dtype=f32, device=dev)
+        outs = [dict(scaled_imgs=torch.empty((1, 1, 3, H, W), dtype=f32, device=dev),
+                     alpha=torch.empty((1, 1, 1, H, W), dtype=f32, device=dev),
+                     alpha_u8=torch.empty((H, W), dtype=torch.uint8, device=dev),
+                     tri_out=torch.empty((1, 1, 3, H, W), dtype=f32, device=dev),
+                     tri_gt_out=torch.empty((1, 1, 3, H, W), dtype=f32, device=dev)) for _ in range(B)]
         # ---- deferred memorize of the previous frame (reference order: memorize(t) ends frame t, alpha/model.py:461-493;
         # here it opens frame t+1 so that Encoder_M(t) and Encoder_Q(t+1), two chains of small launches that cannot fill
         # 256 CUs on their own, run concurrently on two HIP streams; they meet before the memory read)
@@ -468,21 +506,24 @@ class HipEngine:
         self.guard_check(sync=False)
         pend, self.pending = self.pending, None
         if pend is not None and pend["plan"] is not pl:
-            self._memorize(pend, stream)                      # resolution changed: finish it in order
+            self._memorize(pend, stream)                      # resolution / batch changed: finish it in order
             pend = None
         par = self.parity
         self.parity ^= 1
-        pp = L.PreprocessParams()
-        pp.a = a.data_ptr()
-        if u8:
-            pp.fg_u8, pp.bg_u8, pp.u8_rgb = fg.data_ptr(), bg.data_ptr(), 1 if frames_rgb else 0
-        else:
-            pp.fg, pp.bg = fg.data_ptr(), bg.data_ptr()
-        pp.H, pp.W, pp.Hp, pp.Wp, pp.lh, pp.lw = H, W, pl.Hp, pl.Wp, pl.lh, pl.lw
-        for name, key in (("mean", "IMG_MEAN"), ("std", "IMG_STD"), ("mean_q", "trimap.model.Encoder_Q.mean"),
-                          ("std_q", "trimap.model.Encoder_Q.std"), ("mean_m", "trimap.model.Encoder_M.mean"),
-                          ("std_m", "trimap.model.Encoder_M.std")):
-            setattr(pp, name, (C.c_float * 3)(*self._consts(key)))
+        pps = []
+        for (a, fg, bg) in ins:
+            pp = L.PreprocessParams()
+            pp.a = a.data_ptr()
+            if u8:
+                pp.fg_u8, pp.bg_u8, pp.u8_rgb = fg.data_ptr(), bg.data_ptr(), 1 if frames_rgb else 0
+            else:
+                pp.fg, pp.bg = fg.data_ptr(), bg.data_ptr()
+            pp.H, pp.W, pp.Hp, pp.Wp, pp.lh, pp.lw = H, W, pl.Hp, pl.Wp, pl.lh, pl.lw
+            for name, key in (("mean", "IMG_MEAN"), ("std", "IMG_STD"), ("mean_q", "trimap.model.Encoder_Q.mean"),
+                              ("std_q", "trimap.model.Encoder_Q.std"), ("mean_m", "trimap.model.Encoder_M.mean"),
+                              ("std_m", "trimap.model.Encoder_M.std")):
+                setattr(pp, name, (C.c_float * 3)(*self._consts(key)))
+            pps.append(pp)
         # ---- the query encoder (STM.segment's Encoder_Q + KV_Q) needs nothing but the frame itself.  It runs on a side
         # stream: next to Encoder_M of the previous frame (two chains of small launches that cannot fill 256 CUs on their
         # own), and -- when the caller vouches that the frame is already in device memory (inputs_ready) and the host runs
@@ -503,11 +544,13 @@ class HipEngine:
                 ev_in = torch.cuda.Event()
                 ev_in.record(main)
                 side.wait_event(ev_in)
-            for t_ in (a, fg, bg):                           # read on the side stream too: keep the allocator from reusing them early
-                t_.record_stream(side)
-            pq = L.PreprocessParams.from_buffer_copy(pp)
-            pq.sq, pq.sq_ld = pl.SQ.ptr, pl.SQ.ld
-            L.check(lib.otvm_preprocess(C.byref(pq), side.cuda_stream), "preprocess (query encoder input)")
+            for b, (a, fg, bg) in enumerate(ins):
+                for t_ in (a, fg, bg):                       # read on the side stream too: keep the allocator from reusing them early
+                    t_.record_stream(side)
+                pq = L.PreprocessParams.from_buffer_copy(pps[b])
+                sq = pl.SQ.img(b)
+                pq.sq, pq.sq_ld = sq.ptr, sq.ld
+                L.check(lib.otvm_preprocess(C.byref(pq), side.cuda_stream), "preprocess (query encoder input)")
             pl.run("segment_a", side.cuda_stream, side)
             # The memory read is merged from per-chunk partials, so the bank may be visited in any grouping: every slot but
             # the one the previous frame is about to memorise is resident already -- its partials are computed here, on
@@ -532,11 +575,13 @@ class HipEngine:
             # the frame's own preprocess (composite, normalised copies for the alpha network and the next memorize) and the
             # clearing of the GroupNorm statistics need neither encoder: off the launch stream's serial chain
             if PRE_ON_S2:
-                for t_ in (a, fg, bg):
-                    t_.record_stream(side2)
-                scaled_imgs.record_stream(side2)
+                for b, (a, fg, bg) in enumerate(ins):
+                    for t_ in (a, fg, bg):
+                        t_.record_stream(side2)
+                    outs[b]["scaled_imgs"].record_stream(side2)
                 pl.clear_stats(side2.cuda_stream)
-                self._preprocess_rest(pl, pp, par, scaled_imgs, False, side2.cuda_stream)
+                for b in range(B):
+                    self._preprocess_rest(pl, pps[b], par, outs[b]["scaled_imgs"], False, side2.cuda_stream, b)
             if self.precision == L.PREC_F16X3:
                 if pend is not None:
                     nb, _ = bank_update(self.bank, pend["slot"], pend["first_frame"], pend["memorize"], pend["max_memory_num"])
@@ -555,23 +600,29 @@ class HipEngine:
             self._memorize(pend, stream)
         if not (use_side and PRE_ON_S2):
             pl.clear_stats(stream)
-            self._preprocess_rest(pl, pp, par, scaled_imgs, not use_side, stream)
+            for b in range(B):
+                self._preprocess_rest(pl, pps[b], par, outs[b]["scaled_imgs"], not use_side, stream, b)
 
-        if tri_gt is not None:
-            tri_src = tri_gt.to(dev, f32).contiguous()
-            L.check(lib.otvm_onehot_argmax3(tri_src.data_ptr(), H * W, tri_gt_out.data_ptr(), stream), "onehot")
-        else:
-            if dilate_kernel is None:
-                raise ValueError("otvm_amd: tri_gt=None needs a fixed dilate_kernel (reference eval always sets one)")
-            ws = pl.raw("tfa_ws", H * W, torch.uint8)
-            L.check(lib.otvm_trimap_from_alpha(a.data_ptr(), H, W, int(dilate_kernel), tri_gt_out.data_ptr(),
-                                               ws.data_ptr(), stream), "trimap_from_alpha")
-            tri_src = tri_gt_out
+        tri_srcs = []
+        for b in range(B):
+            tri_gt, tri_gt_out, a = tri_gt_l[b], outs[b]["tri_gt_out"], ins[b][0]
+            if tri_gt is not None:
+                tri_src = tri_gt.to(dev, f32).contiguous()
+                L.check(lib.otvm_onehot_argmax3(tri_src.data_ptr(), H * W, tri_gt_out.data_ptr(), stream), "onehot")
+            else:
+                if dilate_kernel is None:
+                    raise ValueError("otvm_amd: tri_gt=None needs a fixed dilate_kernel (reference eval always sets one)")
+                ws = pl.raws("tfa_ws", H * W, torch.uint8)[b]
+                L.check(lib.otvm_trimap_from_alpha(a.data_ptr(), H, W, int(dilate_kernel), tri_gt_out.data_ptr(),
+                                                   ws.data_ptr(), stream), "trimap_from_alpha")
+                tri_src = tri_gt_out
+            tri_srcs.append(tri_src)
 
         self.last_T_read = 0
         if first_frame:
-            L.check(lib.otvm_pad_trimap(tri_src.data_ptr(), H, W, pl.PROBS.data_ptr(), pl.Hp, pl.Wp, pl.lh, pl.lw, stream),
-                    "pad_trimap")
+            for b in range(B):
+                L.check(lib.otvm_pad_trimap(tri_srcs[b].data_ptr(), H, W, pl.PROBS_B[b].data_ptr(), pl.Hp, pl.Wp, pl.lh, pl.lw,
+                                            stream), "pad_trimap")
             # frame 1's query encoder (side stream) is ordered behind everything the launch stream was handed up to here:
             # loop-invariant inputs the caller created for this clip (the trimap flow's constant alpha) are complete
             self.ev_dec = torch.cuda.Event()
@@ -601,7 +652,7 @@ class HipEngine:
                 pl.memory_read(self.bank, stream)
             if self.prof is not None:
                 e1.record()
-                self.prof.append(("memory_read", 1280.0 * len(self.bank) * pl.hw * pl.hw, e0, e1, len(self.bank)))
+                self.prof.append(("memory_read", 1280.0 * len(self.bank) * pl.hw * pl.hw * B, e0, e1, len(self.bank)))
             pl.run("segment_b", stream)
             self.guard(pl.L4, "propagated trimap logits", stream, frame_id)
             self.ev_dec = torch.cuda.Event()                  # the query encoder's buffers are free again
@@ -615,30 +666,36 @@ class HipEngine:
             slot["frame"] = frame_id
             self.pending = dict(plan=pl, par=par, slot=slot, first_frame=first_frame, memorize=memorize,
                                 max_memory_num=max_memory_num)
-        L.check(lib.otvm_crop_outputs(pl.ALPHA_P.data_ptr(), pl.TRI_P.data_ptr(), pl.Hp, pl.Wp, H, W, pl.lh, pl.lw,
-                                      alpha.data_ptr(), alpha_u8.data_ptr(), tri_out.data_ptr(), stream), "crop")
-        self.last_alpha_u8 = alpha_u8
+        for b in range(B):
+            o = outs[b]
+            L.check(lib.otvm_crop_outputs(pl.ALPHA_P_B[b].data_ptr(), pl.TRI_P_B[b].data_ptr(), pl.Hp, pl.Wp, H, W, pl.lh, pl.lw,
+                                          o["alpha"].data_ptr(), o["alpha_u8"].data_ptr(), o["tri_out"].data_ptr(), stream), "crop")
+        self.last_alpha_u8 = outs[0]["alpha_u8"]
+        self.last_alpha_u8_b = [o["alpha_u8"] for o in outs]
         self.last_plan = pl
-        if self.check_finite and not bool(torch.isfinite(alpha).all()):
+        if self.check_finite and not all(bool(torch.isfinite(o["alpha"]).all()) for o in outs):
             raise FloatingPointError("otvm_amd: non-finite alpha at frame %d -- an activation probably left fp16's range on the "
                                      "f16x3 path; rerun with model.precision = 'f32' (exact-fp32 MFMA)" % frame_id)
         if last_frame or self.check_finite:
             # end of the clip: the caller synchronises to collect its results -- the guard's verdict for the whole clip is
             # read here (the reference's loop synchronises after every frame, eval.py:195-197)
             self.guard_check(sync=True)
-        return scaled_imgs, tri_out, tri_gt_out, alpha, a
+        return [(o["scaled_imgs"], o["tri_out"], o["tri_gt_out"], o["alpha"], ins[b][0]) for b, o in enumerate(outs)]
 
-    def _preprocess_rest(self, pl, pp, par, scaled_imgs, with_sq, stream):
-        """otvm_preprocess for everything but (with_sq False) the query encoder's input: the composite returned to the
-        caller, the alpha network's input channels, the next memorize's image channels, the refinement's image channels."""
+    def _preprocess_rest(self, pl, pp, par, scaled_imgs, with_sq, stream, b=0):
+        """otvm_preprocess of image ``b`` for everything but (with_sq False) the query encoder's input: the composite returned
+        to the caller, the alpha network's input channels, the next memorize's image channels, the refinement's image channels."""
         pm = L.PreprocessParams.from_buffer_copy(pp)
         pm.scaled_imgs = scaled_imgs.data_ptr()
-        pm.x11, pm.x11_ld = pl.X11.ptr, pl.X11.ld
+        x11 = pl.X11.img(b)
+        pm.x11, pm.x11_ld = x11.ptr, x11.ld
         if with_sq:
-            pm.sq, pm.sq_ld = pl.SQ.ptr, pl.SQ.ld
-        smv = pl.SMs[par].ch(16, 8)
+            sq = pl.SQ.img(b)
+            pm.sq, pm.sq_ld = sq.ptr, sq.ld
+        smv = pl.SMs[par].ch(16, 8).img(b)
         pm.sm, pm.sm_ld = smv.ptr, smv.ld
-        pm.d80, pm.d80_ld = pl.D80.ptr, pl.D80.ld
+        d80 = pl.D80.img(b)
+        pm.d80, pm.d80_ld = d80.ptr, d80.ld
         L.check(self.lib.otvm_preprocess(C.byref(pm), stream), "preprocess")
 
     def _memorize(self, pend, stream, tstream=None):
@@ -678,11 +735,13 @@ class HipEngine:
 class FramePlan:
     """Buffers + launch lists for one input resolution."""
 
-    def __init__(self, eng, H, W):
+    def __init__(self, eng, H, W, B=1):
         self.e = eng
         self.lib = eng.lib
         self.dev = eng.dev
-        self.H, self.W = H, W
+        self.H, self.W, self.B = H, W, B
+        if B > 1 and eng.precision != L.PREC_F16X3:
+            raise NotImplementedError("otvm_amd: batched sequences (B > 1) run on the f16x3 path only")
         self.lw, self.uw, self.lh, self.uh = pad_amounts(H, W, 32)
         self.Hp, self.Wp = H + self.lh + self.uh, W + self.lw + self.uw
         self.P = self.Hp * self.Wp
@@ -694,7 +753,8 @@ class FramePlan:
         self.n_gn = 0
         self.steps = {}
         self._build()
-        self.stats = torch.zeros(max(self.n_gn, 1) * 64, dtype=torch.float64, device=self.dev)
+        self.stats_bs = max(self.n_gn, 1) * 64                # doubles per image: one [32][2] block per GroupNorm
+        self.stats = torch.zeros(self.B * self.stats_bs, dtype=torch.float64, device=self.dev)
         self._bind_stats()
         self.autotune()
 
@@ -702,7 +762,8 @@ class FramePlan:
     @staticmethod
     def _signature(p):
         return (p.H, p.W, p.Cin, p.in_ld, p.Cout, p.out_ld, p.kh, p.kw, p.stride, p.pad, p.dil, p.in_relu, p.act, int(bool(p.bias)),
-                int(bool(p.residual)), p.res_ld, int(bool(p.gn_stats)), int(bool(p.in_scale)), int(bool(p.splitk_ws)), p.precision)
+                int(bool(p.residual)), p.res_ld, int(bool(p.gn_stats)), int(bool(p.in_scale)), int(bool(p.splitk_ws)), p.precision,
+                max(1, p.batch))
 
     def _time_conv(self, p, code, stream, reps=3):
         p.tune = code
@@ -765,8 +826,8 @@ class FramePlan:
         # the key / value convolutions of STM.memorize are bound to a bank slot at run time (kv_into_slot): time their
         # shapes here against scratch outputs, so the first memorised frame finds them in the cache
         H16, W16 = self.Hp // 16, self.Wp // 16
-        tk = Act(torch.empty(self.hw * 128, dtype=torch.float32, device=self.dev), H16, W16, 128)
-        tv = Act(torch.empty(self.hw * 512, dtype=torch.float32, device=self.dev), H16, W16, 512)
+        tk = Act(torch.empty(self.B * self.hw * 128, dtype=torch.float32, device=self.dev), H16, W16, 128, B=self.B, bs=self.hw * 128)
+        tv = Act(torch.empty(self.B * self.hw * 512, dtype=torch.float32, device=self.dev), H16, W16, 512, B=self.B, bs=self.hw * 512)
         n0, k0 = len(self._convs), len(self._keep)
         self.conv([], self.r4m, "trimap.model.KV_M_r4.Key", tk, pad=1)
         self.conv([], self.r4m, "trimap.model.KV_M_r4.Value", tv, pad=1)
@@ -786,7 +847,8 @@ class FramePlan:
     def buf(self, name, H, W, C):
         key = (name, H, W, C)
         if key not in self._bufs:
-            self._bufs[key] = Act(torch.zeros(H * W * C, dtype=torch.float32, device=self.dev), H, W, C)
+            self._bufs[key] = Act(torch.zeros(self.B * H * W * C, dtype=torch.float32, device=self.dev), H, W, C, B=self.B,
+                                  bs=H * W * C)
         return self._bufs[key]
 
     def raw(self, name, n, dtype=torch.float32):
@@ -794,6 +856,11 @@ class FramePlan:
         if key not in self._bufs:
             self._bufs[key] = torch.zeros(n, dtype=dtype, device=self.dev)
         return self._bufs[key]
+
+    def raws(self, name, n, dtype=torch.float32):
+        """One flat buffer of ``n`` elements PER IMAGE (planar tensors and workspaces of the per-image glue kernels)."""
+        t = self.raw(name, n * self.B, dtype)
+        return [t[b * n:(b + 1) * n] for b in range(self.B)]
 
     # ---- step builders (S = list being filled)
     def conv(self, S, x, wname, out, stride=1, pad=0, dil=1, act=NONE, in_relu=0, residual=None, in_norm=None):
@@ -805,9 +872,9 @@ class FramePlan:
         p = conv_params(x, w, out, w.bias, stride, pad, dil, act, in_relu, residual, self.e.precision, in_norm, self._ws)
         self._keep.append(p)
         self._convs.append((p, wname))
-        flops = 2 * Ho * Wo * w.O * w.kh * w.kw * w.I           # algorithmic (un-padded) 2*MAC
+        flops = 2 * Ho * Wo * w.O * w.kh * w.kw * w.I * x.B     # algorithmic (un-padded) 2*MAC, all images of the launch
         # algorithmic bytes: read the input once, the weights once, write the output once (+ residual read), fp32
-        abytes = 4 * (x.H * x.W * w.I + w.O * w.I * w.kh * w.kw + Ho * Wo * w.O * (2 if residual is not None else 1))
+        abytes = 4 * (x.B * x.H * x.W * w.I + w.O * w.I * w.kh * w.kw + x.B * Ho * Wo * w.O * (2 if residual is not None else 1))
         S.append((self.lib.otvm_conv2d, (C.byref(p),), "conv " + wname, flops, abytes, (x, out.ch(0, _rup(w.O, 4)) if out.C >= _rup(w.O, 4) else out)))
         return p
 
@@ -822,12 +889,19 @@ class FramePlan:
         if conv_p is not None and FUSE_GN_STATS:
             self._fused_stats.append((conv_p, idx))
         else:
-            S.append(("gn_stats", (x.ptr, x.P, x.C, x.ld), idx, "gn_stats " + name))
-        S.append(("gn_apply", (x.ptr, x.P, x.C, x.ld), idx,
-                  (sd[name + ".weight"].data_ptr(), sd[name + ".bias"].data_ptr(),
-                   0 if residual is None else residual.ptr, 0 if residual is None else residual.ld,
-                   0 if res_norm is None else res_norm[0], 0 if res_norm is None else res_norm[1],
-                   0 if res_norm is None else res_norm[2], act, out.ptr, out.ld), "gn_apply " + name))
+            S.append(("gn_stats", (x.ptr, x.P, x.C, x.ld), idx, (self.B, x.bs), "gn_stats " + name))
+        q = L.GnApplyParams()
+        q.x, q.P, q.C, q.ld = x.ptr, x.P, x.C, x.ld
+        q.gamma, q.beta = sd[name + ".weight"].data_ptr(), sd[name + ".bias"].data_ptr()
+        if residual is not None:
+            q.residual, q.res_ld, q.res_bs = residual.ptr, residual.ld, residual.bs
+        if res_norm is not None:
+            q.res_scale, q.res_shift, q.res_act = res_norm[0], res_norm[1], res_norm[2]
+            q.norm_bs = res_norm[3] if len(res_norm) > 3 else 0
+        q.act, q.out, q.out_ld = act, out.ptr, out.ld
+        q.batch, q.x_bs, q.out_bs = self.B, x.bs, out.bs
+        self._keep.append(q)
+        S.append(("gn_apply", q, idx, "gn_apply " + name))
 
     def gn_table_step(self, S, x, gn_name, producer_p):
         """Per-channel scale / shift of GroupNorm(gn_name) over the raw conv output ``x`` (statistics from the producing
@@ -836,10 +910,10 @@ class FramePlan:
         idx = self.n_gn
         self.n_gn += 1
         self._fused_stats.append((producer_p, idx))
-        tab = self.raw("gntab_" + gn_name, 2 * x.C)
+        tab = self.raw("gntab_" + gn_name, 2 * x.C * self.B)             # [B][scale C | shift C]
         S.append(("gn_table", (x.P, x.C, sd[gn_name + ".weight"].data_ptr(), sd[gn_name + ".bias"].data_ptr(),
-                               tab.data_ptr(), tab.data_ptr() + 4 * x.C), idx, "gn_table " + gn_name))
-        return tab.data_ptr(), tab.data_ptr() + 4 * x.C
+                               tab.data_ptr(), tab.data_ptr() + 4 * x.C), idx, 2 * x.C, "gn_table " + gn_name))
+        return tab.data_ptr(), tab.data_ptr() + 4 * x.C, 2 * x.C
 
     def gn_then_conv(self, S, x, gn_name, gn_act, producer_p, wname, out, **kw):
         """GroupNorm(32) + activation of the raw conv output ``x`` whose ONLY consumer is the conv ``wname``.  When
@@ -851,46 +925,50 @@ class FramePlan:
             probe = conv_params(x, w, out, w.bias, kw.get("stride", 1), kw.get("pad", 0), kw.get("dil", 1), kw.get("act", NONE),
                                 0, kw.get("residual"), self.e.precision, (1, 1, gn_act))
             if self.lib.otvm_conv2d_accepts_input_norm(C.byref(probe)):
-                sc, sh = self.gn_table_step(S, x, gn_name, producer_p)
-                return self.conv(S, x, wname, out, in_norm=(sc, sh, gn_act), **kw)
+                sc, sh, nbs = self.gn_table_step(S, x, gn_name, producer_p)
+                return self.conv(S, x, wname, out, in_norm=(sc, sh, gn_act, nbs), **kw)
         self.gn(S, x, gn_name, gn_act, conv_p=producer_p)
         return self.conv(S, x, wname, out, **kw)
 
     def _bind_stats(self):
-        base = self.stats.data_ptr()
+        base, sbs = self.stats.data_ptr(), self.stats_bs
         for conv_p, idx in self._fused_stats:
             conv_p.gn_stats = base + idx * 512
+            conv_p.gn_bs = sbs
         for key, S in self.steps.items():
             for i, st in enumerate(S):
                 if st[0] == "gn_stats":
-                    _, a, idx, label = st
-                    S[i] = (self.lib.otvm_gn_stats, a + (base + idx * 512,), label)
+                    _, a, idx, (nb, x_bs), label = st
+                    S[i] = (self.lib.otvm_gn_stats_b, a + (base + idx * 512, nb, x_bs, sbs), label)
                 elif st[0] == "gn_table":
-                    _, a, idx, label = st
-                    S[i] = (self.lib.otvm_gn_table, (base + idx * 512,) + a, label)
+                    _, a, idx, nbs, label = st
+                    S[i] = (self.lib.otvm_gn_table_b, (base + idx * 512,) + a + (self.B, sbs, nbs), label)
                 elif st[0] == "gn_apply":
-                    _, a, idx, b, label = st
-                    S[i] = (self.lib.otvm_gn_apply, a + (base + idx * 512,) + b, label)
+                    _, q, idx, label = st
+                    q.stats, q.stats_bs = base + idx * 512, sbs
+                    S[i] = (self.lib.otvm_gn_apply_b, (C.byref(q),), label)
 
     def upsample(self, S, x, out, add=None, norm=None):
-        """norm = (scale_ptr, shift_ptr, act): x is a raw GroupNorm input, normalised per source pixel while resampling."""
-        S.append((self.lib.otvm_upsample_bilinear,
+        """norm = (scale_ptr, shift_ptr, act, table stride): x is a raw GroupNorm input, normalised per source pixel while
+        resampling."""
+        S.append((self.lib.otvm_upsample_bilinear_b,
                   (x.ptr, x.H, x.W, x.C, x.ld, 0 if norm is None else norm[0], 0 if norm is None else norm[1],
                    0 if norm is None else norm[2], 0 if add is None else add.ptr, 0 if add is None else add.ld,
-                   out.ptr, out.H, out.W, out.ld), "upsample"))
+                   out.ptr, out.H, out.W, out.ld, x.B, x.bs, 0 if add is None else add.bs, out.bs,
+                   0 if norm is None else norm[3]), "upsample"))
 
     def gn_then_upsample(self, S, x, gn_name, gn_act, producer_p, out):
         """GroupNorm + activation of the raw conv output ``x`` whose only consumer is a bilinear resampling: the apply
         pass is folded into the resampling kernel (x stays raw, the normalised tensor is never written)."""
         if FUSE_GN_APPLY and FUSE_GN_STATS and producer_p is not None:
-            sc, sh = self.gn_table_step(S, x, gn_name, producer_p)
-            self.upsample(S, x, out, norm=(sc, sh, gn_act))
+            sc, sh, nbs = self.gn_table_step(S, x, gn_name, producer_p)
+            self.upsample(S, x, out, norm=(sc, sh, gn_act, nbs))
         else:
             self.gn(S, x, gn_name, gn_act, conv_p=producer_p)
             self.upsample(S, x, out)
 
     def maxpool(self, S, x, out):
-        S.append((self.lib.otvm_maxpool3x3s2, (x.ptr, x.H, x.W, x.C, x.ld, out.ptr, out.ld), "maxpool"))
+        S.append((self.lib.otvm_maxpool3x3s2_b, (x.ptr, x.H, x.W, x.C, x.ld, out.ptr, out.ld, x.B, x.bs, out.bs), "maxpool"))
 
     # ---- network pieces
     def gn_bottleneck(self, S, x, p, planes, stride, dil, has_ds, out):
@@ -952,7 +1030,7 @@ class FramePlan:
 
         # split-K workspaces, one per chain that may run concurrently with the others: [0] decoder + alpha network (launch
         # stream), [1] memorize (launch stream, but tuned / timed separately), [2] query encoder (side stream)
-        self.SPLITK_WS = [self.raw("splitk_ws%d" % i, 16 << 20) for i in range(4)]    # [3]: decoder skip branches (side stream 2)
+        self.SPLITK_WS = [self.raw("splitk_ws%d" % i, (16 << 20) * self.B) for i in range(4)]    # [3]: decoder skip branches (side stream 2)
         self._ws = self.SPLITK_WS[2]
         # ---------------- frame-level buffers
         self.X11 = self.buf("X11", Hp, Wp, 12)          # 0-2 normalised RGB, 3-8 distance encoding, 9-10 soft, 11 zero
@@ -962,11 +1040,13 @@ class FramePlan:
         # while frame t+1 writes its own.
         self.SMs = [self.buf("SM0", Hp, Wp, 24), self.buf("SM1", Hp, Wp, 24)]
         self.D80 = self.buf("D80", Hp, Wp, 80)          # conv_up3 out 0-63 | rgb_n 64-66 | rgb 67-69 | tri2 70-71 | alpha 72
-        self.PROBS = self.raw("probs", 3 * P)           # planar trimap probabilities fed to the encoding
-        self.CLS = self.raw("cls", P, torch.uint8)
-        self.ALPHA_P = self.raw("alpha_p", P)
-        self.TRI_P = self.raw("tri_p", 3 * P)
-        self.enc_ws = self.raw("enc_ws", int(lib.otvm_trimap_encode_ws_bytes(Hp, Wp)), torch.uint8)
+        # planar per-image tensors of the glue kernels (one per image of the batch; the un-suffixed names = image 0)
+        self.PROBS_B = self.raws("probs", 3 * P)        # planar trimap probabilities fed to the encoding
+        self.CLS_B = self.raws("cls", P, torch.uint8)
+        self.ALPHA_P_B = self.raws("alpha_p", P)
+        self.TRI_P_B = self.raws("tri_p", 3 * P)
+        self.enc_ws_B = self.raws("enc_ws", _rup(int(lib.otvm_trimap_encode_ws_bytes(Hp, Wp)), 256), torch.uint8)
+        self.PROBS, self.CLS, self.ALPHA_P, self.TRI_P = self.PROBS_B[0], self.CLS_B[0], self.ALPHA_P_B[0], self.TRI_P_B[0]
 
         # ---------------- STM segment (STM.py:239-257)
         S = []
@@ -1011,7 +1091,8 @@ class FramePlan:
             pm = mo
         self.L4 = self.buf("L4", H4, W4, 4)
         self.conv(S, pm, d + "pred", self.L4, pad=1, in_relu=1)
-        S.append((lib.otvm_upsample4_softmax3, (self.L4.ptr, H4, W4, self.L4.ld, self.PROBS.data_ptr()), "up4softmax"))
+        for b in range(self.B):
+            S.append((lib.otvm_upsample4_softmax3, (self.L4.img(b).ptr, H4, W4, self.L4.ld, self.PROBS_B[b].data_ptr()), "up4softmax"))
         self.steps["segment_b"] = S
 
         # ---------------- FBA encoder (FBA/models.py:251-269)
@@ -1044,36 +1125,38 @@ class FramePlan:
         # ---------------- FBA decoder (FBA/models.py:351-392)
         de = "NET.decoder."
         conv5 = self.PPMCAT.ch(0, 2048)
-        self.POOL = self.raw("ppm_pool", 50 * 2048)
-        self.POOL_WS = self.raw("ppm_ws", int(lib.otvm_ppm_pool_ws_bytes(H8, 2048)) // 4)
-        S.append((lib.otvm_ppm_pool, (conv5.ptr, H8, W8, 2048, conv5.ld, self.POOL.data_ptr(), self.POOL_WS.data_ptr()),
-                  "ppm_pool"))
+        self.POOL_B = self.raws("ppm_pool", 50 * 2048)
+        self.POOL_WS_B = self.raws("ppm_ws", int(lib.otvm_ppm_pool_ws_bytes(H8, 2048)) // 4)
+        for b in range(self.B):                          # (three small launches per image: not batched)
+            S.append((lib.otvm_ppm_pool, (conv5.img(b).ptr, H8, W8, 2048, conv5.ld, self.POOL_B[b].data_ptr(),
+                                          self.POOL_WS_B[b].data_ptr()), "ppm_pool"))
         if FUSE_PPM_HEAD and self.e.W[de + "ppm.0.1"].I_pad == 2048 and self.e.W[de + "ppm.0.1"].O == 256:
             # conv + bias + GroupNorm + LeakyReLU of the four pooled maps in ONE launch (16 launches as library calls)
             sd = self.e.sd
-            hp = L.PpmHeadParams()
-            hp.pooled, hp.C, hp.Cout, hp.act = self.POOL.data_ptr(), 2048, 256, LEAKY
-            ys = []
-            for i, s in enumerate((1, 2, 3, 6)):
-                w = self.e.W[de + "ppm.%d.1" % i]
-                y = self.buf("ppm_y%d" % i, s, s, 256)
-                ys.append(y)
-                hp.K_pad, hp.out_ld = w.K_pad, y.ld
-                hp.w[i], hp.bias[i] = w.w.data_ptr(), 0 if w.bias is None else w.bias.data_ptr()
-                hp.gamma[i], hp.beta[i] = sd[de + "ppm.%d.2.weight" % i].data_ptr(), sd[de + "ppm.%d.2.bias" % i].data_ptr()
-                hp.out[i] = y.ptr
-            self._keep.append(hp)
-            S.append((lib.otvm_ppm_head, (C.byref(hp),), "ppm_head"))
+            ys = [self.buf("ppm_y%d" % i, s_, s_, 256) for i, s_ in enumerate((1, 2, 3, 6))]
+            for b in range(self.B):
+                hp = L.PpmHeadParams()
+                hp.pooled, hp.C, hp.Cout, hp.act = self.POOL_B[b].data_ptr(), 2048, 256, LEAKY
+                for i in range(4):
+                    w = self.e.W[de + "ppm.%d.1" % i]
+                    hp.K_pad, hp.out_ld = w.K_pad, ys[i].ld
+                    hp.w[i], hp.bias[i] = w.w.data_ptr(), 0 if w.bias is None else w.bias.data_ptr()
+                    hp.gamma[i], hp.beta[i] = sd[de + "ppm.%d.2.weight" % i].data_ptr(), sd[de + "ppm.%d.2.bias" % i].data_ptr()
+                    hp.out[i] = ys[i].img(b).ptr
+                self._keep.append(hp)
+                S.append((lib.otvm_ppm_head, (C.byref(hp),), "ppm_head"))
             for i, y in enumerate(ys):
                 self.upsample(S, y, self.PPMCAT.ch(2048 + 256 * i, 256))
         else:
+            if self.B > 1:
+                raise NotImplementedError("otvm_amd: batched sequences need the fused PPM head (OTVM_PPM_HEAD=1)")
             base = 0
-            for i, s in enumerate((1, 2, 3, 6)):
-                pin = Act(self.POOL, s, s, 2048, 2048, base * 2048)
-                y = self.buf("ppm_y%d" % i, s, s, 256)
+            for i, s_ in enumerate((1, 2, 3, 6)):
+                pin = Act(self.POOL_B[0], s_, s_, 2048, 2048, base * 2048)
+                y = self.buf("ppm_y%d" % i, s_, s_, 256)
                 cp = self.conv(S, pin, de + "ppm.%d.1" % i, y)
                 self.gn_then_upsample(S, y, de + "ppm.%d.2" % i, LEAKY, cp, self.PPMCAT.ch(2048 + 256 * i, 256))
-                base += s * s
+                base += s_ * s_
         u1 = self.buf("u1a", H8, W8, 256)
         cp = self.conv(S, self.PPMCAT, de + "conv_up1.0", u1, pad=1)
         self.gn(S, u1, de + "conv_up1.1", LEAKY, conv_p=cp)
@@ -1091,9 +1174,10 @@ class FramePlan:
         hid_d = self.buf("hid_d", Hp, Wp, 16)
         self.conv(S, h32, de + "conv_up4.2", hid_d, pad=1, act=LEAKY)
         img = self.D80.ch(67, 3)
-        S.append((lib.otvm_fba_head,
-                  (hid_d.ptr, hid_d.ld, sd[de + "conv_up4.4.weight"].data_ptr(), sd[de + "conv_up4.4.bias"].data_ptr(), 7,
-                   img.ptr, img.ld, P, self.D80.ch(72, 1).ptr, self.D80.ld, 0, 0, 0), "fba_head7"))
+        for b in range(self.B):
+            S.append((lib.otvm_fba_head,
+                      (hid_d.img(b).ptr, hid_d.ld, sd[de + "conv_up4.4.weight"].data_ptr(), sd[de + "conv_up4.4.bias"].data_ptr(), 7,
+                       img.img(b).ptr, img.ld, P, self.D80.ch(72, 1).img(b).ptr, self.D80.ld, 0, 0, 0), "fba_head7"))
         # ---------------- refinement (FBA/models.py:417-435)
         rf = "NET.refine."
         r0 = self.buf("r0", Hp, Wp, 64)
@@ -1105,8 +1189,8 @@ class FramePlan:
         t1 = self.buf("rt1", Hp, Wp, 64)
         probe = conv_params(r0, w1, t1, w1.bias, 1, 1, 1, NONE, 0, None, e.precision, (1, 1, LEAKY))
         if FUSE_GN_APPLY and FUSE_GN_STATS and lib.otvm_conv2d_accepts_input_norm(C.byref(probe)):
-            sc, sh = self.gn_table_step(S, r0, rf + "conv1.1", cp)
-            x_norm = (sc, sh, LEAKY)
+            sc, sh, nbs = self.gn_table_step(S, r0, rf + "conv1.1", cp)
+            x_norm = (sc, sh, LEAKY, nbs)
         else:
             self.gn(S, r0, rf + "conv1.1", LEAKY, conv_p=cp)
         for l in ("layer1", "layer2"):
@@ -1123,10 +1207,11 @@ class FramePlan:
             SM = self.SMs[par]
             hid = SM.ch(0, 16)
             self.conv(S, h32, rf + "pred.2", hid, pad=1, act=LEAKY)
-            S.append((lib.otvm_fba_head,
-                      (hid.ptr, hid.ld, sd[rf + "pred.4.weight"].data_ptr(), sd[rf + "pred.4.bias"].data_ptr(), 10,
-                       img.ptr, img.ld, P, self.ALPHA_P.data_ptr(), 1, self.TRI_P.data_ptr(),
-                       SM.ch(16, 8).ptr, SM.ld), "fba_head10"))
+            for b in range(self.B):
+                S.append((lib.otvm_fba_head,
+                          (hid.img(b).ptr, hid.ld, sd[rf + "pred.4.weight"].data_ptr(), sd[rf + "pred.4.bias"].data_ptr(), 10,
+                           img.img(b).ptr, img.ld, P, self.ALPHA_P_B[b].data_ptr(), 1, self.TRI_P_B[b].data_ptr(),
+                           SM.ch(16, 8).img(b).ptr, SM.ld), "fba_head10"))
             self.steps["fba_tail%d" % par] = S
 
         # ---------------- STM memorize (STM.py:201-228); key/value convs are bound to a slot at run time
@@ -1210,63 +1295,81 @@ class FramePlan:
         for i, s in enumerate(e.free_slots):
             if s["plan"] is self:
                 return e.free_slots.pop(i)
-        H16, W16 = self.Hp // 16, self.Wp // 16
-        slot = dict(hw=self.hw, plan=self, k=Act(torch.zeros(self.hw * 128, dtype=torch.float32, device=self.dev), H16, W16, 128),
-                    v=Act(torch.zeros(self.hw * 512, dtype=torch.float32, device=self.dev), H16, W16, 512), frame=-1)
-        if e.precision == L.PREC_F16X3:        # packed (split fp16, MFMA fragment order) copy read by the f16x3 kernel
-            slot["packed"] = torch.zeros(int(self.lib.otvm_bank_slot_bytes_f16x3(self.hw)), dtype=torch.uint8, device=self.dev)
+        H16, W16, B = self.Hp // 16, self.Wp // 16, self.B
+        slot = dict(hw=self.hw, plan=self, frame=-1,
+                    k=Act(torch.zeros(B * self.hw * 128, dtype=torch.float32, device=self.dev), H16, W16, 128, B=B, bs=self.hw * 128),
+                    v=Act(torch.zeros(B * self.hw * 512, dtype=torch.float32, device=self.dev), H16, W16, 512, B=B, bs=self.hw * 512))
+        if e.precision == L.PREC_F16X3:        # packed (split fp16, MFMA fragment order) copy read by the f16x3 kernel, per image
+            nb = int(self.lib.otvm_bank_slot_bytes_f16x3(self.hw))
+            slot["packed_b"] = [torch.zeros(nb, dtype=torch.uint8, device=self.dev) for _ in range(B)]
+            slot["packed"] = slot["packed_b"][0]
         return slot
+
+    # ---- memory read (STM.py:140-163).  Every image of a batch has its own bank (per-sequence slots) and its own
+    # workspace: the read is launched per image (three launches of ~320 per frame; the rest of the frame is batched)
+    def _mem_ws_for(self, b, need):
+        if self.mem_ws is None:
+            self.mem_ws = [None] * self.B
+        w = self.mem_ws[b]
+        if w is None or w.numel() < need:
+            torch.cuda.synchronize(self.dev)                  # (rare: the bank grew; nothing in flight may use the old one)
+            w = self.mem_ws[b] = torch.empty(max(need, 2 * (0 if w is None else w.numel())), dtype=torch.uint8, device=self.dev)
+        return w
 
     def memory_read(self, bank, stream):
         T = len(bank)
         need = int(self.lib.otvm_memory_read_ws_bytes(self.hw, T))
-        if self.mem_ws is None or self.mem_ws.numel() < need:
-            torch.cuda.synchronize(self.dev)                  # (rare; the side stream may still be using the old one)
-            self.mem_ws = torch.empty(need, dtype=torch.uint8, device=self.dev)
-        out = self.M4.ch(0, 512)
-        if self.e.precision == L.PREC_F16X3:
-            slots = (C.c_void_p * T)(*[s["packed"].data_ptr() for s in bank])
-            L.check(self.lib.otvm_memory_read_f16x3(self.QK.ptr, self.QK.ld, slots, T, self.hw, out.ptr, out.ld,
-                                                    self.mem_ws.data_ptr(), stream), "memory_read_f16x3")
-            return
-        keys = (C.c_void_p * T)(*[s["k"].ptr for s in bank])
-        vals = (C.c_void_p * T)(*[s["v"].ptr for s in bank])
-        L.check(self.lib.otvm_memory_read(self.QK.ptr, self.QK.ld, keys, vals, T, self.hw, out.ptr, out.ld,
-                                          self.mem_ws.data_ptr(), stream), "memory_read")
+        for b in range(self.B):
+            ws = self._mem_ws_for(b, need)
+            out, qk = self.M4.ch(0, 512).img(b), self.QK.img(b)
+            if self.e.precision == L.PREC_F16X3:
+                slots = (C.c_void_p * T)(*[s["packed_b"][b].data_ptr() for s in bank])
+                L.check(self.lib.otvm_memory_read_f16x3(qk.ptr, qk.ld, slots, T, self.hw, out.ptr, out.ld, ws.data_ptr(), stream),
+                        "memory_read_f16x3")
+                continue
+            keys = (C.c_void_p * T)(*[s["k"].img(b).ptr for s in bank])
+            vals = (C.c_void_p * T)(*[s["v"].img(b).ptr for s in bank])
+            L.check(self.lib.otvm_memory_read(qk.ptr, qk.ld, keys, vals, T, self.hw, out.ptr, out.ld, ws.data_ptr(), stream),
+                    "memory_read")
 
     def memory_read_begin(self, old, fresh, stream):
         """f16x3 memory read, first step: partials over the slots ``old`` (already resident) on ``stream``; ``fresh`` (the
-        slot being memorised right now, 0 or 1 entries) follows in memory_read_finish."""
+        slot being memorised right now, 0 or 1 entries) follows in memory_read_fresh."""
         lib = self.lib
         np_cap = int(lib.otvm_memory_read_f16x3_partial_count(len(old), self.hw))
         if fresh:
             np_cap += int(lib.otvm_memory_read_f16x3_partial_count(len(fresh), self.hw))
         need = np_cap * self.hw * (512 + 2) * 4
-        if self.mem_ws is None or self.mem_ws.numel() < need:
-            torch.cuda.synchronize(self.dev)                  # (rare: the bank grew; nothing in flight may use the old one)
-            self.mem_ws = torch.empty(max(need, 2 * (0 if self.mem_ws is None else self.mem_ws.numel())), dtype=torch.uint8,
-                                      device=self.dev)
-        arr = (C.c_void_p * len(old))(*[s["packed"].data_ptr() for s in old])
-        end = C.c_int(0)
-        L.check(lib.otvm_memory_read_f16x3_partial(self.QK.ptr, self.QK.ld, arr, len(old), self.hw, self.mem_ws.data_ptr(), np_cap, 0,
-                                                   C.byref(end), stream), "memory_read_f16x3_partial")
-        return dict(old=old, fresh=fresh, np_cap=np_cap, done=end.value, ws=self.mem_ws)
+        wss, done = [], 0
+        for b in range(self.B):
+            ws = self._mem_ws_for(b, need)
+            qk = self.QK.img(b)
+            arr = (C.c_void_p * len(old))(*[s["packed_b"][b].data_ptr() for s in old])
+            end = C.c_int(0)
+            L.check(lib.otvm_memory_read_f16x3_partial(qk.ptr, qk.ld, arr, len(old), self.hw, ws.data_ptr(), np_cap, 0, C.byref(end),
+                                                       stream), "memory_read_f16x3_partial")
+            wss.append(ws)
+            done = end.value
+        return dict(old=old, fresh=fresh, np_cap=np_cap, done=done, ws=wss)
 
     def memory_read_fresh(self, split, stream):
         lib, n = self.lib, split["done"]
         if split["fresh"]:
             fr = split["fresh"]
-            arr = (C.c_void_p * len(fr))(*[s["packed"].data_ptr() for s in fr])
-            end = C.c_int(0)
-            L.check(lib.otvm_memory_read_f16x3_partial(self.QK.ptr, self.QK.ld, arr, len(fr), self.hw, split["ws"].data_ptr(),
-                                                       split["np_cap"], n, C.byref(end), stream), "memory_read_f16x3_partial")
+            for b in range(self.B):
+                qk = self.QK.img(b)
+                arr = (C.c_void_p * len(fr))(*[s["packed_b"][b].data_ptr() for s in fr])
+                end = C.c_int(0)
+                L.check(lib.otvm_memory_read_f16x3_partial(qk.ptr, qk.ld, arr, len(fr), self.hw, split["ws"][b].data_ptr(),
+                                                           split["np_cap"], n, C.byref(end), stream), "memory_read_f16x3_partial")
             n = end.value
         split["done"] = n
 
     def memory_read_merge(self, split, stream):
-        out = self.M4.ch(0, 512)
-        L.check(self.lib.otvm_memory_read_f16x3_combine(split["ws"].data_ptr(), split["np_cap"], split["done"], self.hw, out.ptr,
-                                                        out.ld, stream), "memory_read_f16x3_combine")
+        for b in range(self.B):
+            out = self.M4.ch(0, 512).img(b)
+            L.check(self.lib.otvm_memory_read_f16x3_combine(split["ws"][b].data_ptr(), split["np_cap"], split["done"], self.hw,
+                                                            out.ptr, out.ld, stream), "memory_read_f16x3_combine")
 
     def kv_into_slot(self, slot, stream):
         if "kv_steps" not in slot:
@@ -1287,13 +1390,16 @@ class FramePlan:
                 prof.append((st[2], st[3], e0, e1, st[4]))
         self.e.guard(slot["k"], "memorised key", stream, slot["frame"])
         self.e.guard(slot["v"], "memorised value", stream, slot["frame"])
-        if "packed" in slot:
-            L.check(self.lib.otvm_bank_pack_f16x3(slot["k"].ptr, slot["v"].ptr, self.hw, slot["packed"].data_ptr(), stream),
-                    "bank_pack")
+        if "packed_b" in slot:
+            for b in range(self.B):
+                L.check(self.lib.otvm_bank_pack_f16x3(slot["k"].img(b).ptr, slot["v"].img(b).ptr, self.hw,
+                                                      slot["packed_b"][b].data_ptr(), stream), "bank_pack")
 
     def encode(self, stream, cls_override=None):
-        """8-channel trimap encoding of PROBS into X11[3:11] / D80[70:72] (alpha/model.py:40-53)."""
-        L.check(self.lib.otvm_trimap_encode(self.PROBS.data_ptr(), self.Hp, self.Wp,
-                                            0 if cls_override is None else cls_override.data_ptr(), self.CLS.data_ptr(),
-                                            self.X11.ptr, self.X11.ld, self.D80.ptr, self.D80.ld, self.enc_ws.data_ptr(),
-                                            stream), "trimap_encode")
+        """8-channel trimap encoding of PROBS into X11[3:11] / D80[70:72] (alpha/model.py:40-53), image by image."""
+        for b in range(self.B):
+            co = None if cls_override is None else (cls_override[b] if isinstance(cls_override, (list, tuple)) else cls_override)
+            x11, d80 = self.X11.img(b), self.D80.img(b)
+            L.check(self.lib.otvm_trimap_encode(self.PROBS_B[b].data_ptr(), self.Hp, self.Wp, 0 if co is None else co.data_ptr(),
+                                                self.CLS_B[b].data_ptr(), x11.ptr, x11.ld, d80.ptr, d80.ld,
+                                                self.enc_ws_B[b].data_ptr(), stream), "trimap_encode")

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3 = 0, 1
-ABI_VERSION = 10         # include/otvm_hip.h OTVM_ABI_VERSION
+ABI_VERSION = 11         # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -26,7 +26,15 @@ class ConvParams(C.Structure):
                 ("gn_stats", vp),
                 ("in_scale", vp), ("in_shift", vp), ("in_act", i32),
                 ("tune", i32),
-                ("splitk_ws", vp), ("splitk_ws_bytes", i64)]
+                ("splitk_ws", vp), ("splitk_ws_bytes", i64),
+                ("batch", i32), ("in_bs", i64), ("out_bs", i64), ("res_bs", i64), ("gn_bs", i32), ("norm_bs", i32)]
+
+
+class GnApplyParams(C.Structure):
+    _fields_ = [("x", vp), ("P", i64), ("C", i32), ("ld", i32), ("stats", vp), ("gamma", vp), ("beta", vp),
+                ("residual", vp), ("res_ld", i32), ("res_scale", vp), ("res_shift", vp), ("res_act", i32), ("act", i32),
+                ("out", vp), ("out_ld", i32),
+                ("batch", i32), ("x_bs", i64), ("res_bs", i64), ("out_bs", i64), ("stats_bs", i32), ("norm_bs", i32)]
 
 
 class PreprocessParams(C.Structure):
@@ -84,6 +92,11 @@ _PROTOS = {
     "otvm_trimap_from_alpha": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "otvm_onehot_argmax3": (i32, [vp, i64, vp, vp]),
     "otvm_matting_metrics": (i32, [vp, vp, vp, vp, vp, vp, i64, vp, vp]),
+    "otvm_gn_stats_b": (i32, [vp, i64, i32, i32, vp, i32, i64, i32, vp]),
+    "otvm_gn_table_b": (i32, [vp, i64, i32, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "otvm_gn_apply_b": (i32, [C.POINTER(GnApplyParams), vp]),
+    "otvm_maxpool3x3s2_b": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i64, i64, vp]),
+    "otvm_upsample_bilinear_b": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i64, i64, i64, i32, vp]),
     "otvm_finite_guard": (i32, [vp, i64, i32, i32, f32, i32, vp, vp]),
     "otvm_clear": (i32, [vp, i64, vp]),
 }

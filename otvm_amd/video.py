@@ -148,6 +148,74 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
     return res
 
 
+def run_video_matte_batch(model, clips, trimaps=None, alphas=None, backgrounds=None, skip=10, max_num=5, frames_are_rgb=False,
+                          device=None, keep_on_device=False):
+    """Matte B sequences of one resolution and one length in LOCK-STEP (round 3): frame i of every clip goes through the
+    network in one batched step (EvalModel.forward_batch: one launch per layer over the B images, per-sequence memory
+    banks).  clips: list of B frame arrays ([T,H,W,3] uint8 / float, BGR unless frames_are_rgb); trimaps: list of B
+    first-frame one-hot trimaps [3,H,W] (demo flow) or None with alphas = list of B per-frame GT alpha lists (V108 flow:
+    the first-frame trimap is derived from the alpha); backgrounds: optional list of B per-frame background lists.
+    Sequences of a data set are independent, so batching them changes no result: each returned dict equals
+    run_video_matte of that clip alone (bit for bit under the same kernel configurations).  Returns a list of B dicts
+    (alpha, alpha_u8, trimap, bank_frames)."""
+    B = len(clips)
+    T = len(clips[0])
+    if any(len(c) != T for c in clips):
+        raise ValueError("run_video_matte_batch: the clips of a batch must have the same number of frames")
+    if (trimaps is None) == (alphas is None):
+        raise ValueError("run_video_matte_batch: give either trimaps (demo flow) or alphas (VideoMatting108 flow)")
+    core = model.module if hasattr(model, "module") else model
+    dev = device or next(core.parameters()).device
+    res = [dict(alpha=[], alpha_u8=[], trimap=[], bank_frames=[]) for _ in range(B)]
+    tri_dev = None if trimaps is None else [_as_tensor(t).to(dev).float()[None, None] for t in trimaps]
+    ones = None
+    for i in range(T):
+        A, FG, BG = [], [], []
+        for b in range(B):
+            f = _as_tensor(clips[b][i])
+            bk = _as_tensor(backgrounds[b][i]) if backgrounds is not None else None
+            if f.dtype == torch.uint8 and (bk is None or bk.dtype == torch.uint8):
+                fg = f.to(dev, non_blocking=True)
+                bg = fg if bk is None else bk.to(dev, non_blocking=True)
+                H, W = fg.shape[:2]
+                rgb = bool(frames_are_rgb)
+            else:
+                f = f.to(dev).float()
+                if frames_are_rgb:
+                    f = f.flip(-1)
+                fg = f.permute(2, 0, 1)[None, None].contiguous()
+                H, W = fg.shape[-2:]
+                if bk is not None:
+                    bk = bk.to(dev).float()
+                    if frames_are_rgb:
+                        bk = bk.flip(-1)
+                    bg = bk.permute(2, 0, 1)[None, None].contiguous()
+                else:
+                    bg = fg
+                rgb = False
+            if trimaps is not None:
+                if ones is None or ones.shape[-2:] != (H, W):
+                    ones = torch.ones(1, 1, 1, H, W, device=dev)
+                a = ones
+            else:
+                a = _as_tensor(alphas[b][i]).to(dev).float()[None, None, None]
+            A.append(a), FG.append(fg), BG.append(bg)
+        memorize, max_memory_num, large = memory_schedule(i, H, W, skip, max_num)
+        outs = core.forward_batch(A, FG, BG, tri_dev if tri_dev is not None else [None] * B, first_frame=(i == 0),
+                                  last_frame=(i == T - 1), memorize=memorize, max_memory_num=max_memory_num, large_input=large,
+                                  _frames_rgb=rgb)
+        u8s = core._engine.last_alpha_u8_b
+        bank = list(core.memories["frames"])
+        for b in range(B):
+            al, u8, tr = outs[b][3][0, 0, 0], u8s[b], outs[b][1][0, 0]
+            if not keep_on_device:
+                al, u8, tr = al.cpu(), u8.cpu(), tr.cpu()
+            res[b]["alpha"].append(al), res[b]["alpha_u8"].append(u8), res[b]["trimap"].append(tr)
+            res[b]["bank_frames"].append(bank)
+    return [dict(alpha=torch.stack(r["alpha"]), alpha_u8=torch.stack(r["alpha_u8"]), trimap=torch.stack(r["trimap"]),
+                 bank_frames=r["bank_frames"]) for r in res]
+
+
 class ClipMetrics:
     """SAD / MSE / dtSSD of a clip accumulated on the device (otvm_matting_metrics), reference definitions
     utils/tmp/metric.py:177-189,252-264 on the 8-bit alphas the path writes (eval.py:209).  One row of partial sums

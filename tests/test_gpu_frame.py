@@ -461,3 +461,67 @@ def test_range_guard_raises_when_the_bank_leaves_fp16_range(synth_sd):
     m0(torch.ones(1, 1, 1, H, W, device="cuda"), fg, fg, tri_gt=torch.from_numpy(tri)[None, None].cuda(), first_frame=True,
        last_frame=True, max_memory_num=5)
     assert int(m0._engine.guard_flag.item()) == 2 ** 31 - 1
+
+
+def test_batched_sequences_equal_single_runs(synth_sd, monkeypatch):
+    """Round 3, multi-sequence batching: B independent clips stepped in lock-step through ONE launch per layer
+    (EvalModel.forward_batch / run_video_matte_batch: otvm_conv_params.batch, otvm_gn_*_b, per-sequence banks) give, for every
+    clip, bit for bit the alphas / trimaps / 8-bit alphas of that clip matted alone -- under the same kernel configurations
+    (the plan-time autotuner times a layer per batch size and may pick another tile for B = 3 than for B = 1, i.e. another
+    fp32 summation order; here it is switched off so both runs use the built-in heuristic).  Demo flow and V108 flow,
+    padded size, a bank that appends / replaces / evicts."""
+    from otvm_amd import engine, helpers
+    from otvm_amd.synth_data import soft_alpha, synthetic_clip
+    from otvm_amd.video import run_video_matte, run_video_matte_batch
+    monkeypatch.setattr(engine, "AUTOTUNE", False)
+    cfg = helpers.default_cfg()
+
+    def mk(dk):
+        m = helpers.get_model_alpha(cfg, helpers.get_model_trimap(cfg, "Test", dk), "Test", dk)
+        m.load_state_dict(synth_sd, strict=True)
+        return m.cuda().eval()
+    H, W, T, B = 70, 90, 7, 3                                        # pads to 96 x 96
+    clips, tris = [], []
+    for b in range(B):
+        fr, tri = synthetic_clip(H, W, T, seed=300 + b)
+        clips.append(fr), tris.append(tri)
+    m = mk(12)
+    single = [run_video_matte(m, clips[b], trimap=tris[b], skip=3, max_num=3) for b in range(B)]
+    batched = run_video_matte_batch(m, clips, trimaps=tris, skip=3, max_num=3)
+    for b in range(B):
+        assert torch.equal(batched[b]["alpha"], single[b]["alpha"]), "demo flow, clip %d" % b
+        assert torch.equal(batched[b]["alpha_u8"], single[b]["alpha_u8"]) and torch.equal(batched[b]["trimap"], single[b]["trimap"])
+        assert batched[b]["bank_frames"] == single[b]["bank_frames"]
+    assert not torch.equal(batched[0]["alpha"], batched[1]["alpha"])          # (the clips do differ)
+    # V108 flow: per-frame GT alpha, separate backgrounds, trimap derived from the alpha
+    m5 = mk(5)
+    als = [[soft_alpha(H, W, t + b) for t in range(T)] for b in range(B)]
+    bgs = [synthetic_clip(H, W, T, seed=400 + b)[0] for b in range(B)]
+    single = [run_video_matte(m5, clips[b], alphas=als[b], backgrounds=bgs[b], skip=3, max_num=3) for b in range(B)]
+    batched = run_video_matte_batch(m5, clips, alphas=als, backgrounds=bgs, skip=3, max_num=3)
+    for b in range(B):
+        assert torch.equal(batched[b]["alpha"], single[b]["alpha"]), "V108 flow, clip %d" % b
+        assert torch.equal(batched[b]["alpha_u8"], single[b]["alpha_u8"])
+
+
+def test_batched_sequences_vs_oracle_with_autotune(synth_sd):
+    """The batched step under its own tuned configurations (the default) against the CPU oracle: alpha <= 1e-3 per clip."""
+    from oracle.otvm_oracle import OtvmOracle
+    from otvm_amd import helpers
+    from otvm_amd.synth_data import synthetic_clip
+    from otvm_amd.video import run_video_matte_batch
+    cfg = helpers.default_cfg()
+    m = helpers.get_model_alpha(cfg, helpers.get_model_trimap(cfg, "Test", 12), "Test", 12)
+    m.load_state_dict(synth_sd, strict=True)
+    m = m.cuda().eval()
+    H, W, T, B = 64, 96, 4, 2
+    clips, tris = zip(*[synthetic_clip(H, W, T, seed=500 + b) for b in range(B)])
+    res = run_video_matte_batch(m, list(clips), trimaps=list(tris), skip=3, max_num=3)
+    for b in range(B):
+        orc = OtvmOracle(synth_sd, dilate_kernel=12)
+        for t in range(T):
+            fg = torch.from_numpy(clips[b][t].astype(np.float32)).permute(2, 0, 1)[None, None].contiguous()
+            ref = orc.frame(torch.ones(1, 1, 1, H, W), fg, fg.clone(), tri_gt=torch.from_numpy(tris[b])[None, None], frame_id=t,
+                            first_frame=(t == 0), last_frame=(t == T - 1), memorize=(t % 3 == 0), max_memory_num=3)
+            d = float((res[b]["alpha"][t] - ref[3][0, 0, 0]).abs().max())
+            assert d <= ALPHA_TOL, "clip %d frame %d: alpha max-abs %.3e" % (b, t, d)
