@@ -980,13 +980,21 @@ class FramePlan:
         self.gn(S, t2, p + ".bn2", RELU, conv_p=cp)
         t3 = self.buf("bt3", Ho, Wo, planes * 4)
         cp3 = self.conv(S, t2, p + ".conv3", t3)
+        res_norm = None
         if has_ds:
             idt = self.buf("btd", Ho, Wo, planes * 4)
             cp = self.conv(S, x, p + ".downsample.0", idt, stride=stride)
-            self.gn(S, idt, p + ".downsample.1", NONE, conv_p=cp)
+            if FUSE_GN_APPLY and FUSE_GN_STATS:
+                # round 3: the identity path's GroupNorm (no activation) has ONE reader, the residual input of bn3's apply
+                # pass below: it is normalised there on the fly (res_scale / res_shift from otvm_gn_table) -- the four widest
+                # apply passes of the encoder (256 / 512 / 1024 / 2048 channels) are gone, the tensor stays raw in memory
+                sc, sh, nbs = self.gn_table_step(S, idt, p + ".downsample.1", cp)
+                res_norm = (sc, sh, NONE, nbs)
+            else:
+                self.gn(S, idt, p + ".downsample.1", NONE, conv_p=cp)
         else:
             idt = x
-        self.gn(S, t3, p + ".bn3", RELU, out=out, residual=idt, conv_p=cp3)
+        self.gn(S, t3, p + ".bn3", RELU, out=out, residual=idt, conv_p=cp3, res_norm=res_norm)
 
     def bn_bottleneck(self, S, x, p, planes, stride, has_ds, out, tag):
         Ho, Wo = x.H // stride, x.W // stride

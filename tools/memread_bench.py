@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--case", action="append")
+    ap.add_argument("--warm", type=int, default=3, help="untimed warm-up reads (0 under a profiler that counts every launch)")
     args = ap.parse_args()
     cases = [tuple(int(v) for v in c.split(",")) for c in args.case] if args.case else DEFAULT
     lib = L.load()
@@ -40,7 +41,7 @@ def main():
 
         def run():
             L.check(lib.otvm_memory_read_f16x3(q.data_ptr(), 128, sp, T, hw, out.data_ptr(), 512, ws.data_ptr(), st))
-        for _ in range(3):
+        for _ in range(args.warm):
             run()
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
