@@ -35,14 +35,15 @@ extern "C" {
 #define OTVM_PREC_F16X3 1
 
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 11   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
+#define OTVM_ABI_VERSION 12   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
                                  4: otvm_conv_params.splitk_ws; 5: otvm_preprocess_params.fg_u8/bg_u8/u8_rgb;
                                  6: otvm_conv_params.tune + otvm_conv2d_candidates;
                                  7: folded GroupNorm tables on otvm_gn_apply's residual and otvm_upsample_bilinear's input;
                                  8: otvm_memory_read_f16x3_partial / _combine / _partial_count; 9: otvm_ppm_head;
                                  10: otvm_finite_guard, otvm_clear;
                                  11: batch of images per launch (otvm_conv_params.batch ..., otvm_gn_*_b, otvm_upsample_bilinear_b,
-                                     otvm_maxpool3x3s2_b) */
+                                     otvm_maxpool3x3s2_b);
+                                 12: training forward (otvm_fba_head_train, otvm_upsample4_logits3, otvm_trimap_to_sm, otvm_loss_*) */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -308,6 +309,44 @@ int otvm_matting_metrics(const uint8_t* pred, const uint8_t* target, const uint8
 int otvm_finite_guard(const float* x, int64_t P, int C, int ld, float limit, int tag, int* flag, void* stream);
 /* stream-ordered zero fill (hipMemsetAsync) -- the GroupNorm statistics arena is cleared once per frame           */
 int otvm_clear(void* p, int64_t bytes, void* stream);
+
+/* ---------------------------------------------------------------- training forward -------------
+ * FullModel.forward of the reference's training class (models/alpha/model.py:189-312), FORWARD ONLY: the network runs on
+ * the kernels above (B clips in lock-step, memory every frame); these entry points add what the losses need.
+ * All tensors planar fp32; "N images" = batch x frames (x channels where noted); sums leave in fp64 accumulators that
+ * the caller zeroes and divides by the element counts torch.mean / mse_loss / CrossEntropyLoss use.               */
+/* the heads again with all outputs: out7 planar [7][P] = fused alpha, F, B (FBA/models.py:383-388,425-432);
+ * logits_out planar [3][P] = the refinement's trimap logits (n_out == 10)                                           */
+int otvm_fba_head_train(const float* hid, int hid_ld, const float* w, const float* b, int n_out, const float* img, int img_ld,
+                        int64_t P, float* out7, float* logits_out, void* stream);
+/* the STM decoder's logits, x4 bilinear (STM.py:136), WITHOUT the softmax: planar [3][Hp*Wp]                         */
+int otvm_upsample4_logits3(const float* logits, int h4, int w4, int ld, float* logits_out, void* stream);
+/* frame 0 of a training clip memorises the GROUND-TRUTH trimap (model.py:212, preds_trimap_refine[0] = tri[:,0]):
+ * planar [3][P] -> the unknown / foreground channels of the Encoder_M input buffer                                   */
+int otvm_trimap_to_sm(const float* tri, int64_t P, float* sm, int sm_ld, void* stream);
+/* model.py:59-60: out = in.flip(channel) * s on planar [N][3][P]; model.py:42-44: trimask = (argmax == unknown), class map */
+int otvm_scale_flip3(const float* in, int64_t N, int64_t P, float s, float* out, void* stream);
+int otvm_trimask(const float* tri, int64_t N, int64_t P, float* mask, unsigned char* cls, const float* gts, float* vis, void* stream);
+                                                    /* vis (optional): where(trimask, 128/255, gts), model.py:296-300 */
+/* fba_single_image_loss, per-pixel part (model.py:117-150): writes cF, cB, comp [N][3][P], alpha_out [N][P]; acc5 += sums of |a - gt|,
+ * |cF gt + cB (1-gt) - img|, |fgs a + bgs (1-a) - img|, |cF - fgs|, |cB - bgs|                                      */
+int otvm_loss_fba_comp(const float* pred7, const float* gt, const float* trimask, const float* fgs, const float* bgs, const float* img,
+                       int64_t N, int64_t P, float* cF, float* cB, float* comp, float* alpha_out, double* acc5, void* stream);
+/* L1_grad (utils/loss_func.py:44-51): acc += | |grad x| - |grad y| | over planar [N][H][W]                            */
+int otvm_loss_grad_l1(const float* x, const float* y, int64_t N, int H, int W, float eps, double* acc, void* stream);
+/* exclusion_loss (loss_func.py:56-82), one pyramid level over images [B][S][3][H][W]: acc1[S][4] (zeroed) receives the
+ * per-frame sums of |gx1|, |gy1|, |gx2|, |gy2|, acc2[B*S][2] (zeroed) the per-sample sums of the squared products       */
+int otvm_loss_exclusion_level(const float* img1, const float* img2, int B, int S, int H, int W, float eps, double* acc1, double* acc2,
+                              void* stream);
+int otvm_avgpool2(const float* x, int64_t N, int H, int W, float* y, void* stream);
+/* LapLoss (loss_func.py:95-155), one level: down = gauss(cur)[::2, ::2] for image and target (written), acc += weight *
+ * | (cur_i - up(down_i)) - (cur_t - up(down_t)) |                                                                    */
+int otvm_loss_lap_level(const float* cur_img, const float* cur_tgt, int64_t N, int H, int W, double weight, float* down_img,
+                        float* down_tgt, double* acc, void* stream);
+/* model.py:177-182: acc += ((x[b,t+1]-x[b,t]) - (y[b,t+1]-y[b,t]))^2 over planar [B][S][CP]                           */
+int otvm_loss_temporal(const float* x, const float* y, int B, int S, int64_t CP, double* acc, void* stream);
+/* nn.CrossEntropyLoss (model.py:286-290): acc += -log_softmax(logits)[cls] over planar logits [N][3][P], cls [N][P] u8 */
+int otvm_loss_ce3(const float* logits, const unsigned char* cls, int64_t N, int64_t P, double* acc, void* stream);
 
 #ifdef __cplusplus
 }

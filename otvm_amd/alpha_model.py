@@ -82,3 +82,18 @@ class EvalModel(nn.Module):
                               cls_override=_cls_override, frames_rgb=bool(_frames_rgb), inputs_ready=_inputs_ready)
         self.memory_update = memorize
         return out
+
+
+class FullModel(EvalModel):
+    """Mirror of the reference's TRAINING class ``models/alpha/model.py::FullModel`` (lines 9-312), forward only: same
+    constructor and state_dict as ``EvalModel``, ``forward(a, fg, bg, ignore_region=None, tri=None)`` over a batch of clips
+    ``[B, S, C, H, W]`` returning the reference's list ``[loss1, loss2, loss3, loss_trimap, scaled_imgs, tris_vis, alphas, comps,
+    scaled_gts, Fs, Bs, preds_trimap]`` (otvm_amd/train.py).  There is no backward: the library holds no gradient kernels."""
+    FBA_LOSS_NORMALIZE = True
+
+    @torch.no_grad()
+    def forward(self, a, fg, bg, ignore_region=None, tri=None):
+        if ignore_region is not None:
+            raise NotImplementedError("ignore_region is not used by the stage-4 training loop of the reference")
+        from .train import train_forward
+        return train_forward(self, a, fg, bg, tri)

@@ -24,6 +24,7 @@ SOURCES = [
     ("memory_read_f16x3.hip", []),
     ("metrics.hip", []),
     ("guard.hip", []),
+    ("losses.hip", ["-ffp-contract=off"]),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 

@@ -70,7 +70,8 @@ __global__ void pad_trimap_kernel(const float* __restrict__ tri, int H, int W, f
     }
 }
 
-__global__ void upsample4_softmax3_kernel(const float* __restrict__ lg, int h4, int w4, int ld, float* __restrict__ probs) {
+__global__ void upsample4_softmax3_kernel(const float* __restrict__ lg, int h4, int w4, int ld, float* __restrict__ probs,
+                                          float* __restrict__ logits_out) {
     const int Hp = h4 * 4, Wp = w4 * 4;
     const int64_t P = (int64_t)Hp * Wp;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
@@ -88,6 +89,12 @@ __global__ void upsample4_softmax3_kernel(const float* __restrict__ lg, int h4, 
             const float v10 = lg[((int64_t)y1 * w4 + x0) * ld + c], v11 = lg[((int64_t)y1 * w4 + x1) * ld + c];
             l[c] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
         }
+        if (logits_out) {                                       // training forward: the cross-entropy takes the logits
+            logits_out[i] = l[0];
+            logits_out[P + i] = l[1];
+            logits_out[2 * P + i] = l[2];
+        }
+        if (!probs) continue;
         const float m = fmaxf(l[0], fmaxf(l[1], l[2]));
         const float e0 = expf(l[0] - m), e1 = expf(l[1] - m), e2 = expf(l[2] - m);
         const float inv = 1.f / (e0 + e1 + e2);
@@ -106,7 +113,8 @@ __global__ __launch_bounds__(256) void fba_head_kernel(const float* __restrict__
                                                        const float* __restrict__ w, const float* __restrict__ b, int n_out,
                                                        const float* __restrict__ img, int img_ld, int64_t P,
                                                        float* __restrict__ alpha_out, int alpha_stride,
-                                                       float* __restrict__ tri_out, float* __restrict__ sm, int sm_ld) {
+                                                       float* __restrict__ tri_out, float* __restrict__ sm, int sm_ld,
+                                                       float* __restrict__ out7, float* __restrict__ logits_out) {
     __shared__ float sw[10 * 16 + 10];
     for (int i = threadIdx.x; i < n_out * 16; i += blockDim.x) sw[i] = w[i];
     for (int i = threadIdx.x; i < n_out; i += blockDim.x) sw[160 + i] = b[i];
@@ -148,8 +156,21 @@ __global__ __launch_bounds__(256) void fba_head_kernel(const float* __restrict__
             den += (F[c] - B[c]) * (F[c] - B[c]);
         }
         al = clamp01((al * 0.1f + num) / (den + 0.1f));
-        alpha_out[i * alpha_stride] = al;
-        if (n_out == 10) {
+        if (alpha_out) alpha_out[i * alpha_stride] = al;
+        if (out7) {                                             // training forward: the fused (alpha, F, B) of FBA/models.py:388
+            out7[i] = al;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                out7[(1 + c) * P + i] = F[c];
+                out7[(4 + c) * P + i] = B[c];
+            }
+        }
+        if (logits_out && n_out == 10) {
+            logits_out[i] = o[7];
+            logits_out[P + i] = o[8];
+            logits_out[2 * P + i] = o[9];
+        }
+        if (n_out == 10 && tri_out) {
             const float m = fmaxf(o[7], fmaxf(o[8], o[9]));
             const float e0 = expf(o[7] - m), e1 = expf(o[8] - m), e2 = expf(o[9] - m);
             const float inv = 1.f / (e0 + e1 + e2);
@@ -254,8 +275,30 @@ extern "C" int otvm_pad_trimap(const float* tri, int H, int W, float* out, int H
 
 extern "C" int otvm_upsample4_softmax3(const float* logits, int h4, int w4, int ld, float* probs, void* stream) {
     hipLaunchKernelGGL(upsample4_softmax3_kernel, dim3(grid_for((int64_t)h4 * w4 * 16)), dim3(256), 0, (hipStream_t)stream,
-                       logits, h4, w4, ld, probs);
+                       logits, h4, w4, ld, probs, (float*)nullptr);
     OTVM_CHECK_LAUNCH("otvm_upsample4_softmax3");
+    return 0;
+}
+
+extern "C" int otvm_upsample4_logits3(const float* logits, int h4, int w4, int ld, float* logits_out, void* stream) {
+    OTVM_REQUIRE(logits && logits_out, "otvm_upsample4_logits3: null pointer");
+    hipLaunchKernelGGL(upsample4_softmax3_kernel, dim3(grid_for((int64_t)h4 * w4 * 16)), dim3(256), 0, (hipStream_t)stream,
+                       logits, h4, w4, ld, (float*)nullptr, logits_out);
+    OTVM_CHECK_LAUNCH("otvm_upsample4_logits3");
+    return 0;
+}
+
+__global__ void trimap_to_sm_kernel(const float* __restrict__ tri, int64_t P, float* __restrict__ sm, int sm_ld) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+        sm[i * sm_ld + 3] = tri[P + i];                         // unknown -> conv1_m (STM.py:58)
+        sm[i * sm_ld + 4] = tri[2 * P + i];                     // foreground -> conv1_o
+    }
+}
+
+extern "C" int otvm_trimap_to_sm(const float* tri, int64_t P, float* sm, int sm_ld, void* stream) {
+    OTVM_REQUIRE(tri && sm && P > 0, "otvm_trimap_to_sm: bad arguments");
+    hipLaunchKernelGGL(trimap_to_sm_kernel, dim3(grid_for(P)), dim3(256), 0, (hipStream_t)stream, tri, P, sm, sm_ld);
+    OTVM_CHECK_LAUNCH("otvm_trimap_to_sm");
     return 0;
 }
 
@@ -266,8 +309,19 @@ extern "C" int otvm_fba_head(const float* hid, int hid_ld, const float* w, const
     OTVM_REQUIRE(n_out == 7 || tri_out, "otvm_fba_head: tri_out required when n_out == 10");
     OTVM_REQUIRE(hid_ld % 4 == 0 && ((uintptr_t)hid & 15) == 0, "otvm_fba_head: hid view must be 16-byte aligned");
     hipLaunchKernelGGL(fba_head_kernel, dim3(grid_for(P)), dim3(256), 0, (hipStream_t)stream, hid, hid_ld, w, b, n_out, img,
-                       img_ld, P, alpha_out, alpha_stride, tri_out, sm, sm_ld);
+                       img_ld, P, alpha_out, alpha_stride, tri_out, sm, sm_ld, (float*)nullptr, (float*)nullptr);
     OTVM_CHECK_LAUNCH("otvm_fba_head");
+    return 0;
+}
+
+extern "C" int otvm_fba_head_train(const float* hid, int hid_ld, const float* w, const float* b, int n_out, const float* img,
+                                   int img_ld, int64_t P, float* out7, float* logits_out, void* stream) {
+    OTVM_REQUIRE(n_out == 7 || n_out == 10, "otvm_fba_head_train: n_out must be 7 or 10 (got %d)", n_out);
+    OTVM_REQUIRE(out7 && (n_out == 7 || logits_out), "otvm_fba_head_train: out7 (and logits_out for n_out == 10) required");
+    OTVM_REQUIRE(hid_ld % 4 == 0 && ((uintptr_t)hid & 15) == 0, "otvm_fba_head_train: hid view must be 16-byte aligned");
+    hipLaunchKernelGGL(fba_head_kernel, dim3(grid_for(P)), dim3(256), 0, (hipStream_t)stream, hid, hid_ld, w, b, n_out, img,
+                       img_ld, P, (float*)nullptr, 0, (float*)nullptr, (float*)nullptr, 0, out7, logits_out);
+    OTVM_CHECK_LAUNCH("otvm_fba_head_train");
     return 0;
 }
 

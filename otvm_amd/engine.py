@@ -437,9 +437,11 @@ class HipEngine:
                                  frame_id, None if cls_override is None else [cls_override], frames_rgb, inputs_ready)[0]
 
     def _frame_batch(self, a_l, fg_l, bg_l, tri_gt_l, first_frame=False, last_frame=False, memorize=False, max_memory_num=2,
-                     dilate_kernel=None, frame_id=None, cls_override=None, frames_rgb=False, inputs_ready=None):
+                     dilate_kernel=None, frame_id=None, cls_override=None, frames_rgb=False, inputs_ready=None, train=None):
         """The same frame step for B independent sequences in LOCK-STEP (round 3): lists of B inputs of one resolution, one
         memory schedule (first_frame / last_frame / memorize / max_memory_num apply to all), per-sequence banks.  Every
+        (train: buffers of the training-mode forward, otvm_amd/train.py -- the heads' full outputs and the raw logits are
+        written there as well, and frame 0 memorises the ground-truth trimap.)  Every
         layer is ONE launch over the B images (otvm_conv_params.batch, otvm_gn_*_b, ...): the weights are read once, and
         the small maps of the encoders -- too few tiles for 256 CUs from one image -- fill the chip.  Each image is computed
         exactly as a batch-1 call computes it (same tiles, same summation order).  Returns a list of B 5-tuples."""
@@ -655,12 +657,34 @@ class HipEngine:
                 self.prof.append(("memory_read", 1280.0 * len(self.bank) * pl.hw * pl.hw * B, e0, e1, len(self.bank)))
             pl.run("segment_b", stream)
             self.guard(pl.L4, "propagated trimap logits", stream, frame_id)
+            if train is not None and train.get("seg_logits") is not None:
+                for b in range(B):                             # the cross-entropy takes the logits (model.py:286-288)
+                    l4 = pl.L4.img(b)
+                    L.check(lib.otvm_upsample4_logits3(l4.ptr, l4.H, l4.W, l4.ld, train["seg_logits"][b].data_ptr(), stream),
+                            "upsample4_logits3")
             self.ev_dec = torch.cuda.Event()                  # the query encoder's buffers are free again
             self.ev_dec.record(main)
         pl.encode(stream, cls_override)
         pl.run("fba", stream)
         pl.run("fba_tail%d" % par, stream)
         self.guard(pl.SMs[par].ch(0, 16), "hidden state", stream, frame_id)
+        if train is not None:
+            # training forward (model.py:226-233,259-275): the fused (alpha, F, B) of both heads and the refinement's trimap
+            # logits feed the losses; frame 0 memorises the ground-truth trimap (preds_trimap_refine[0] = tri[:, 0])
+            sd, P_ = self.sd, pl.P
+            img = pl.D80.ch(67, 3)
+            for b in range(B):
+                hd, hr = pl.HID_D.img(b), pl.SMs[par].ch(0, 16).img(b)
+                L.check(lib.otvm_fba_head_train(hd.ptr, hd.ld, sd["NET.decoder.conv_up4.4.weight"].data_ptr(),
+                                                sd["NET.decoder.conv_up4.4.bias"].data_ptr(), 7, img.img(b).ptr, img.ld, P_,
+                                                train["dec7"][b].data_ptr(), 0, stream), "fba_head_train (decoder)")
+                L.check(lib.otvm_fba_head_train(hr.ptr, hr.ld, sd["NET.refine.pred.4.weight"].data_ptr(),
+                                                sd["NET.refine.pred.4.bias"].data_ptr(), 10, img.img(b).ptr, img.ld, P_,
+                                                train["ref7"][b].data_ptr(), train["ref_logits"][b].data_ptr(), stream),
+                        "fba_head_train (refinement)")
+                if train.get("tri0") is not None:
+                    smv = pl.SMs[par].ch(16, 8).img(b)
+                    L.check(lib.otvm_trimap_to_sm(train["tri0"][b].data_ptr(), P_, smv.ptr, smv.ld, stream), "trimap_to_sm")
         if not last_frame:
             slot = pl.new_slot()
             slot["frame"] = frame_id
@@ -1179,7 +1203,7 @@ class FramePlan:
         self.gn_then_upsample(S, u3, de + "conv_up3.1", LEAKY, cp, self.D80.ch(0, 64))
         h32 = self.buf("h32", Hp, Wp, 32)
         self.conv(S, self.D80, de + "conv_up4.0", h32, pad=1, act=LEAKY)      # ch 72.. carry zero weights
-        hid_d = self.buf("hid_d", Hp, Wp, 16)
+        hid_d = self.HID_D = self.buf("hid_d", Hp, Wp, 16)
         self.conv(S, h32, de + "conv_up4.2", hid_d, pad=1, act=LEAKY)
         img = self.D80.ch(67, 3)
         for b in range(self.B):

@@ -12,14 +12,17 @@ def get_model_name(cfg):
 
 
 def get_model_trimap(cfg, mode="Test", dilate_kernel=None):
-    if mode != "Test":
-        raise NotImplementedError("otvm_amd covers the inference path (mode='Test') only")
+    # mode='Train' (helpers.py:332-346 returns the training class there): the same parameter container -- the training
+    # forward (otvm_amd/train.py, forward only) is driven by the alpha model as well
+    if mode not in ("Test", "Train"):
+        raise ValueError("mode must be 'Test' or 'Train'")
     from .trimap_model import FullModel_eval
     return FullModel_eval(eps=0, stage=cfg.TRAIN.STAGE, dilate_kernel=dilate_kernel, hdim=16)
 
 
 def get_model_alpha(cfg, model_trimap, mode="Test", dilate_kernel=None):
-    if mode != "Test":
-        raise NotImplementedError("otvm_amd covers the inference path (mode='Test') only")
-    from .alpha_model import EvalModel
-    return EvalModel(dilate_kernel=dilate_kernel, trimap=model_trimap, stage=cfg.TRAIN.STAGE)
+    if mode not in ("Test", "Train"):
+        raise ValueError("mode must be 'Test' or 'Train'")
+    from .alpha_model import EvalModel, FullModel
+    cls = EvalModel if mode == "Test" else FullModel          # 'Train': forward-only mirror of models/alpha/model.py::FullModel
+    return cls(dilate_kernel=dilate_kernel, trimap=model_trimap, stage=cfg.TRAIN.STAGE)

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3 = 0, 1
-ABI_VERSION = 11         # include/otvm_hip.h OTVM_ABI_VERSION
+ABI_VERSION = 12         # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -97,6 +97,18 @@ _PROTOS = {
     "otvm_gn_apply_b": (i32, [C.POINTER(GnApplyParams), vp]),
     "otvm_maxpool3x3s2_b": (i32, [vp, i32, i32, i32, i32, vp, i32, i32, i64, i64, vp]),
     "otvm_upsample_bilinear_b": (i32, [vp, i32, i32, i32, i32, vp, vp, i32, vp, i32, vp, i32, i32, i32, i32, i64, i64, i64, i32, vp]),
+    "otvm_fba_head_train": (i32, [vp, i32, vp, vp, i32, vp, i32, i64, vp, vp, vp]),
+    "otvm_upsample4_logits3": (i32, [vp, i32, i32, i32, vp, vp]),
+    "otvm_trimap_to_sm": (i32, [vp, i64, vp, i32, vp]),
+    "otvm_scale_flip3": (i32, [vp, i64, i64, f32, vp, vp]),
+    "otvm_trimask": (i32, [vp, i64, i64, vp, vp, vp, vp, vp]),
+    "otvm_loss_fba_comp": (i32, [vp, vp, vp, vp, vp, vp, i64, i64, vp, vp, vp, vp, vp, vp]),
+    "otvm_loss_grad_l1": (i32, [vp, vp, i64, i32, i32, f32, vp, vp]),
+    "otvm_loss_exclusion_level": (i32, [vp, vp, i32, i32, i32, i32, f32, vp, vp, vp]),
+    "otvm_avgpool2": (i32, [vp, i64, i32, i32, vp, vp]),
+    "otvm_loss_lap_level": (i32, [vp, vp, i64, i32, i32, C.c_double, vp, vp, vp, vp]),
+    "otvm_loss_temporal": (i32, [vp, vp, i32, i32, i64, vp, vp]),
+    "otvm_loss_ce3": (i32, [vp, vp, i64, i64, vp, vp]),
     "otvm_finite_guard": (i32, [vp, i64, i32, i32, f32, i32, vp, vp]),
     "otvm_clear": (i32, [vp, i64, vp]),
 }

@@ -57,3 +57,31 @@ def soft_alpha(H, W, t=0):
     a = np.clip((H / 3.5 - r) / edge + 0.5, 0, 1)
     # quantise like an 8-bit PNG alpha channel (dataset.py:863-864)
     return (np.floor(a * 255.0 + 0.5) / 255.0).astype(np.float32)
+
+
+def train_batch(B, S, H, W, seed=0, radius=4):
+    """A training-style batch (reference dataset conventions, models/alpha/model.py:189-196): B clips of S frames,
+    a [B,S,1,H,W] soft GT alpha, fg / bg [B,S,3,H,W] float32 BGR 0..255, tri [B,S,3,H,W] one-hot GT trimap of EVERY frame
+    ([bg, unknown, fg]; unknown = the soft band of the alpha dilated by ``radius`` pixels).  Pure numpy."""
+    a = np.empty((B, S, 1, H, W), np.float32)
+    fg = np.empty((B, S, 3, H, W), np.float32)
+    bg = np.empty((B, S, 3, H, W), np.float32)
+    tri = np.zeros((B, S, 3, H, W), np.float32)
+    for b in range(B):
+        f, _ = synthetic_clip(H, W, S, seed * 100 + b)
+        g, _ = synthetic_clip(H, W, S, seed * 100 + 50 + b)
+        for s in range(S):
+            al = soft_alpha(H, W, s + 2 * b)
+            a[b, s, 0] = al
+            fg[b, s] = f[s].astype(np.float32).transpose(2, 0, 1)
+            bg[b, s] = g[s][::-1, ::-1].astype(np.float32).transpose(2, 0, 1)
+            soft = (al > 0) & (al < 1)
+            un = np.zeros_like(soft)
+            pad = np.pad(soft, radius)
+            for dy in range(2 * radius + 1):
+                for dx in range(2 * radius + 1):
+                    un |= pad[dy:dy + H, dx:dx + W]
+            tri[b, s, 1] = un
+            tri[b, s, 2] = (al >= 1) & ~un
+            tri[b, s, 0] = ~(un | ((al >= 1) & ~un))
+    return a, fg, bg, tri

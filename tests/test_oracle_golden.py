@@ -159,3 +159,24 @@ def test_memory_read_query_blocks_equal_one_matrix():
     f64 = memory_read(keys, vals, qk, qv, dtype=torch.float64, max_bytes=64 * T * h * w * 8)
     assert f64.dtype == torch.float32 and float((one - f64).abs().max()) <= 2e-5
     assert torch.equal(one[512:], qv) and torch.equal(f64[512:], qv)
+
+
+@pytest.mark.parametrize("name", ["b2_s3_64x64", "b1_s4_64x96"])
+def test_train_oracle_vs_reference_fixture(name):
+    """oracle/train_oracle.py (training-mode forward + the FBA / trimap losses) against the outputs of the
+    reference's own FullModel.forward (tests/golden/make_train_golden.py).  Batch 1 is bit-identical on the generating
+    machine; with batch 2 the reference convolves both samples in one oneDNN call (another blocking than per sample)."""
+    import numpy as np
+    import torch
+    from oracle.otvm_oracle import OtvmOracle
+    from oracle.train_oracle import train_forward
+    from otvm_amd.synth_data import train_batch
+    from otvm_amd.synth_weights import synthetic_state_dict
+    g = np.load(os.path.join(GOLDEN, "train_%s.npz" % name))
+    B, S, H, W, seed = (int(g[k]) for k in ("B", "S", "H", "W", "seed"))
+    a, fg, bg, tri = (torch.from_numpy(x) for x in train_batch(B, S, H, W, seed))
+    r = train_forward(OtvmOracle(synthetic_state_dict(0)), a, fg, bg, tri)
+    for k in ("loss1", "loss2", "loss3", "loss_trimap"):
+        assert abs(float(r[k]) - float(g[k])) <= 2e-5 * max(1.0, abs(float(g[k]))), (k, float(r[k]), float(g[k]))
+    for k in ("alphas", "comps", "Fs", "Bs", "preds_trimap"):
+        assert float((r[k] - torch.from_numpy(g[k])).abs().max()) <= 2e-4, k
