@@ -42,16 +42,18 @@ def test_loss_kernels_vs_oracle_functions():
     mask, vis = torch.empty(5, H, W, device=dev), torch.empty(5, H, W, device=dev)
     cls = torch.empty(5, H, W, dtype=torch.uint8, device=dev)
     gt5 = torch.rand(5, H, W, generator=g)
-    L.check(lib.otvm_trimask(tri.to(dev).data_ptr(), 5, H * W, mask.data_ptr(), cls.data_ptr(), gt5.to(dev).data_ptr(), vis.data_ptr(), st))
+    tri_d, gt5_d, lg_d = tri.to(dev), gt5.to(dev), lg.to(dev)        # (kept alive: the raw pointers go to the C ABI)
+    L.check(lib.otvm_trimask(tri_d.data_ptr(), 5, H * W, mask.data_ptr(), cls.data_ptr(), gt5_d.data_ptr(), vis.data_ptr(), st))
     assert torch.equal(cls.cpu().long(), tri.max(dim=1)[1]) and torch.equal(mask.cpu(), (tri.max(dim=1)[1] == 1).float())
     assert torch.equal(vis.cpu(), torch.where(mask.cpu().bool(), torch.ones_like(gt5) * 128 * (1. / 255), gt5))
     acc = torch.zeros(1, dtype=torch.float64, device=dev)
-    L.check(lib.otvm_loss_ce3(lg.to(dev).data_ptr(), cls.data_ptr(), 5, H * W, acc.data_ptr(), st))
+    L.check(lib.otvm_loss_ce3(lg_d.data_ptr(), cls.data_ptr(), 5, H * W, acc.data_ptr(), st))
     want_ce = float(F.cross_entropy(lg, tri.max(dim=1)[1]))
     assert abs(float(acc[0]) / (5 * H * W) - want_ce) <= 2e-5 * want_ce
     x = torch.rand(4, 3, H, W, generator=g) * 255
     y = torch.empty(4, 3, H, W, device=dev)
-    L.check(lib.otvm_scale_flip3(x.to(dev).data_ptr(), 4, H * W, 1.0 / 255, y.data_ptr(), st))
+    x_d = x.to(dev)
+    L.check(lib.otvm_scale_flip3(x_d.data_ptr(), 4, H * W, 1.0 / 255, y.data_ptr(), st))
     assert torch.equal(y.cpu(), x.flip([1]) * (1.0 / 255))
 
 
