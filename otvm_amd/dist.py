@@ -105,8 +105,26 @@ def reduce_metrics(sums, maxes, device="cpu"):
     return s.tolist(), m.tolist()
 
 
-def run_sharded(sequences, matte_fn, rank=0, world=1, device="cpu", reference_fn=None):
+def batch_groups(indices, keys, lengths, batch):
+    """Group sequence indices into lock-step batches of at most ``batch``: only sequences with the same key (resolution)
+    share a batch; inside a key the longest go together (a batch runs as many steps as its longest clip, a clip that has
+    ended idles along -- video.run_video_matte_batch)."""
+    order = sorted(indices, key=lambda i: (str(keys[i]), -lengths[i], i))
+    groups, cur = [], []
+    for i in order:
+        if cur and (keys[i] != keys[cur[0]] or len(cur) == batch):
+            groups.append(cur)
+            cur = []
+        cur.append(i)
+    if cur:
+        groups.append(cur)
+    return groups
+
+
+def run_sharded(sequences, matte_fn, rank=0, world=1, device="cpu", reference_fn=None, batch=1, matte_batch_fn=None, key_fn=None):
     """Matte ``sequences`` (list of dicts with at least 'frames') sharded over ranks.
+    batch > 1 with matte_batch_fn(list of sequences) -> list of outputs: this rank's sequences are stepped in lock-step groups
+    of up to ``batch`` clips of equal key_fn(seq) (their resolution).
 
     matte_fn(seq) -> dict(alpha=[T,H,W] tensor)       (the HIP path: video.run_video_matte on this rank's GPU)
     reference_fn(seq) -> [T,H,W] tensor or None         (optional ground truth / oracle alpha for SAD, max-abs)
@@ -117,8 +135,15 @@ def run_sharded(sequences, matte_fn, rank=0, world=1, device="cpu", reference_fn
     maxabs = 0.0
     t0 = time.perf_counter()
     outputs = {}
-    for i in mine:
-        out = matte_fn(sequences[i])
+    if batch > 1 and matte_batch_fn is not None:
+        keys = {i: key_fn(sequences[i]) if key_fn is not None else None for i in mine}
+        todo = []
+        for grp in batch_groups(mine, keys, lengths, batch):
+            outs = matte_batch_fn([sequences[i] for i in grp]) if len(grp) > 1 else [matte_fn(sequences[grp[0]])]
+            todo += list(zip(grp, outs))
+    else:
+        todo = ((i, matte_fn(sequences[i])) for i in mine)
+    for i, out in todo:
         outputs[i] = out
         frames += len(sequences[i]["frames"])
         if reference_fn is not None:

@@ -37,6 +37,9 @@ def main(argv=None):
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3"])
     ap.add_argument("--gpus", type=int, default=None, help="start this many ranks, one per GPU (default: the launcher's)")
     ap.add_argument("--sync-io", action="store_true", help="write PNGs synchronously in the frame loop (as eval.py does)")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="sequences of equal resolution stepped in lock-step per GPU (one launch per layer over the batch; "
+                         "frames are decoded up front in this mode)")
     ap.add_argument("--summary-json", default=None, help="rank 0 writes the reduced summary (frames, fps, metrics, shards) here")
     args = ap.parse_args(argv)
     from PIL import Image
@@ -139,8 +142,34 @@ def main(argv=None):
                                os.path.join(args.out, "viz", "test", helpers.get_model_name(cfg), "viz",
                                             seq["name"].replace("/", "_") + ".mp4"))
         return res
+    def matte_batch(group):
+        """--batch: the clips of ``group`` (one resolution) in lock-step; PNGs through one asynchronous writer per clip."""
+        from .video import run_video_matte_batch
+        datas = [datasets.load_sequence(sq["item"], max_frames=args.max_frames, decode_frames=True) for sq in group]
+        writers = []
+        for sq, data in zip(group, datas):
+            outdir = os.path.join(root_out, "pred", sq["name"])
+            os.makedirs(outdir, exist_ok=True)
+            writers.append(AlphaWriter(dev, outdir, [n + ".png" for n in data["names"]]))
+        save = lambda b, i, alpha, u8, out: writers[b].put(i, u8)
+        if group[0]["item"][0] == "demo":
+            res = run_video_matte_batch(model, [d["frames"] for d in datas], trimaps=[d["trimap"] for d in datas], skip=args.skip,
+                                        max_num=args.max_num, on_frame=save, device=dev, keep_on_device=True)
+        else:
+            res = run_video_matte_batch(model, [d["frames"] for d in datas], alphas=[d["alphas"] for d in datas],
+                                        backgrounds=[d["backgrounds"] for d in datas], skip=args.skip, max_num=args.max_num,
+                                        on_frame=save, device=dev, keep_on_device=True,
+                                        gt_alpha_u8=[d["gt_alpha_u8"] for d in datas], gt_mask="unknown")
+        for w in writers:
+            w.close()
+        return res
+
+    def resolution(sq):
+        with Image.open(os.path.join(sq["item"][1], sq["frames"][0])) as im:
+            return (im.height, im.width)
     from .dist import reduce_device
-    summary = run_sharded(seqs, matte, rank=rank, world=world, device=reduce_device(dev) if world > 1 else dev)
+    summary = run_sharded(seqs, matte, rank=rank, world=world, device=reduce_device(dev) if world > 1 else dev,
+                          batch=max(1, args.batch), matte_batch_fn=matte_batch, key_fn=resolution)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

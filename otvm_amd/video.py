@@ -149,31 +149,35 @@ def run_video_matte(model, frames, trimap=None, alphas=None, backgrounds=None, s
 
 
 def run_video_matte_batch(model, clips, trimaps=None, alphas=None, backgrounds=None, skip=10, max_num=5, frames_are_rgb=False,
-                          device=None, keep_on_device=False):
-    """Matte B sequences of one resolution and one length in LOCK-STEP (round 3): frame i of every clip goes through the
-    network in one batched step (EvalModel.forward_batch: one launch per layer over the B images, per-sequence memory
-    banks).  clips: list of B frame arrays ([T,H,W,3] uint8 / float, BGR unless frames_are_rgb); trimaps: list of B
-    first-frame one-hot trimaps [3,H,W] (demo flow) or None with alphas = list of B per-frame GT alpha lists (V108 flow:
-    the first-frame trimap is derived from the alpha); backgrounds: optional list of B per-frame background lists.
-    Sequences of a data set are independent, so batching them changes no result: each returned dict equals
-    run_video_matte of that clip alone (bit for bit under the same kernel configurations).  Returns a list of B dicts
-    (alpha, alpha_u8, trimap, bank_frames)."""
+                          device=None, keep_on_device=False, on_frame=None, gt_alpha_u8=None, gt_mask=None):
+    """Matte B sequences of one resolution in LOCK-STEP (round 3): frame i of every clip goes through the network in one
+    batched step (EvalModel.forward_batch: one launch per layer over the B images, per-sequence memory banks).
+    clips: list of B frame arrays ([T_b,H,W,3] uint8 / float, BGR unless frames_are_rgb); trimaps: list of B first-frame
+    one-hot trimaps [3,H,W] (demo flow) or None with alphas = list of B per-frame GT alpha lists (V108 flow: the first-frame
+    trimap is derived from the alpha); backgrounds: optional list of B per-frame background lists; gt_alpha_u8: optional
+    list of B per-frame uint8 ground truths (SAD / MSE / dtSSD per clip, as run_video_matte); on_frame(b, i, alpha, u8, out).
+    Clips may differ in LENGTH: the batch runs max(T_b) steps, a clip that has ended keeps feeding its last frame (its
+    outputs from then on are discarded) -- sequences are independent (all recurrent state is per sequence), so
+    this changes no result of the others; the frame flags follow the frame index, which the clips share.
+    Each returned dict equals run_video_matte of that clip alone (bit for bit under the same kernel configurations).
+    Returns a list of B dicts (alpha, alpha_u8, trimap, bank_frames[, metrics])."""
     B = len(clips)
-    T = len(clips[0])
-    if any(len(c) != T for c in clips):
-        raise ValueError("run_video_matte_batch: the clips of a batch must have the same number of frames")
+    lens = [len(c) for c in clips]
+    T = max(lens)
     if (trimaps is None) == (alphas is None):
         raise ValueError("run_video_matte_batch: give either trimaps (demo flow) or alphas (VideoMatting108 flow)")
     core = model.module if hasattr(model, "module") else model
     dev = device or next(core.parameters()).device
     res = [dict(alpha=[], alpha_u8=[], trimap=[], bank_frames=[]) for _ in range(B)]
+    metrics = [ClipMetrics(dev) for _ in range(B)] if gt_alpha_u8 is not None else None
     tri_dev = None if trimaps is None else [_as_tensor(t).to(dev).float()[None, None] for t in trimaps]
     ones = None
     for i in range(T):
         A, FG, BG = [], [], []
         for b in range(B):
-            f = _as_tensor(clips[b][i])
-            bk = _as_tensor(backgrounds[b][i]) if backgrounds is not None else None
+            j = min(i, lens[b] - 1)                               # a clip that has ended repeats its last frame (discarded)
+            f = _as_tensor(clips[b][j])
+            bk = _as_tensor(backgrounds[b][j]) if backgrounds is not None else None
             if f.dtype == torch.uint8 and (bk is None or bk.dtype == torch.uint8):
                 fg = f.to(dev, non_blocking=True)
                 bg = fg if bk is None else bk.to(dev, non_blocking=True)
@@ -198,7 +202,7 @@ def run_video_matte_batch(model, clips, trimaps=None, alphas=None, backgrounds=N
                     ones = torch.ones(1, 1, 1, H, W, device=dev)
                 a = ones
             else:
-                a = _as_tensor(alphas[b][i]).to(dev).float()[None, None, None]
+                a = _as_tensor(alphas[b][j]).to(dev).float()[None, None, None]
             A.append(a), FG.append(fg), BG.append(bg)
         memorize, max_memory_num, large = memory_schedule(i, H, W, skip, max_num)
         outs = core.forward_batch(A, FG, BG, tri_dev if tri_dev is not None else [None] * B, first_frame=(i == 0),
@@ -207,13 +211,25 @@ def run_video_matte_batch(model, clips, trimaps=None, alphas=None, backgrounds=N
         u8s = core._engine.last_alpha_u8_b
         bank = list(core.memories["frames"])
         for b in range(B):
+            if i >= lens[b]:
+                continue
             al, u8, tr = outs[b][3][0, 0, 0], u8s[b], outs[b][1][0, 0]
+            if metrics is not None:
+                metrics[b].add(u8, _as_tensor(gt_alpha_u8[b][i]).to(dev), gt_mask)
+            if on_frame is not None:
+                on_frame(b, i, al, u8, outs[b])
             if not keep_on_device:
                 al, u8, tr = al.cpu(), u8.cpu(), tr.cpu()
             res[b]["alpha"].append(al), res[b]["alpha_u8"].append(u8), res[b]["trimap"].append(tr)
             res[b]["bank_frames"].append(bank)
-    return [dict(alpha=torch.stack(r["alpha"]), alpha_u8=torch.stack(r["alpha_u8"]), trimap=torch.stack(r["trimap"]),
-                 bank_frames=r["bank_frames"]) for r in res]
+    out = []
+    for b, r in enumerate(res):
+        d = dict(alpha=torch.stack(r["alpha"]), alpha_u8=torch.stack(r["alpha_u8"]), trimap=torch.stack(r["trimap"]),
+                 bank_frames=r["bank_frames"])
+        if metrics is not None:
+            d["metrics"] = metrics[b].result()
+        out.append(d)
+    return out
 
 
 class ClipMetrics:

@@ -504,6 +504,47 @@ def test_batched_sequences_equal_single_runs(synth_sd, monkeypatch):
         assert torch.equal(batched[b]["alpha_u8"], single[b]["alpha_u8"])
 
 
+def test_batched_ragged_lengths_and_eval_cli_batch(tmp_path, synth_sd, monkeypatch):
+    """Clips of different lengths share a lock-step batch (the shorter one idles on its last frame, its extra outputs are
+    discarded): every clip's alphas equal its single run.  And `eval_cli --batch 2` over a small V108-layout tree writes the
+    PNGs and reports the metrics of the unbatched command."""
+    import json
+    import os
+    from PIL import Image
+    from otvm_amd import engine, eval_cli, helpers
+    from otvm_amd.synth_data import synthetic_clip
+    from otvm_amd.video import run_video_matte, run_video_matte_batch
+    from tests.test_gpu_multirank import _v108_tree
+    monkeypatch.setattr(engine, "AUTOTUNE", False)
+    cfg = helpers.default_cfg()
+    m = helpers.get_model_alpha(cfg, helpers.get_model_trimap(cfg, "Test", 12), "Test", 12)
+    m.load_state_dict(synth_sd, strict=True)
+    m = m.cuda().eval()
+    H, W = 64, 96
+    (c0, t0), (c1, t1) = synthetic_clip(H, W, 7, seed=601), synthetic_clip(H, W, 4, seed=602)
+    single = [run_video_matte(m, c0, trimap=t0, skip=3, max_num=3), run_video_matte(m, c1, trimap=t1, skip=3, max_num=3)]
+    batched = run_video_matte_batch(m, [c0, c1], trimaps=[t0, t1], skip=3, max_num=3)
+    assert batched[0]["alpha"].shape[0] == 7 and batched[1]["alpha"].shape[0] == 4
+    for b in range(2):
+        assert torch.equal(batched[b]["alpha"], single[b]["alpha"]) and torch.equal(batched[b]["alpha_u8"], single[b]["alpha_u8"])
+    root = os.path.join(str(tmp_path), "data")
+    os.makedirs(root)
+    names = _v108_tree(root, [4, 2, 3])
+    out1, out2 = os.path.join(str(tmp_path), "o1"), os.path.join(str(tmp_path), "o2")
+    j1, j2 = os.path.join(str(tmp_path), "s1.json"), os.path.join(str(tmp_path), "s2.json")
+    common = ["--data", root, "--synthetic-weights", "--skip", "3", "--trimap", "narrow"]
+    eval_cli.main(common + ["--out", out1, "--summary-json", j1])
+    eval_cli.main(common + ["--out", out2, "--summary-json", j2, "--batch", "2"])
+    s1, s2 = json.load(open(j1)), json.load(open(j2))
+    assert s1["frames"] == s2["frames"] == 9
+    for clip, T in zip(names, [4, 2, 3]):
+        for t in range(T):
+            rel = os.path.join("alpha", "test", "s4_OTVM", "pred", clip, "%05d.png" % t)
+            assert np.array_equal(np.asarray(Image.open(os.path.join(out1, rel))), np.asarray(Image.open(os.path.join(out2, rel)))), rel
+    for k in ("sad", "mse", "mse_mean", "dtssd_mean"):
+        assert abs(s1["gt_metrics"][k] - s2["gt_metrics"][k]) <= 1e-12 * max(1.0, abs(s1["gt_metrics"][k])), k
+
+
 def test_batched_sequences_vs_oracle_with_autotune(synth_sd):
     """The batched step under its own tuned configurations (the default) against the CPU oracle: alpha <= 1e-3 per clip."""
     from oracle.otvm_oracle import OtvmOracle

@@ -393,3 +393,25 @@ def test_rank_affinity_and_graph_policy(monkeypatch):
     assert D.dist_backend() == "nccl" and D.reduce_device("cuda:3") == "cuda:3"
     monkeypatch.setenv("OTVM_DIST_BACKEND", "gloo")
     assert D.dist_backend() == "gloo" and D.reduce_device("cuda:3") == "cpu"
+
+
+def test_batch_groups_and_sharded_runner_with_batches():
+    """Lock-step batches (round 3): only sequences of one resolution share a batch, the longest first; run_sharded hands
+    groups to matte_batch_fn and single leftovers to matte_fn, and the reduced frame count is unchanged."""
+    from otvm_amd.dist import batch_groups, run_sharded
+    keys = {0: (480, 832), 1: (480, 832), 2: (1080, 1920), 3: (480, 832), 4: (1080, 1920)}
+    assert sorted(batch_groups([0, 1, 2, 3, 4], keys, [5, 9, 3, 7, 8], 2)) == sorted([[1, 3], [0], [4, 2]])
+    assert batch_groups([0, 1, 3], keys, [5, 9, 3, 7, 8], 4) == [[1, 3, 0]]
+    seqs = [dict(frames=list(range(n)), res=keys[i]) for i, n in enumerate([5, 9, 3, 7, 8])]
+    calls = []
+
+    def single(sq):
+        calls.append(("single", len(sq["frames"])))
+        return dict(alpha=torch.zeros(len(sq["frames"]), 1, 1))
+
+    def batched(group):
+        calls.append(("batch", [len(sq["frames"]) for sq in group]))
+        return [dict(alpha=torch.zeros(len(sq["frames"]), 1, 1)) for sq in group]
+    s = run_sharded(seqs, single, batch=2, matte_batch_fn=batched, key_fn=lambda sq: sq["res"])
+    assert s["frames"] == 32 and sorted(s["outputs"]) == [0, 1, 2, 3, 4]
+    assert sorted(calls, key=str) == sorted([("batch", [9, 7]), ("single", 5), ("batch", [8, 3])], key=str)
