@@ -66,7 +66,12 @@ _TUNE_FILE_LOADED = False
 def _tune_file_tag():
     """What a tune file is valid for: the chip and the library ABI (choices timed on another chip, or for another set of
     kernels, must not be applied silently)."""
-    name = torch.cuda.get_device_name(torch.cuda.current_device()) if torch.cuda.is_available() else "none"
+    # (not the marketing name: it comes from an ids file that is missing on some boxes and was seen to differ between two
+    # processes of one box -- the ISA name and the CU count identify the chip)
+    name = "none"
+    if torch.cuda.is_available():
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        name = "%s/%dcu" % (getattr(pr, "gcnArchName", "?").split(":")[0], pr.multi_processor_count)
     return {"device": name, "abi": L.ABI_VERSION}
 
 
@@ -77,7 +82,8 @@ def _load_tune_file():
     import json
     import warnings
     try:
-        doc = json.load(open(TUNE_FILE))
+        with open(TUNE_FILE) as f:
+            doc = json.load(f)
         if not isinstance(doc, dict) or "choices" not in doc:
             raise ValueError("no 'choices' table (file written by an older build)")
         tag = _tune_file_tag()
