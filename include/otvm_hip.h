@@ -35,7 +35,7 @@ extern "C" {
 #define OTVM_PREC_F16X3 1
 
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 12   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
+#define OTVM_ABI_VERSION 13   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
                                  4: otvm_conv_params.splitk_ws; 5: otvm_preprocess_params.fg_u8/bg_u8/u8_rgb;
                                  6: otvm_conv_params.tune + otvm_conv2d_candidates;
                                  7: folded GroupNorm tables on otvm_gn_apply's residual and otvm_upsample_bilinear's input;
@@ -43,7 +43,8 @@ const char* otvm_last_error(void);
                                  10: otvm_finite_guard, otvm_clear;
                                  11: batch of images per launch (otvm_conv_params.batch ..., otvm_gn_*_b, otvm_upsample_bilinear_b,
                                      otvm_maxpool3x3s2_b);
-                                 12: training forward (otvm_fba_head_train, otvm_upsample4_logits3, otvm_trimap_to_sm, otvm_loss_*) */
+                                 12: training forward (otvm_fba_head_train, otvm_upsample4_logits3, otvm_trimap_to_sm, otvm_loss_*);
+                                 13: otvm_conv_params.w_wfrag + otvm_pack_wave_weight_f16x3 (one-wave 64x64 tile) */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -118,6 +119,9 @@ typedef struct {
     int64_t in_bs, out_bs, res_bs;                  /* floats between consecutive images of in / out / residual        */
     int gn_bs;                                      /* doubles between the images' [32][2] statistics blocks (gn_stats) */
     int norm_bs;                                    /* floats between the images' in_scale / in_shift tables            */
+    const void* w_wfrag;                            /* f16x3, optional (ABI 13): the split weights in MFMA B-fragment order for
+                                                       the one-wave 64x64 tile (otvm_pack_wave_weight_f16x3); layers with
+                                                       Cin % 32 == 0; NULL = that tile is never a candidate               */
 } otvm_conv_params;
 int otvm_conv2d(const otvm_conv_params* p, void* stream);
 /* The legal kernel configurations of a layer (f16x3): the patch kernel where the shape allows it, and the implicit-GEMM
@@ -136,6 +140,13 @@ int otvm_conv2d_accepts_input_norm(const otvm_conv_params* p);
  * that the taps of one channel block are consecutive K chunks (input re-reads hit L1/L2).        */
 int otvm_split_conv_weight_f16x3(const float* w_packed, int O, int O_pad, int K_pad, int taps, int I_pad,
                                  void* w_hi, void* w_lo, float* w_scale, void* stream);
+
+/* f16x3, layers with I_pad % 32 == 0 (K in whole 32-channel chunks): the split weights w_hi / w_lo [O_pad][K_pad] (from
+ * otvm_split_conv_weight_f16x3, K already in the kernel's chunk order) re-packed as MFMA B fragments
+ * [O_pad/32][K_pad/32][2 k-steps][hi|lo][64 lanes][8 halfs] (1-KiB blocks, one coalesced load each) for the one-wave
+ * 64x64 tile -- the small-map configuration whose operands bypass LDS; goes into otvm_conv_params.w_wfrag.           */
+int64_t otvm_wave_weight_bytes_f16x3(int O_pad, int K_pad);
+int otvm_pack_wave_weight_f16x3(const void* w_hi, const void* w_lo, int O_pad, int K_pad, void* w_wfrag, void* stream);
 
 /* ---------------------------------------------------------------- GroupNorm(32) ----------------
  * nn.GroupNorm(32, C, eps=1e-5, affine) (layers_WS.py:26-27, FBA/models.py:272-276), two passes:

@@ -31,6 +31,22 @@
 #ifndef OTVM_PFS_LARGE
 #define OTVM_PFS_LARGE 1
 #endif
+// timing probes for tools/build_variant.sh (the results are WRONG with any of them set): which part of the K loop costs what
+#ifndef OTVM_ABL_NOMFMA
+#define OTVM_ABL_NOMFMA 0      // skip the MFMAs
+#endif
+#ifndef OTVM_ABL_NOLOAD
+#define OTVM_ABL_NOLOAD 0      // no global loads after the first chunk (its registers are re-staged)
+#endif
+#ifndef OTVM_ABL_NOLDSRD
+#define OTVM_ABL_NOLDSRD 0     // fragments are read from LDS only for the first k-step
+#endif
+#ifndef OTVM_ABL_NOSTAGE
+#define OTVM_ABL_NOSTAGE 0     // no split + LDS writes after the first chunk
+#endif
+#ifndef OTVM_PF_DB
+#define OTVM_PF_DB 2           // register sets of the pipelined small tiles
+#endif
 #ifndef OTVM_BRANCHY_LOADS
 #define OTVM_BRANCHY_LOADS 1
 #endif
@@ -56,6 +72,8 @@ struct Conv3Args {
     // batch: image blockIdx.z of every tensor lives *_bs elements behind image 0 (split-K: each image owns gridDim.y
     // partial tiles of the workspace, out_bs = gridDim.y * split_stride)
     int64_t in_bs, out_bs, res_bs; int gn_bs;
+    // wave kernel (conv_wave_f16x3_kernel): the split weights in MFMA B-fragment order, see otvm_pack_wave_weight_f16x3
+    const _Float16* wf;
 };
 
 constexpr int BK = 32;
@@ -77,7 +95,7 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
 
 // FAST: Cin % 32 == 0 and <= 32 taps -> a K chunk never straddles a tap, so the tap walk is wave-uniform
 // (scalar registers) and the per-row work per chunk shrinks to one add and one mask test.
-template <int BM, int BN, int WM, int WN, bool FAST, bool RELU_IN>
+template <int BM, int BN, int WM, int WN, bool FAST, bool RELU_IN, bool DB = false>
 __global__ __launch_bounds__(WM* WN * 64)
 __attribute__((amdgpu_waves_per_eu((BM * BN == 32768 && WM * WN == 4) ? 2 : 1, (BM * BN == 32768 && WM * WN == 4) ? 2 : 10)))
 void conv_igemm_f16x3_kernel(const Conv3Args pa) {
@@ -97,7 +115,13 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
     constexpr int STAGE = 2 * (BM + BN) * LDH;                 // halfs per LDS stage (A_hi, A_lo, B_hi, B_lo)
     // Two LDS stages + one barrier per chunk on the 256-row tiles (+5..14 % on the layers that use them; the smaller
     // tiles lose more from the halved occupancy than they gain: 32.7 vs 33.1 frames/s with DBUF everywhere).
-    constexpr bool DBUF = BM == 256 && BN >= 128 && WM * WN == 8;   // (the 4-wave 256x128 / 128x256 tiles: one stage, two workgroups per CU)
+    // Round 3: DB = the same pipelined loop on a small tile, as a separate autotuner candidate ("64x64 D", ...).  Ablation of
+    // the single-stage 64x64 tile (1024->256 1x1 at 68x120, profiles/r03_small_tile_ablation.txt): 31 us in all; MFMAs +
+    // barriers alone 13, the global loads add 8 (16 KB per chunk and workgroup through a 64 B/clk L1), split + LDS writes 7,
+    // fragment reads 1 -- the parts ADD because a workgroup's phases are serialised by its two barriers per chunk and the
+    // two workgroups of a CU run in step.  Converting chunk c+1 between the two k-steps of chunk c lets one wave's VALU /
+    // LDS work issue under its own MFMAs.
+    constexpr bool DBUF = DB || (BM == 256 && BN >= 128 && WM * WN == 8);   // (the 4-wave 256x128 / 128x256 tiles: one stage, two workgroups per CU)
     __shared__ __attribute__((aligned(16))) _Float16 smem[(DBUF ? 2 : 1) * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -169,7 +193,7 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
     constexpr int SETREGS = 4 * A_LD + 8 * B_LD;
     constexpr int PFS = (BM * BN == 32768 && WM * WN == 4) ? 1 :                  // 4-wave 256x128 / 128x256: 128 VGPRs, no room
                         (SETREGS <= 16 ? OTVM_PFS_SMALL : SETREGS <= 24 ? OTVM_PFS_MID : SETREGS <= 32 ? OTVM_PFS_LARGE : 1);
-    constexpr int PF = DBUF ? (BN == 128 ? OTVM_PF_DEPTH : 1) : PFS;
+    constexpr int PF = DB ? OTVM_PF_DB : (DBUF ? (BN == 128 ? OTVM_PF_DEPTH : 1) : PFS);
     constexpr bool BRANCHY = OTVM_BRANCHY_LOADS && (DBUF || PFS == 1);
     struct RegSet {
         f32x4 ra[A_LD];
@@ -274,18 +298,36 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
         const _Float16* Bl = Bh + BN * LDH;
         const int frow = lane & 31, fk = (lane >> 5) * 8;
         f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#if OTVM_ABL_NOLDSRD
+        static_assert(true, "");
+        {
+            const f16x8 one = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+#pragma unroll
+            for (int a = 0; a < TM; ++a) { ah[a] = one * (_Float16)(float)(lane + ks); al[a] = one; }
+#pragma unroll
+            for (int b = 0; b < TN; ++b) { bh[b] = one; bl[b] = one * (_Float16)(float)lane; }
+        }
+        if (buf < 0)
+#endif
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             const int o = ((wm * TM + a) * 32 + frow) * LDH + 16 * ks + fk;
             ah[a] = *reinterpret_cast<const f16x8*>(&Ah[o]);
             al[a] = *reinterpret_cast<const f16x8*>(&Al[o]);
         }
+#if OTVM_ABL_NOLDSRD
+        if (buf < 0)
+#endif
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int o = ((wn * TN + b) * 32 + frow) * LDH + 16 * ks + fk;
             bh[b] = *reinterpret_cast<const f16x8*>(&Bh[o]);
             bl[b] = *reinterpret_cast<const f16x8*>(&Bl[o]);
         }
+#if OTVM_ABL_NOMFMA
+        if (ah[0][0] == (_Float16)12345.f) acc[0][0][0] += (float)bh[0][0];      // keep the fragment reads alive
+        return;
+#endif
         // three passes over the accumulator tiles, so consecutive MFMAs never share an accumulator
 #pragma unroll
         for (int a = 0; a < TM; ++a)
@@ -336,9 +378,9 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
     } else if (PF == 1) {
         for (int c = c_begin; c < c_end; ++c) {
             __syncthreads();
-            store_chunk(0, rs[0]);
+            if (!OTVM_ABL_NOSTAGE || c == c_begin) store_chunk(0, rs[0]);
             __syncthreads();
-            if (c + 1 < c_end) load_chunk(c + 1, rs[0]);
+            if (c + 1 < c_end && !OTVM_ABL_NOLOAD) load_chunk(c + 1, rs[0]);
             compute_ks(0, 0);
             compute_ks(0, 1);
         }
@@ -479,6 +521,289 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: the "wave tile" -- a 64x64 output tile computed by ONE wavefront, no LDS and no barrier in the K loop.
+//
+// Why: on the small maps (OS8 / OS16 layers, everything at 480p) the 4-wave 64x64 / 128x64 tiles above are LDS-bound, not
+// MFMA-bound: with one 32x32 accumulator per wave every MFMA triple needs a fresh A and a fresh B fragment pair from LDS
+// (4 KB per 96 MFMA cycles and wave, 170 B/clk for the four waves of a CU against the 128 B/clk LDS delivers), plus two
+// barriers per 32-deep chunk: MFMA busy 12-15 % (profiles/r03_mfma_busy_*).  Register reuse needs a 2x2 block of
+// accumulators per wave; with four such waves a workgroup covers 128x128 and an 8160-pixel map has too few workgroups.
+// So the workgroup IS one wave here: it owns a 64x64 tile (2x2 accumulators, 12 MFMAs per 16-deep k-step against 4 + 4
+// fragment loads), and both operands go from global memory / L2 straight into MFMA operand registers:
+//   A: lane l needs pixel row (l & 31) and 8 consecutive channels 8 (l >> 5) .. of the k-step -- 32 contiguous bytes of the
+//      NHWC tensor per lane (two float4 loads), split into fp16 hi / lo in registers; the two k-steps of a 32-channel chunk
+//      consume one 128-byte line per row, so every fetched byte is used;
+//   B: the split weights packed ONCE in fragment order (otvm_pack_wave_weight_f16x3:
+//      [n/32][chunk][k-step][hi|lo][64 lanes][8 halfs] = 1-KiB blocks), one fully coalesced load per fragment.
+// No staging, no conversion in LDS, no __syncthreads; latency is covered by a ring of register sets (PF chunks of loads in
+// flight; branch-free so that the compiler waits with exact vmcnt counts, see above).  K order, tap walk, split-K and the
+// epilogue (LDS patch for 16-byte stores, residual, activation, fused GroupNorm sums) as in the kernel above.
+#ifndef OTVM_WAVE_PF
+#define OTVM_WAVE_PF 3
+#endif
+
+template <bool RELU_IN>
+__global__ __launch_bounds__(64) void conv_wave_f16x3_kernel(const Conv3Args pa) {
+    Conv3Args p = pa;
+    {
+        const int zb = blockIdx.z;
+        p.in += zb * p.in_bs;
+        p.out += zb * p.out_bs;
+        if (p.residual) p.residual += zb * p.res_bs;
+        if (p.gn_stats) p.gn_stats += zb * p.gn_bs;
+    }
+    constexpr int BM = 64, BN = 64, TM = 2, TN = 2, PF = OTVM_WAVE_PF;
+    __shared__ __attribute__((aligned(16))) float patch[32 * 36];
+    __shared__ double gred[2 * BN];
+    const int lane = threadIdx.x;
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    const int wgid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int tile_n = wgid % p.tiles_n, tile_m = wgid / p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int frow = lane & 31, fk = (lane >> 5) * 8;
+
+    int rowoff[TM];
+    unsigned tapmask[TM];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+        const int m = m0 + a * 32 + frow;
+        int iy0 = -(1 << 28), ix0 = -(1 << 28);
+        if (m < p.M) {
+            const int oy = m / p.Wo, ox = m - oy * p.Wo;
+            iy0 = oy * p.stride - p.pad;
+            ix0 = ox * p.stride - p.pad;
+        }
+        rowoff[a] = (iy0 * p.W + ix0) * p.in_ld + fk;
+        unsigned mk = 0;
+        for (int t = 0; t < p.taps; ++t) {
+            const int ky = t / p.kw, kx = t - ky * p.kw;
+            const int iy = iy0 + ky * p.dil, ix = ix0 + kx * p.dil;
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) mk |= 1u << t;
+        }
+        tapmask[a] = mk;
+    }
+    const int c_begin = (int)(((int64_t)blockIdx.y * p.nchunks) / gridDim.y);
+    const int c_end = (int)(((int64_t)(blockIdx.y + 1) * p.nchunks) / gridDim.y);
+    float* const outp = p.out + (int64_t)blockIdx.y * p.split_stride;
+    int u_cb = c_begin / p.taps, u_tap = c_begin - u_cb * p.taps;
+    int u_ky = u_tap / p.kw, u_kx = u_tap - u_ky * p.kw;
+    // fragment blocks of this tile's two 32-column n-tiles: [n-tile][chunk][k-step][hi|lo][lane][8]
+    const _Float16* const wfl = p.wf + (int64_t)(n0 >> 5) * p.nchunks * 2048 + lane * 8;
+    const int64_t wnt = (int64_t)p.nchunks * 2048;            // halfs between consecutive n-tiles
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    struct RegSet {
+        f32x4 ra[TM][2][2];          // [m-tile][k-step][first / second quad of the lane's 8 channels]
+        f16x8 rb[TN][2][2];          // [n-tile][k-step][hi|lo]
+        unsigned okmask;
+    };
+    RegSet rs[PF];
+    auto load_chunk = [&](int c, RegSet& R, const bool valid) __attribute__((always_inline)) {
+        const int delta = (u_ky * p.dil * p.W + u_kx * p.dil) * p.in_ld + (u_cb << 5);   // scalar
+        const unsigned bit = 1u << u_tap;
+        unsigned okm = 0;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const bool ok = valid && (tapmask[a] & bit) != 0;
+            const float* src = p.in + (int64_t)(ok ? rowoff[a] + delta : 0);
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                R.ra[a][ks][0] = *reinterpret_cast<const f32x4*>(src + ks * 16);
+                R.ra[a][ks][1] = *reinterpret_cast<const f32x4*>(src + ks * 16 + 4);
+            }
+            okm |= ok ? (1u << a) : 0u;
+        }
+        R.okmask = okm;
+        ++u_tap;
+        if (++u_kx == p.kw) { u_kx = 0; ++u_ky; }
+        if (u_tap == p.taps) { u_tap = 0; u_kx = 0; u_ky = 0; ++u_cb; }
+        const int cw = valid ? c : c_end - 1;
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int hl = 0; hl < 2; ++hl)
+                    R.rb[b][ks][hl] = *reinterpret_cast<const f16x8*>(wfl + b * wnt + ((int64_t)(cw * 2 + ks) * 2 + hl) * 512);
+    };
+    auto compute = [&](RegSet& R) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            f16x8 ah[TM], al[TM];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                f32x4 v0 = R.ra[a][ks][0], v1 = R.ra[a][ks][1];
+                if (RELU_IN) {
+                    v0.x = fmaxf(v0.x, 0.f); v0.y = fmaxf(v0.y, 0.f); v0.z = fmaxf(v0.z, 0.f); v0.w = fmaxf(v0.w, 0.f);
+                    v1.x = fmaxf(v1.x, 0.f); v1.y = fmaxf(v1.y, 0.f); v1.z = fmaxf(v1.z, 0.f); v1.w = fmaxf(v1.w, 0.f);
+                }
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const bool ok = (R.okmask >> a) & 1u;
+                v0 = ok ? v0 : z;
+                v1 = ok ? v1 : z;
+                f16x4 h0, l0, h1, l1;
+                split4(v0, h0, l0);
+                split4(v1, h1, l1);
+                ah[a] = f16x8{h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+                al[a] = f16x8{l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w};
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], R.rb[b][ks][0], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], R.rb[b][ks][1], acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], R.rb[b][ks][0], acc[a][b], 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < PF; ++j) load_chunk(c_begin + j, rs[j], c_begin + j < c_end);
+    for (int c = c_begin; c < c_end; c += PF) {
+#pragma unroll
+        for (int j = 0; j < PF; ++j) {
+            if (j > 0 && c + j >= c_end) break;
+            RegSet cur = rs[j];                                // (registers: the set is reloaded below, its values used after)
+            load_chunk(c + j + PF, rs[j], c + j + PF < c_end);
+            compute(cur);
+        }
+    }
+
+    // ---- epilogue (as conv_igemm_f16x3_kernel with one wave: wm = wn = 0)
+    const int col = lane & 31, rbase = (lane >> 5) * 4;
+    {
+        const int prow = lane >> 3, pc = (lane & 7) * 4;
+        const bool vec_ok = ((p.out_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(outp) & 15) == 0) &&
+                            (!p.residual || (((p.res_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0)));
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int nb = n0 + b * 32;
+            if (nb >= p.Cout) continue;
+            const int n4 = nb + pc;
+            f32x4 sc4 = {0.f, 0.f, 0.f, 0.f}, bi4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (n4 + j < p.Cout) {
+                    sc4[j] = p.wscale[n4 + j];
+                    bi4[j] = p.bias ? p.bias[n4 + j] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int mb = m0 + a * 32;
+                f32x4 rres[4];
+                const bool res_vec = p.residual && vec_ok && n4 + 3 < p.Cout;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int m = mb + r4 * 8 + prow;
+                    rres[r4] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (res_vec && m < p.M) rres[r4] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)m * p.res_ld + n4);
+                }
+                __syncthreads();                               // (one wave: orders the LDS patch between its two uses)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
+                __syncthreads();
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int row = r4 * 8 + prow;
+                    const int m = mb + row;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&patch[row * 36 + pc]);
+                    v = v * sc4 + bi4;
+                    if (m < p.M) {
+                        if (vec_ok && n4 + 3 < p.Cout) {
+                            v += rres[r4];
+                            v.x = otvm_act(v.x, p.act); v.y = otvm_act(v.y, p.act);
+                            v.z = otvm_act(v.z, p.act); v.w = otvm_act(v.w, p.act);
+                            *reinterpret_cast<f32x4*>(outp + (int64_t)m * p.out_ld + n4) = v;
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                if (n4 + j < p.Cout) {
+                                    float x = v[j];
+                                    if (p.residual) x += p.residual[(int64_t)m * p.res_ld + n4 + j];
+                                    outp[(int64_t)m * p.out_ld + n4 + j] = otvm_act(x, p.act);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (p.gn_stats) {
+        const int cg = p.Cout >> 5;
+        const int seg = cg < 32 ? cg : 32;
+        for (int i = threadIdx.x; i < 2 * BN; i += blockDim.x) gred[i] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int nl = b * 32 + col;
+            const int n = n0 + nl;
+            float s = 0.f, ss = 0.f;
+            if (n < p.Cout) {
+                const float sc_ = p.wscale[n];
+                const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = m0 + a * 32 + (e & 3) + 8 * (e >> 2) + rbase;
+                        if (m < p.M) {
+                            const float v = acc[a][b][e] * sc_ + bias;
+                            s += v;
+                            ss += v * v;
+                        }
+                    }
+            }
+            s += __shfl_xor(s, 32);
+            ss += __shfl_xor(ss, 32);
+            for (int off = 1; off < seg; off <<= 1) {
+                s += __shfl_xor(s, off);
+                ss += __shfl_xor(ss, off);
+            }
+            if (lane < 32 && (lane & (seg - 1)) == 0 && n < p.Cout) {
+                const int gl = nl / cg;
+                atomicAdd(&gred[2 * gl], (double)s);
+                atomicAdd(&gred[2 * gl + 1], (double)ss);
+            }
+        }
+        __syncthreads();
+        const int ng = (BN + cg - 1) / cg;
+        for (int i = threadIdx.x; i < 2 * ng; i += blockDim.x) {
+            const int g = n0 / cg + (i >> 1);
+            if (g < 32 && gred[i] != 0.0) atomicAdd(&p.gn_stats[2 * g + (i & 1)], gred[i]);
+        }
+    }
+}
+
+// [O_pad][K_pad] split weights (K already in the kernel's chunk order) -> fragment blocks [n/32][chunk][k-step][hi|lo][lane][8]
+__global__ __launch_bounds__(256) void pack_wave_weight_kernel(const _Float16* __restrict__ wh, const _Float16* __restrict__ wl,
+                                                               int K_pad, _Float16* __restrict__ wf) {
+    const int nt = blockIdx.x, nchunks = K_pad >> 5;
+    for (int i = threadIdx.x; i < nchunks * 2 * 2 * 64; i += 256) {
+        const int l = i & 63, hl = (i >> 6) & 1, ks = (i >> 7) & 1, c = i >> 8;
+        const _Float16* src = (hl ? wl : wh) + (int64_t)(nt * 32 + (l & 31)) * K_pad + c * 32 + ks * 16 + 8 * (l >> 5);
+        _Float16* dst = wf + ((((int64_t)nt * nchunks + c) * 2 + ks) * 2 + hl) * 512 + l * 8;
+        *reinterpret_cast<f16x8*>(dst) = *reinterpret_cast<const f16x8*>(src);
+    }
+}
+
 // split-K epilogue: out = act(sum_z part[z] + bias + residual), partials added in a fixed order (deterministic)
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int S, int64_t stride, int64_t M,
                                                             int Cout, int ldp, const float* __restrict__ bias,
@@ -509,7 +834,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 static thread_local int g_batch = 1;
 static inline int a_batch(const Conv3Args&) { return g_batch; }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool DB = false>
 int launch3(Conv3Args& a, hipStream_t s, int ksplit = 1) {
     a.tiles_m = otvm_ceil_div(a.M, BM);
     a.tiles_n = otvm_ceil_div(a.Cout, BN);
@@ -522,11 +847,14 @@ int launch3(Conv3Args& a, hipStream_t s, int ksplit = 1) {
         return 1;
     }
     if (fast) {
-        if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, false>), grid, block, 0, s, a);
+        if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, true, DB>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, false, DB>), grid, block, 0, s, a);
+    } else if (!DB) {
+        if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, true, false>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, false, false>), grid, block, 0, s, a);
     } else {
-        if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, true>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, false>), grid, block, 0, s, a);
+        otvm_set_error("otvm_conv2d(f16x3): the pipelined small tiles take whole-chunk layers only");
+        return 1;
     }
     OTVM_CHECK_LAUNCH("otvm_conv2d(f16x3)");
     return 0;
@@ -577,6 +905,16 @@ extern "C" int otvm_split_conv_weight_f16x3(const float* w_packed, int O, int O_
     return 0;
 }
 
+extern "C" int64_t otvm_wave_weight_bytes_f16x3(int O_pad, int K_pad) { return (int64_t)O_pad * K_pad * 2 * sizeof(_Float16); }
+
+extern "C" int otvm_pack_wave_weight_f16x3(const void* w_hi, const void* w_lo, int O_pad, int K_pad, void* w_wfrag, void* stream) {
+    OTVM_REQUIRE(w_hi && w_lo && w_wfrag && O_pad % 32 == 0 && K_pad % 32 == 0, "otvm_pack_wave_weight_f16x3: bad arguments");
+    hipLaunchKernelGGL(pack_wave_weight_kernel, dim3(O_pad / 32), dim3(256), 0, (hipStream_t)stream, (const _Float16*)w_hi,
+                       (const _Float16*)w_lo, K_pad, (_Float16*)w_wfrag);
+    OTVM_CHECK_LAUNCH("otvm_pack_wave_weight_f16x3");
+    return 0;
+}
+
 int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream);    // conv_patch_f16x3.hip, -1 = not eligible
 
 // (measured and rejected, round 2: an "activation-stationary" kernel for the expanding 1x1 layers of the bottlenecks --
@@ -589,10 +927,26 @@ int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream);    //
 // tile shared by S workgroups (S > 1: partial tiles through the caller's workspace, added in a fixed order by
 // splitk_finish_kernel), or the 3x3 patch kernel.  otvm_conv_params.tune forces one (the host's plan-time autotuner,
 // otvm_amd/engine.py, times the candidates of otvm_conv2d_candidates on the device); 0 = the heuristic below.
-enum { T256x256 = 0, T256x128, T128x128, T128x64, T64x64, T256x64, T256x32, T256x128W4, T128x256W4, T_COUNT, T_STEM = 12, T_PATCH = 14 };
+enum { T256x256 = 0, T256x128, T128x128, T128x64, T64x64, T256x64, T256x32, T256x128W4, T128x256W4, T64x64W1, T64x64D, T128x64D,
+       T_COUNT, T_STEM = 12, T_PATCH = 14 };
+static_assert(T_COUNT <= T_STEM, "tile codes collide with the stem / patch codes");
 static inline int tune_code(int tile, int S) { return (tile + 1) * 16 + S; }
-static const int TILE_BM[T_COUNT] = {256, 256, 128, 128, 64, 256, 256, 256, 128};
-static const int TILE_BN[T_COUNT] = {256, 128, 128, 64, 64, 64, 32, 128, 256};
+static const int TILE_BM[T_COUNT] = {256, 256, 128, 128, 64, 256, 256, 256, 128, 64, 64, 128};
+static const int TILE_BN[T_COUNT] = {256, 128, 128, 64, 64, 64, 32, 128, 256, 64, 64, 64};
+
+static int launch_wave(Conv3Args& a, hipStream_t s, int ksplit) {
+    a.tiles_m = otvm_ceil_div(a.M, 64);
+    a.tiles_n = otvm_ceil_div(a.Cout, 64);
+    const dim3 grid(a.tiles_m * a.tiles_n, ksplit, g_batch), block(64);
+    if ((int64_t)a.H * a.W * a.in_ld >= (1ll << 31) - (1 << 20)) {
+        otvm_set_error("otvm_conv2d(f16x3 wave tile): input view too large for 32-bit offsets");
+        return 1;
+    }
+    if (a.in_relu) hipLaunchKernelGGL((conv_wave_f16x3_kernel<true>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((conv_wave_f16x3_kernel<false>), grid, block, 0, s, a);
+    OTVM_CHECK_LAUNCH("otvm_conv2d(f16x3 wave tile)");
+    return 0;
+}
 
 static int launch_tile(int tile, Conv3Args& a, hipStream_t s, int S) {
     switch (tile) {
@@ -607,6 +961,11 @@ static int launch_tile(int tile, Conv3Args& a, hipStream_t s, int S) {
         // GroupNorm sums) overlaps the other's main loop -- candidates for the short-K, output-heavy 1x1 layers
         case T256x128W4: return launch3<256, 128, 2, 2>(a, s, S);
         case T128x256W4: return launch3<128, 256, 2, 2>(a, s, S);
+        // one-wave workgroups, operands straight from L2 into MFMA registers (small maps)
+        case T64x64W1: return launch_wave(a, s, S);
+        // pipelined small tiles: two LDS stages, one barrier per chunk, the next chunk converted under the MFMAs
+        case T64x64D: return launch3<64, 64, 2, 2, true>(a, s, S);
+        case T128x64D: return launch3<128, 64, 2, 2, true>(a, s, S);
     }
     otvm_set_error("otvm_conv2d(f16x3): unknown tile %d", tile);
     return 1;
@@ -623,6 +982,9 @@ static bool config_ok(const otvm_conv_params* p, int tile, int S) {
     // the 4-wave big tiles hold 128 accumulator registers per lane: only their wave-uniform-tap-walk variants fit two
     // waves per SIMD without spilling
     if ((tile == T256x128W4 || tile == T128x256W4) && !f16x3_fast_layout(p->kh * p->kw, p->Cin)) return false;
+    // the wave tile reads fragment-major weights and walks whole 32-channel blocks: fast layout + w_wfrag only
+    if ((tile == T64x64D || tile == T128x64D) && !f16x3_fast_layout(p->kh * p->kw, p->Cin)) return false;
+    if (tile == T64x64W1 && !(p->w_wfrag && f16x3_fast_layout(p->kh * p->kw, p->Cin) && (p->in_ld & 3) == 0)) return false;
     if (S > 1) {
         const int nchunks = p->K_pad / 32;
         const int ldp = (p->Cout + 3) & ~3;
@@ -667,19 +1029,20 @@ extern "C" int otvm_conv2d_candidates(const otvm_conv_params* p, int* out, int m
     if (p->in_scale) return n;
     const int64_t M = (int64_t)p->Ho * p->Wo;
     const int nchunks = p->K_pad / 32;
-    static const int tiles_wide[] = {T256x256, T256x128, T128x128, T128x64, T64x64, T256x128W4, T128x256W4};
-    static const int tiles_64[] = {T256x64, T128x64, T64x64};
+    static const int tiles_wide[] = {T256x256, T256x128, T128x128, T128x64, T64x64, T256x128W4, T128x256W4, T64x64W1, T64x64D, T128x64D};
+    static const int tiles_64[] = {T256x64, T128x64, T64x64, T64x64W1, T64x64D, T128x64D};
     static const int tiles_32[] = {T256x32, T64x64};
     const int* tl = p->Cout <= 32 ? tiles_32 : (p->Cout <= 64 ? tiles_64 : tiles_wide);
-    const int ntl = p->Cout <= 32 ? 2 : (p->Cout <= 64 ? 3 : 7);
+    const int ntl = p->Cout <= 32 ? 2 : (p->Cout <= 64 ? 6 : 10);
     static const int splits[] = {1, 2, 3, 4, 6, 8};
     for (int i = 0; i < ntl; ++i) {
         const int t = tl[i];
         const int64_t wgs = (int64_t)otvm_ceil_div(M, TILE_BM[t]) * otvm_ceil_div(p->Cout, TILE_BN[t]);
         if (wgs > 16384 && TILE_BM[t] < 256) continue;              // huge maps: only the 256-row tiles are worth timing
+        if (t == T64x64W1 && wgs > 4096) continue;                  // the wave tile is for maps that cannot fill the chip otherwise
         for (int j = 0; j < 6; ++j) {
             const int S = splits[j];
-            if (S > 1 && (wgs * S > 1536 || nchunks < 16)) continue;      // splitting K only helps launches that cannot fill the chip
+            if (S > 1 && (wgs * S > (t == T64x64W1 ? 4096 : 1536) || nchunks < 16)) continue;   // splitting K only helps launches that cannot fill the chip
             if (config_ok(p, t, S)) add(tune_code(t, S));
         }
     }
@@ -710,6 +1073,7 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     a.in_relu = p->in_relu; a.act = p->act;
     a.M = p->Ho * p->Wo; a.taps = p->kh * p->kw; a.nchunks = p->K_pad / 32;
     a.split_stride = 0;
+    a.wf = (const _Float16*)p->w_wfrag;
     g_batch = p->batch > 1 ? p->batch : 1;
     a.in_bs = g_batch > 1 ? p->in_bs : 0; a.out_bs = g_batch > 1 ? p->out_bs : 0; a.res_bs = g_batch > 1 ? p->res_bs : 0;
     a.gn_bs = g_batch > 1 ? p->gn_bs : 0;

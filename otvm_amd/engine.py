@@ -46,6 +46,10 @@ def graphs_wanted(setting, padded_pixels):
         return True
     return padded_pixels < GRAPH_AUTO_PIXELS
 PRE_ON_S2 = os.environ.get("OTVM_PRE_ON_S2", "1") != "0"           # preprocess + statistics clear on the second side stream
+# one-wave 64x64 tile (operands straight from L2 into MFMA registers, no LDS / barriers in the K loop) as an autotuner
+# candidate.  Built and verified in round 3, measured 20-90 % SLOWER than the 4-wave LDS tiles on every small-map shape
+# (scattered 32-byte A loads: 32 cache lines per load instruction through a 64 B/clk L1): off by default, no weight copy.
+WAVE_TILE = os.environ.get("OTVM_WAVE_TILE", "0") != "0"
 FUSE_PPM_HEAD = os.environ.get("OTVM_PPM_HEAD", "1") != "0"       # the four PPM heads in one launch (otvm_ppm_head)
 
 
@@ -159,7 +163,7 @@ class Act:
 
 
 class ConvW:
-    __slots__ = ("w", "K_pad", "O", "I", "I_pad", "kh", "kw", "bias", "w_hi", "w_lo", "w_scale", "w_frag")
+    __slots__ = ("w", "K_pad", "O", "I", "I_pad", "kh", "kw", "bias", "w_hi", "w_lo", "w_scale", "w_frag", "w_wfrag")
 
 
 def pad_amounts(h, w, d):
@@ -213,13 +217,17 @@ def pack_conv_weight(lib, dev, w, ws=False, scale=None, i_pad=None, split=True, 
     L.check(lib.otvm_pack_conv_weight(w.data_ptr(), O, I, kh, kw, 1 if ws else 0,
                                       0 if scale is None else scale.data_ptr(), cw.w.data_ptr(), O_pad,
                                       cw.I_pad, cw.K_pad, stream), "pack_conv_weight")
-    cw.w_hi = cw.w_lo = cw.w_scale = cw.w_frag = None
+    cw.w_hi = cw.w_lo = cw.w_scale = cw.w_frag = cw.w_wfrag = None
     if split:
         cw.w_hi = torch.empty(O_pad * cw.K_pad, dtype=torch.float16, device=dev)
         cw.w_lo = torch.empty(O_pad * cw.K_pad, dtype=torch.float16, device=dev)
         cw.w_scale = torch.empty(O, dtype=torch.float32, device=dev)
         L.check(lib.otvm_split_conv_weight_f16x3(cw.w.data_ptr(), O, O_pad, cw.K_pad, kh * kw, cw.I_pad, cw.w_hi.data_ptr(),
                                                  cw.w_lo.data_ptr(), cw.w_scale.data_ptr(), stream), "split_conv_weight")
+        if cw.I_pad % 32 == 0 and kh * kw <= 32 and WAVE_TILE:     # whole 32-channel chunks: fragment-major copy for the one-wave tile
+            cw.w_wfrag = torch.zeros(int(lib.otvm_wave_weight_bytes_f16x3(O_pad, cw.K_pad)), dtype=torch.uint8, device=dev)
+            L.check(lib.otvm_pack_wave_weight_f16x3(cw.w_hi.data_ptr(), cw.w_lo.data_ptr(), O_pad, cw.K_pad, cw.w_wfrag.data_ptr(),
+                                                    stream), "pack_wave_weight")
         if kh == 7 and kw == 7 and O <= 64 and cw.I_pad <= 64:   # 7x7 stems: fragment-major copy for the stem kernel
             cw.w_frag = torch.zeros(int(lib.otvm_stem_weight_bytes_f16x3(cw.I_pad)), dtype=torch.uint8, device=dev)
             L.check(lib.otvm_pack_stem_weight_f16x3(cw.w.data_ptr(), O, cw.K_pad, cw.I_pad, cw.w_frag.data_ptr(),
@@ -252,7 +260,8 @@ def conv_params(x, cw, out, bias=None, stride=1, pad=0, dil=1, act=NONE, in_relu
                         0 if splitk_ws is None else splitk_ws.data_ptr(),
                         0 if splitk_ws is None else splitk_ws.numel() * splitk_ws.element_size(),
                         x.B, x.bs, out.bs, 0 if residual is None else residual.bs, 0,
-                        0 if in_norm is None or len(in_norm) < 4 else in_norm[3])
+                        0 if in_norm is None or len(in_norm) < 4 else in_norm[3],
+                        0 if cw.w_wfrag is None else cw.w_wfrag.data_ptr())
 
 
 class HipEngine:

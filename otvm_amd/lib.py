@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3 = 0, 1
-ABI_VERSION = 12         # include/otvm_hip.h OTVM_ABI_VERSION
+ABI_VERSION = 13         # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -27,7 +27,8 @@ class ConvParams(C.Structure):
                 ("in_scale", vp), ("in_shift", vp), ("in_act", i32),
                 ("tune", i32),
                 ("splitk_ws", vp), ("splitk_ws_bytes", i64),
-                ("batch", i32), ("in_bs", i64), ("out_bs", i64), ("res_bs", i64), ("gn_bs", i32), ("norm_bs", i32)]
+                ("batch", i32), ("in_bs", i64), ("out_bs", i64), ("res_bs", i64), ("gn_bs", i32), ("norm_bs", i32),
+                ("w_wfrag", vp)]
 
 
 class GnApplyParams(C.Structure):
@@ -59,6 +60,8 @@ _PROTOS = {
     "otvm_patch_weight_bytes_f16x3": (i64, [i32, i32]),
     "otvm_pack_patch_weight_f16x3": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "otvm_stem_weight_bytes_f16x3": (i64, [i32]),
+    "otvm_wave_weight_bytes_f16x3": (i64, [i32, i32]),
+    "otvm_pack_wave_weight_f16x3": (i32, [vp, vp, i32, i32, vp, vp]),
     "otvm_pack_stem_weight_f16x3": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "otvm_fold_bn": (i32, [vp, vp, vp, vp, f32, i32, vp, vp, vp]),
     "otvm_pack_conv_weight": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, vp]),

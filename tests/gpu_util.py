@@ -39,6 +39,8 @@ def from_act(a, Cc=None):
 
 
 def pack_weight(w, ws=False, scale=None, i_pad=None):
+    from otvm_amd import engine
+    engine.WAVE_TILE = True                      # kernel tests cover the one-wave tile too (off by default in the product)
     cw = pack_conv_weight(L.load(), DEV, w.contiguous().to(DEV), ws, None if scale is None else scale.contiguous().to(DEV),
                           i_pad, split=True, stream=stream())
     torch.cuda.synchronize()

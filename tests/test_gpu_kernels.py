@@ -706,6 +706,9 @@ def test_conv_every_tunable_configuration(G, Cin, Cout, k, stride, dil, H, W, us
     codes = (C.c_int * 64)()
     n = int(lib.otvm_conv2d_candidates(C.byref(p), codes, 64))
     assert n >= 3 and len(set(codes[:n])) == n
+    if Cin % 32 == 0 and Cout > 32:
+        assert any(c // 16 - 1 == 9 for c in codes[:n]), "the one-wave 64x64 tile must be a candidate of a whole-chunk layer"
+        assert any(c // 16 - 1 == 10 for c in codes[:n]) and any(c // 16 - 1 == 11 for c in codes[:n]), "pipelined small tiles"
     seen_split = False
     for c in list(codes[:n]) + [0]:
         out.t.fill_(float("nan"))
@@ -723,7 +726,7 @@ def test_conv_every_tunable_configuration(G, Cin, Cout, k, stride, dil, H, W, us
             want = torch.stack([g.sum((1, 2)), (g * g).sum((1, 2))], 1).flatten()
             assert float((stats.cpu() - want).abs().max()) <= 1e-5 * float(want.abs().max()), c
     assert seen_split or Cin * k * k < 512
-    p.tune = (11 + 1) * 16 + 1                                 # no such tile
+    p.tune = (15 + 1) * 16 + 1                                 # no such tile
     assert lib.otvm_conv2d(C.byref(p), G.stream()) != 0
     if Cout < 256:
         p.tune = (0 + 1) * 16 + 1                              # 256x256 needs Cout >= 256
@@ -791,6 +794,10 @@ BATCH_CONV_CASES = [
     (1024, 128, 3, 1, 1, 12, 16, False, 0, False, (3 + 1) * 16 + 4),   # 128x64 tile, K split over 4 workgroups
     (512, 128, 1, 1, 1, 17, 23, False, 0, True, (2 + 1) * 16 + 2),     # 128x128 / S2 + statistics pass behind the reduction
     (40, 128, 3, 2, 1, 33, 47, False, 2, False, 0),          # generic K decode, stride 2
+    (256, 256, 3, 1, 1, 16, 24, True, 1, False, (9 + 1) * 16 + 1),     # one-wave 64x64 tile + residual + ReLU
+    (1024, 128, 1, 1, 1, 12, 16, False, 0, True, (9 + 1) * 16 + 4),    # one-wave tile, K split over 4, statistics pass
+    (256, 256, 3, 1, 1, 16, 24, True, 1, False, (10 + 1) * 16 + 2),    # pipelined 64x64 tile, K split over 2
+    (512, 128, 1, 1, 1, 17, 23, False, 0, True, (11 + 1) * 16 + 1),    # pipelined 128x64 tile + fused statistics
 ]
 
 

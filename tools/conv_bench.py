@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--res", type=int, default=0)
     ap.add_argument("--gn", type=int, default=0, help="fused GroupNorm statistics in the epilogue")
     ap.add_argument("--bias", type=int, default=0)
+    ap.add_argument("--pad-ld", type=int, default=0, help="extra floats per pixel row of the input / output / residual views (ld = C + pad)")
     ap.add_argument("--tune", default="0", help="otvm_conv_params.tune codes to time, comma separated; 'all' = every candidate")
     args = ap.parse_args()
     shapes = [tuple(int(v) for v in s.split(",")) for s in args.shape] if args.shape else DEFAULT
@@ -43,13 +44,14 @@ def main():
     st = torch.cuda.current_stream().cuda_stream
     for (Cin, Cout, k, stride, dil, H, W) in shapes:
         pad = dil * (k - 1) // 2
-        x = Act(torch.randn(H * W * Cin, device=dev), H, W, Cin)
+        pl = args.pad_ld
+        x = Act(torch.randn(H * W * (Cin + pl), device=dev), H, W, Cin, Cin + pl)
         w = torch.randn(Cout, Cin, k, k, device=dev) / math.sqrt(Cin * k * k)
         cw = pack_conv_weight(lib, dev, w, split=True, stream=st)
         Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
         Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
-        out = Act(torch.empty(Ho * Wo * max(4, Cout), device=dev), Ho, Wo, Cout)
-        res = Act(torch.randn(Ho * Wo * Cout, device=dev), Ho, Wo, Cout) if args.res else None
+        out = Act(torch.empty(Ho * Wo * (max(4, Cout) + pl), device=dev), Ho, Wo, Cout, max(4, Cout) + pl)
+        res = Act(torch.randn(Ho * Wo * (Cout + pl), device=dev), Ho, Wo, Cout, Cout + pl) if args.res else None
         bias = torch.randn(Cout, device=dev) if args.bias else None
         p = conv_params(x, cw, out, bias, stride, pad, dil, 0, args.relu, res, args.prec)
         stats = torch.zeros(64, dtype=torch.float64, device=dev)
@@ -63,7 +65,7 @@ def main():
             tunes = [0] + [int(codes[i]) for i in range(n)]
         else:
             tunes = [int(v) for v in args.tune.split(",")]
-        names = {0: "256x256", 1: "256x128", 2: "128x128", 3: "128x64", 4: "64x64", 5: "256x64", 6: "256x32", 7: "256x128w4", 8: "128x256w4", 12: "stem", 14: "patch"}
+        names = {0: "256x256", 1: "256x128", 2: "128x128", 3: "128x64", 4: "64x64", 5: "256x64", 6: "256x32", 7: "256x128w4", 8: "128x256w4", 9: "wave64", 10: "64x64D", 11: "128x64D", 12: "stem", 14: "patch"}
         for tune in tunes:
             p.tune = tune
             for _ in range(3):
