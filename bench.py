@@ -236,6 +236,8 @@ def main():
                    "batch": NB,
                    "T_read_timed_frames": {"mean": sum(timed_T) / float(K), "histogram": hist}},
         "ranks_seen": ranks_seen,
+        # wall time the host spends inside model() per step: issue time when the launch lists are replayed as graphs; with
+        # direct launches the HIP queue fills up and the host blocks in launches, so this approaches ms_per_step
         "host_issue_ms_per_frame": 1000.0 * host_issue_s / K,
         "graphs": bool(__import__("otvm_amd.engine", fromlist=["graphs_wanted"]).graphs_wanted(model._engine.use_graphs, Hp * Wp)),
         "algorithmic_tflop_per_frame": flops_frame / 1e12,

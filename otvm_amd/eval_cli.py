@@ -12,6 +12,10 @@ accumulated on the device and reduced over ranks.  Alpha PNGs are written as tru
 Frame IO runs through otvm_amd/io_pipeline.py: the demo flow decodes ahead in a thread pool and uploads on a copy
 stream, both flows download the 8-bit alphas asynchronously and PNG-encode them in a pool (the reference's loop blocks
 on .cpu() + cv2.imwrite per frame, eval.py:209-217).
+Reproducibility: the first call per resolution times the convolution configurations on the device (a per-process choice
+among kernels that differ in fp32 summation order): two runs agree bit for bit only with fixed configurations -- set
+OTVM_TUNE_FILE=path (choices are written once and re-used; multi-rank runs share rank 0's choices in any case) or
+OTVM_AUTOTUNE=0 (built-in heuristic).  `--batch B` steps B sequences of equal resolution per launch.
 Multi-GPU: `--gpus N` starts N ranks (one process per GPU) itself, or launch with torchrun; sequences are sharded
 one-per-GPU and the metric sums meet in one all-reduce.
 """
