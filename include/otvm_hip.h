@@ -35,7 +35,7 @@ extern "C" {
 #define OTVM_PREC_F16X3 1
 
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 13   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
+#define OTVM_ABI_VERSION 14   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
                                  4: otvm_conv_params.splitk_ws; 5: otvm_preprocess_params.fg_u8/bg_u8/u8_rgb;
                                  6: otvm_conv_params.tune + otvm_conv2d_candidates;
                                  7: folded GroupNorm tables on otvm_gn_apply's residual and otvm_upsample_bilinear's input;
@@ -44,7 +44,8 @@ const char* otvm_last_error(void);
                                  11: batch of images per launch (otvm_conv_params.batch ..., otvm_gn_*_b, otvm_upsample_bilinear_b,
                                      otvm_maxpool3x3s2_b);
                                  12: training forward (otvm_fba_head_train, otvm_upsample4_logits3, otvm_trimap_to_sm, otvm_loss_*);
-                                 13: otvm_conv_params.w_wfrag + otvm_pack_wave_weight_f16x3 (one-wave 64x64 tile) */
+                                 13: otvm_conv_params.w_wfrag + otvm_pack_wave_weight_f16x3 (one-wave 64x64 tile);
+                                 14: otvm_ppm_conv_z / otvm_ppm_conv_add (the PPM branches' share of conv_up1.0 without upsampling) */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -209,6 +210,15 @@ typedef struct otvm_ppm_head_params {
     float* out[4]; int out_ld, act;
 } otvm_ppm_head_params;
 int otvm_ppm_head(const otvm_ppm_head_params* p, void* stream);
+
+/* The PPM branches' share of conv_up1.0 (FBA/models.py:358-365: 3x3 conv over cat[layer4, 4 upsampled PPM maps]) WITHOUT
+ * materialising the upsampled maps: convolution and bilinear interpolation are linear, so
+ *   otvm_ppm_conv_z  : Z[tap][j][o] = sum_c w_ppm[scale(j)][tap][c][o] * y_scale[j][c]  for the 50 pooled pixels j (otvm_ppm_head's
+ *                      outputs y[4], pixel stride y_ld, 256 channels) and the 9 taps; w_ppm fp32 [4][9][256 c][256 o]; Z [9][50][256];
+ *   otvm_ppm_conv_add: out[p][o] += sum_tap [p + tap inside HxW] sum_scale bilinear_up(Z[tap][scale])(p + tap)   (256 channels).
+ * Identical to the reference's conv(cat(...)) restricted to the PPM channels up to fp32 summation order.                 */
+int otvm_ppm_conv_z(const float* const* y, int y_ld, const float* w_ppm, float* Z, void* stream);
+int otvm_ppm_conv_add(const float* Z, int H, int W, float* out, int out_ld, void* stream);
 
 /* ---------------------------------------------------------------- memory read (STM.py:140-163) -
  * mem[q, :] = sum_m softmax_m(K[m,:].Q[q,:] / sqrt(128)) V[m,:], m over T slots x hw positions.

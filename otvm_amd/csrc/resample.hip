@@ -393,3 +393,133 @@ extern "C" int otvm_ppm_head(const otvm_ppm_head_params* q, void* stream) {
     OTVM_CHECK_LAUNCH("otvm_ppm_head");
     return 0;
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: the PPM branches never materialise at 1/8 resolution.
+//
+// FBA/models.py:358-365 upsamples the four pooled-and-projected maps (1x1, 2x2, 3x3, 6x6 pixels x 256 channels) to the
+// layer-4 resolution, concatenates them with layer 4 (2048 + 4 x 256 = 3072 channels) and convolves the result with
+// conv_up1.0 (3x3, 3072 -> 256): a third of that layer's 462 GFLOP at 1080p multiplies weights with bilinear interpolations
+// of 50 pixels.  Convolution and interpolation are both linear, so the contribution of the PPM channels to output pixel p is
+//      sum_tap [p + tap inside the image]  sum_scale  up_scale( Z[tap][scale] )(p + tap),
+//      Z[tap][scale][j][o] = sum_c W[o][2048 + 256 scale + c][tap] * y_scale[j][c]        (j = one of the 50 pooled pixels)
+// -- a 9 x 50 x 256 table of 256-long dot products (59 MFLOP instead of 154 GFLOP) followed by a gather of 9 taps x 4 scales
+// x 4 bilinear neighbours per output value.  The zero padding of the convolution (taps outside the image contribute
+// nothing) and PyTorch's bilinear index / weight arithmetic (align_corners = False) are reproduced exactly; only the order
+// of the fp32 additions differs from the materialised form.  conv_up1.0 then runs on the 2048 layer-4 channels alone.
+constexpr int PPMZ_BINS = 50, PPMZ_TAPS = 9;
+
+// grid (50 pooled pixels, 9 taps), 256 threads = output channels; w: [4 scales][9 taps][256 c][256 o] fp32
+__global__ __launch_bounds__(256) void ppm_z_kernel(const float* __restrict__ y0, const float* __restrict__ y1,
+                                                    const float* __restrict__ y2, const float* __restrict__ y3, int y_ld,
+                                                    const float* __restrict__ w, float* __restrict__ Z) {
+    const int j = blockIdx.x, tap = blockIdx.y, o = threadIdx.x;
+    const int sc = j < 1 ? 0 : (j < 5 ? 1 : (j < 14 ? 2 : 3));
+    const int base = sc == 0 ? 0 : (sc == 1 ? 1 : (sc == 2 ? 5 : 14));
+    const float* y = (sc == 0 ? y0 : (sc == 1 ? y1 : (sc == 2 ? y2 : y3))) + (int64_t)(j - base) * y_ld;
+    __shared__ float ys[256];
+    ys[o] = y[o];
+    __syncthreads();
+    const float* wp = w + ((int64_t)(sc * PPMZ_TAPS + tap) * 256) * 256 + o;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+    for (int c = 0; c < 256; c += 4) {
+        a0 = fmaf(wp[(int64_t)(c + 0) * 256], ys[c + 0], a0);
+        a1 = fmaf(wp[(int64_t)(c + 1) * 256], ys[c + 1], a1);
+        a2 = fmaf(wp[(int64_t)(c + 2) * 256], ys[c + 2], a2);
+        a3 = fmaf(wp[(int64_t)(c + 3) * 256], ys[c + 3], a3);
+    }
+    Z[((int64_t)tap * PPMZ_BINS + j) * 256 + o] = (a0 + a1) + (a2 + a3);
+}
+
+// out[p][o] += contribution(p)[o].  grid (pixel blocks, 4 channel groups of 64); a workgroup keeps its 9 x 50 x 64 slice of Z
+// in LDS (112.5 KB) and walks pixels: one wave per pixel (the bilinear index arithmetic is wave-uniform), lane = channel.
+// 16 waves share the slice (one workgroup per CU fits; with 4 waves -- one per SIMD -- every LDS round trip of the 36 tap x
+// scale steps of a pixel was exposed: 467 us at 136x240, rocprof).
+constexpr int PPMA_WAVES = 16;
+__global__ __launch_bounds__(PPMA_WAVES * 64) void ppm_add_kernel(const float* __restrict__ Z, int H, int W, float* __restrict__ out, int out_ld) {
+    extern __shared__ float zs[];                               // [9][50][64]
+    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < PPMZ_TAPS * PPMZ_BINS * 64; i += PPMA_WAVES * 64) {
+        const int tj = i >> 6, o = i & 63;
+        zs[i] = Z[(int64_t)tj * 256 + g * 64 + o];
+    }
+    __syncthreads();
+    const int P = H * W;
+    // the pixel is the same for all lanes of a wave: tell the compiler (scalar index arithmetic), and compute the row terms of
+    // the three filter rows and the column terms of the three filter columns ONCE per scale instead of once per tap
+    for (int pv = blockIdx.x * PPMA_WAVES + wave; pv < P; pv += gridDim.x * PPMA_WAVES) {
+        const int p = __builtin_amdgcn_readfirstlane(pv);
+        const int y = p / W, x = p - y * W;
+        float acc = 0.f;
+#pragma unroll
+        for (int sc = 0; sc < 4; ++sc) {
+            const int s = sc == 0 ? 1 : (sc == 1 ? 2 : (sc == 2 ? 3 : 6));
+            const int base = sc == 0 ? 0 : (sc == 1 ? 1 : (sc == 2 ? 5 : 14));
+            // F.interpolate(bilinear, align_corners=False), as upsample_bilinear_kernel
+            const float sy = (float)s / (float)H, sx = (float)s / (float)W;
+            int ro0[3], ro1[3], co0[3], co1[3];
+            float rl[3], cl[3];
+            bool rok[3], cok[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int qy = y + k - 1, qx = x + k - 1;
+                rok[k] = (unsigned)qy < (unsigned)H;               // zero padding of the convolution
+                cok[k] = (unsigned)qx < (unsigned)W;
+                float fy = ((float)qy + 0.5f) * sy - 0.5f, fx = ((float)qx + 0.5f) * sx - 0.5f;
+                fy = fy < 0.f ? 0.f : fy;
+                fx = fx < 0.f ? 0.f : fx;
+                const int y0 = (int)fy, x0 = (int)fx;
+                const int y1 = y0 + (y0 < s - 1 ? 1 : 0), x1 = x0 + (x0 < s - 1 ? 1 : 0);
+                rl[k] = fy - (float)y0;
+                cl[k] = fx - (float)x0;
+                ro0[k] = (base + y0 * s) * 64; ro1[k] = (base + y1 * s) * 64;
+                co0[k] = x0 * 64; co1[k] = x1 * 64;
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                if (!rok[ky]) continue;
+                const float ly = rl[ky], hy = 1.f - ly;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    if (!cok[kx]) continue;
+                    const float lx = cl[kx], hx = 1.f - lx;
+                    const float* zt = zs + (ky * 3 + kx) * PPMZ_BINS * 64 + lane;
+                    const float v00 = zt[ro0[ky] + co0[kx]], v01 = zt[ro0[ky] + co1[kx]];
+                    const float v10 = zt[ro1[ky] + co0[kx]], v11 = zt[ro1[ky] + co1[kx]];
+                    acc += hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+                }
+            }
+        }
+        out[(int64_t)p * out_ld + g * 64 + lane] += acc;
+    }
+}
+
+extern "C" int otvm_ppm_conv_z(const float* const* y, int y_ld, const float* w_ppm, float* Z, void* stream) {
+    OTVM_REQUIRE(y && y[0] && y[1] && y[2] && y[3] && w_ppm && Z, "otvm_ppm_conv_z: null pointer");
+    hipLaunchKernelGGL(ppm_z_kernel, dim3(PPMZ_BINS, PPMZ_TAPS), dim3(256), 0, (hipStream_t)stream, y[0], y[1], y[2], y[3], y_ld,
+                       w_ppm, Z);
+    OTVM_CHECK_LAUNCH("otvm_ppm_conv_z");
+    return 0;
+}
+
+extern "C" int otvm_ppm_conv_add(const float* Z, int H, int W, float* out, int out_ld, void* stream) {
+    OTVM_REQUIRE(Z && out && H > 0 && W > 0, "otvm_ppm_conv_add: bad arguments");
+    constexpr int LDS = PPMZ_TAPS * PPMZ_BINS * 64 * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        const hipError_t e = hipFuncSetAttribute((const void*)ppm_add_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) {
+            otvm_set_error("otvm_ppm_conv_add: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
+            return 2;
+        }
+        attr_set = true;
+    }
+    int bx = otvm_ceil_div((int64_t)H * W, PPMA_WAVES * 8);        // >= 8 pixels per wave
+    if (bx > 64) bx = 64;                                         // 64 x 4 channel groups = one workgroup per CU
+    if (bx < 1) bx = 1;
+    hipLaunchKernelGGL(ppm_add_kernel, dim3(bx, 4), dim3(PPMA_WAVES * 64), LDS, (hipStream_t)stream, Z, H, W, out, out_ld);
+    OTVM_CHECK_LAUNCH("otvm_ppm_conv_add");
+    return 0;
+}

@@ -50,7 +50,10 @@ PRE_ON_S2 = os.environ.get("OTVM_PRE_ON_S2", "1") != "0"           # preprocess 
 # candidate.  Built and verified in round 3, measured 20-90 % SLOWER than the 4-wave LDS tiles on every small-map shape
 # (scattered 32-byte A loads: 32 cache lines per load instruction through a 64 B/clk L1): off by default, no weight copy.
 WAVE_TILE = os.environ.get("OTVM_WAVE_TILE", "0") != "0"
-FUSE_PPM_HEAD = os.environ.get("OTVM_PPM_HEAD", "1") != "0"       # the four PPM heads in one launch (otvm_ppm_head)
+FUSE_PPM_HEAD = os.environ.get("OTVM_PPM_HEAD", "1") != "0"
+# round 3: the PPM branches' third of conv_up1.0 computed from the 50 pooled pixels (otvm_ppm_conv_z / _add) instead of
+# convolving their upsampled copies; conv_up1.0 then reads layer 4 only.  OTVM_PPM_ALGEBRA=0 keeps the materialised form.
+PPM_ALGEBRA = os.environ.get("OTVM_PPM_ALGEBRA", "1") != "0"       # the four PPM heads in one launch (otvm_ppm_head)
 
 
 # Plan-time autotuning of the convolution configurations (f16x3): every distinct layer shape is timed once on the device
@@ -368,6 +371,17 @@ class HipEngine:
                           sd[e + "conv1_o.weight"], sd[e + "conv1_a.weight"]], dim=1)
         scale, bias = self._fold_bn(e + "bn1")
         self._pack(e + "stem", wcat, scale=scale, bias=bias, i_pad=24)
+        # conv_up1.0 = 3x3 over cat[layer4 (2048) | 4 PPM maps (4 x 256)] (FBA/models.py:362-365), weight-standardised over
+        # the WHOLE filter: take the standardised weights from the packed copy and split them into the layer-4 part (a
+        # convolution of its own) and the PPM part in the table layout otvm_ppm_conv_z reads ([scale][tap][c][o])
+        up1 = self.W.get("NET.decoder.conv_up1.0")
+        self.W_ppm = None
+        if PPM_ALGEBRA and FUSE_PPM_HEAD and up1 is not None and (up1.O, up1.I, up1.kh, up1.kw) == (256, 3072, 3, 3):
+            O_pad = up1.w.numel() // up1.K_pad
+            wk = up1.w.view(O_pad, up1.K_pad)[:256, :9 * up1.I_pad].reshape(256, 3, 3, up1.I_pad)
+            w_main = wk[..., :2048].permute(0, 3, 1, 2).contiguous()                       # OIHW, standardised already
+            self._pack("NET.decoder.conv_up1.0.main", w_main, ws=False, bias=up1.bias)
+            self.W_ppm = wk[..., 2048:3072].reshape(256, 9, 4, 256).permute(2, 1, 3, 0).contiguous()
         torch.cuda.synchronize(self.dev)
 
     # ------------------------------------------------------------------ range guard (f16x3 operands must stay in fp16 range)
@@ -1147,7 +1161,9 @@ class FramePlan:
         en = "NET.encoder."
         self.U3 = self.buf("U3", H2, W2, 320)            # [up(conv_up2) 256 | c1 64]
         self.U2 = self.buf("U2", H4, W4, 512)            # [up(conv_up1) 256 | l1 256]
-        self.PPMCAT = self.buf("PPMCAT", H8, W8, 3072)   # [l4 2048 | ppm 4x256]
+        # [l4 2048 | ppm 4x256]; with the PPM algebra (round 3) the upsampled PPM maps do not exist: layer 4 alone
+        ppm_alg = FUSE_PPM_HEAD and self.e.W_ppm is not None
+        self.PPMCAT = self.buf("PPMCAT", H8, W8, 2048 if ppm_alg else 3072)
         c1raw = self.buf("c1raw", H2, W2, 64)
         cp = self.conv(S, self.X11, en + "conv1", c1raw, stride=2, pad=3)
         c1 = self.U3.ch(256, 64)
@@ -1192,9 +1208,12 @@ class FramePlan:
                     hp.out[i] = ys[i].img(b).ptr
                 self._keep.append(hp)
                 S.append((lib.otvm_ppm_head, (C.byref(hp),), "ppm_head"))
-            for i, y in enumerate(ys):
-                self.upsample(S, y, self.PPMCAT.ch(2048 + 256 * i, 256))
+            self._ppm_algebra = ppm_alg
+            if not self._ppm_algebra:
+                for i, y in enumerate(ys):
+                    self.upsample(S, y, self.PPMCAT.ch(2048 + 256 * i, 256))
         else:
+            self._ppm_algebra = False
             if self.B > 1:
                 raise NotImplementedError("otvm_amd: batched sequences need the fused PPM head (OTVM_PPM_HEAD=1)")
             base = 0
@@ -1205,8 +1224,20 @@ class FramePlan:
                 self.gn_then_upsample(S, y, de + "ppm.%d.2" % i, LEAKY, cp, self.PPMCAT.ch(2048 + 256 * i, 256))
                 base += s_ * s_
         u1 = self.buf("u1a", H8, W8, 256)
-        cp = self.conv(S, self.PPMCAT, de + "conv_up1.0", u1, pad=1)
-        self.gn(S, u1, de + "conv_up1.1", LEAKY, conv_p=cp)
+        if self._ppm_algebra:
+            # the PPM maps are never upsampled: conv_up1.0 over layer 4 alone, then the PPM channels' share of the same
+            # convolution from the 50 pooled pixels (resample.hip: otvm_ppm_conv_z / _add), then the GroupNorm statistics
+            self.conv(S, self.PPMCAT.ch(0, 2048), de + "conv_up1.0.main", u1, pad=1)
+            self.PPM_Z = self.raws("ppm_z", 9 * 50 * 256)
+            for b in range(self.B):
+                yp = (C.c_void_p * 4)(*[y.img(b).ptr for y in ys])
+                self._keep.append(yp)
+                S.append((lib.otvm_ppm_conv_z, (yp, ys[0].ld, self.e.W_ppm.data_ptr(), self.PPM_Z[b].data_ptr()), "ppm_conv_z"))
+                S.append((lib.otvm_ppm_conv_add, (self.PPM_Z[b].data_ptr(), H8, W8, u1.img(b).ptr, u1.ld), "ppm_conv_add"))
+            self.gn(S, u1, de + "conv_up1.1", LEAKY, conv_p=None)
+        else:
+            cp = self.conv(S, self.PPMCAT, de + "conv_up1.0", u1, pad=1)
+            self.gn(S, u1, de + "conv_up1.1", LEAKY, conv_p=cp)
         u1b = self.buf("u1b", H8, W8, 256)
         cp = self.conv(S, u1, de + "conv_up1.3", u1b, pad=1)
         self.gn_then_upsample(S, u1b, de + "conv_up1.4", LEAKY, cp, self.U2.ch(0, 256))

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3 = 0, 1
-ABI_VERSION = 13         # include/otvm_hip.h OTVM_ABI_VERSION
+ABI_VERSION = 14         # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -77,6 +77,8 @@ _PROTOS = {
     "otvm_ppm_pool_ws_bytes": (i64, [i32, i32]),
     "otvm_ppm_pool": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "otvm_ppm_head": (i32, [C.POINTER(PpmHeadParams), vp]),
+    "otvm_ppm_conv_z": (i32, [C.POINTER(vp), i32, vp, vp, vp]),
+    "otvm_ppm_conv_add": (i32, [vp, i32, i32, vp, i32, vp]),
     "otvm_memory_read_ws_bytes": (i64, [i32, i32]),
     "otvm_memory_read": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp), i32, i32, vp, i32, vp, vp]),
     "otvm_bank_slot_bytes_f16x3": (i64, [i32]),

@@ -910,3 +910,27 @@ def test_groupnorm_and_resampling_batched_equal_single(G):
     sc, sh = tab[2 * 2 * Cc:2 * 2 * Cc + Cc].cpu(), tab[2 * 2 * Cc + Cc:3 * 2 * Cc].cpu()
     res = F.leaky_relu(rs[2] * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), 0.01)
     assert float((got - F.relu(want + res)).abs().max()) <= 2e-5 * max(1.0, float(want.abs().max()))
+
+
+def test_ppm_conv_algebra_matches_conv_over_upsampled_maps(G):
+    """otvm_ppm_conv_z + otvm_ppm_conv_add: the PPM channels' share of conv_up1.0 (FBA/models.py:358-365) computed from the
+    50 pooled pixels == F.conv2d over the four bilinearly upsampled maps (zero padding, align_corners=False), odd map size."""
+    from otvm_amd import lib as L
+    lib, st = L.load(), G.stream()
+    H, W = 17, 29
+    g = torch.Generator().manual_seed(8)
+    ys = [torch.randn(1, 256, s, s, generator=g) for s in (1, 2, 3, 6)]
+    w = torch.randn(256, 1024, 3, 3, generator=g) / math.sqrt(1024 * 9)
+    ups = [F.interpolate(y, size=(H, W), mode="bilinear", align_corners=False) for y in ys]
+    base = torch.randn(1, 256, H, W, generator=g)
+    want = base + F.conv2d(torch.cat(ups, 1), w, None, 1, 1)
+    ya = [G.to_act(y) for y in ys]
+    yp = (C.c_void_p * 4)(*[a.ptr for a in ya])
+    w_ppm = w.reshape(256, 4, 256, 9).permute(1, 3, 2, 0).contiguous().to(G.DEV)      # [scale][tap][c][o]
+    Z = torch.zeros(9 * 50 * 256, device=G.DEV)
+    out = G.to_act(base)
+    L.check(lib.otvm_ppm_conv_z(yp, ya[0].ld, w_ppm.data_ptr(), Z.data_ptr(), st), "ppm_conv_z")
+    L.check(lib.otvm_ppm_conv_add(Z.data_ptr(), H, W, out.ptr, out.ld, st), "ppm_conv_add")
+    torch.cuda.synchronize()
+    got = G.from_act(out)
+    assert G.maxdiff(got, want) <= 2e-5 * max(1.0, float(want.abs().max()))
