@@ -218,7 +218,8 @@ int otvm_ppm_head(const otvm_ppm_head_params* p, void* stream);
  *   otvm_ppm_conv_add: out[p][o] += sum_tap [p + tap inside HxW] sum_scale bilinear_up(Z[tap][scale])(p + tap)   (256 channels).
  * Identical to the reference's conv(cat(...)) restricted to the PPM channels up to fp32 summation order.                 */
 int otvm_ppm_conv_z(const float* const* y, int y_ld, const float* w_ppm, float* Z, void* stream);
-int otvm_ppm_conv_add(const float* Z, int H, int W, float* out, int out_ld, void* stream);
+int otvm_ppm_conv_add(const float* Z, int H, int W, float* out, int out_ld, double* gn_stats, void* stream);
+                                  /* gn_stats (optional, zeroed [32][2] fp64): GroupNorm(32) sums of the FINAL out, as otvm_conv_params.gn_stats */
 
 /* ---------------------------------------------------------------- memory read (STM.py:140-163) -
  * mem[q, :] = sum_m softmax_m(K[m,:].Q[q,:] / sqrt(128)) V[m,:], m over T slots x hw positions.

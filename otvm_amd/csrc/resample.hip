@@ -438,7 +438,8 @@ __global__ __launch_bounds__(256) void ppm_z_kernel(const float* __restrict__ y0
 // 16 waves share the slice (one workgroup per CU fits; with 4 waves -- one per SIMD -- every LDS round trip of the 36 tap x
 // scale steps of a pixel was exposed: 467 us at 136x240, rocprof).
 constexpr int PPMA_WAVES = 16;
-__global__ __launch_bounds__(PPMA_WAVES * 64) void ppm_add_kernel(const float* __restrict__ Z, int H, int W, float* __restrict__ out, int out_ld) {
+__global__ __launch_bounds__(PPMA_WAVES * 64) void ppm_add_kernel(const float* __restrict__ Z, int H, int W, float* __restrict__ out, int out_ld,
+                                                                  double* __restrict__ gn_stats) {
     extern __shared__ float zs[];                               // [9][50][64]
     const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < PPMZ_TAPS * PPMZ_BINS * 64; i += PPMA_WAVES * 64) {
@@ -447,6 +448,7 @@ __global__ __launch_bounds__(PPMA_WAVES * 64) void ppm_add_kernel(const float* _
     }
     __syncthreads();
     const int P = H * W;
+    float gs = 0.f, gss = 0.f;                                    // GroupNorm(32) sums of this lane's channel over the wave's pixels
     // the pixel is the same for all lanes of a wave: tell the compiler (scalar index arithmetic), and compute the row terms of
     // the three filter rows and the column terms of the three filter columns ONCE per scale instead of once per tap
     for (int pv = blockIdx.x * PPMA_WAVES + wave; pv < P; pv += gridDim.x * PPMA_WAVES) {
@@ -492,7 +494,27 @@ __global__ __launch_bounds__(PPMA_WAVES * 64) void ppm_add_kernel(const float* _
                 }
             }
         }
-        out[(int64_t)p * out_ld + g * 64 + lane] += acc;
+        const float v = out[(int64_t)p * out_ld + g * 64 + lane] + acc;
+        out[(int64_t)p * out_ld + g * 64 + lane] = v;
+        gs += v;
+        gss += v * v;
+    }
+    if (gn_stats) {
+        // 256 channels in 32 groups of 8: lanes 8k .. 8k+7 of this 64-channel slice share group g*8 + k; per-wave partial
+        // sums in fp32 over <= a few dozen pixels, promoted to fp64 for the workgroup (LDS) and device (atomic) reductions
+        __shared__ double gred[16];
+        if (tid < 16) gred[tid] = 0.0;
+        __syncthreads();
+        for (int off = 1; off < 8; off <<= 1) {
+            gs += __shfl_xor(gs, off);
+            gss += __shfl_xor(gss, off);
+        }
+        if ((lane & 7) == 0) {
+            atomicAdd(&gred[2 * (lane >> 3)], (double)gs);
+            atomicAdd(&gred[2 * (lane >> 3) + 1], (double)gss);
+        }
+        __syncthreads();
+        if (tid < 16) atomicAdd(&gn_stats[2 * (g * 8 + (tid >> 1)) + (tid & 1)], gred[tid]);
     }
 }
 
@@ -504,7 +526,7 @@ extern "C" int otvm_ppm_conv_z(const float* const* y, int y_ld, const float* w_p
     return 0;
 }
 
-extern "C" int otvm_ppm_conv_add(const float* Z, int H, int W, float* out, int out_ld, void* stream) {
+extern "C" int otvm_ppm_conv_add(const float* Z, int H, int W, float* out, int out_ld, double* gn_stats, void* stream) {
     OTVM_REQUIRE(Z && out && H > 0 && W > 0, "otvm_ppm_conv_add: bad arguments");
     constexpr int LDS = PPMZ_TAPS * PPMZ_BINS * 64 * (int)sizeof(float);
     static bool attr_set = false;
@@ -519,7 +541,7 @@ extern "C" int otvm_ppm_conv_add(const float* Z, int H, int W, float* out, int o
     int bx = otvm_ceil_div((int64_t)H * W, PPMA_WAVES * 8);        // >= 8 pixels per wave
     if (bx > 64) bx = 64;                                         // 64 x 4 channel groups = one workgroup per CU
     if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(ppm_add_kernel, dim3(bx, 4), dim3(PPMA_WAVES * 64), LDS, (hipStream_t)stream, Z, H, W, out, out_ld);
+    hipLaunchKernelGGL(ppm_add_kernel, dim3(bx, 4), dim3(PPMA_WAVES * 64), LDS, (hipStream_t)stream, Z, H, W, out, out_ld, gn_stats);
     OTVM_CHECK_LAUNCH("otvm_ppm_conv_add");
     return 0;
 }

@@ -996,6 +996,9 @@ class FramePlan:
                 elif st[0] == "gn_table":
                     _, a, idx, nbs, label = st
                     S[i] = (self.lib.otvm_gn_table_b, (base + idx * 512,) + a + (self.B, sbs, nbs), label)
+                elif st[0] == "ppm_add":
+                    _, a, b, label = st
+                    S[i] = (self.lib.otvm_ppm_conv_add, a + (self._ppm_stats.gn_stats + 8 * b * sbs,), label)
                 elif st[0] == "gn_apply":
                     _, q, idx, label = st
                     q.stats, q.stats_bs = base + idx * 512, sbs
@@ -1233,8 +1236,11 @@ class FramePlan:
                 yp = (C.c_void_p * 4)(*[y.img(b).ptr for y in ys])
                 self._keep.append(yp)
                 S.append((lib.otvm_ppm_conv_z, (yp, ys[0].ld, self.e.W_ppm.data_ptr(), self.PPM_Z[b].data_ptr()), "ppm_conv_z"))
-                S.append((lib.otvm_ppm_conv_add, (self.PPM_Z[b].data_ptr(), H8, W8, u1.img(b).ptr, u1.ld), "ppm_conv_add"))
-            self.gn(S, u1, de + "conv_up1.1", LEAKY, conv_p=None)
+                S.append(("ppm_add", (self.PPM_Z[b].data_ptr(), H8, W8, u1.img(b).ptr, u1.ld), b, "ppm_conv_add"))
+            # the gather writes the layer's final values: it also accumulates their GroupNorm sums (bound in _bind_stats)
+            import types
+            self._ppm_stats = types.SimpleNamespace(gn_stats=0, gn_bs=0)
+            self.gn(S, u1, de + "conv_up1.1", LEAKY, conv_p=self._ppm_stats)
         else:
             cp = self.conv(S, self.PPMCAT, de + "conv_up1.0", u1, pad=1)
             self.gn(S, u1, de + "conv_up1.1", LEAKY, conv_p=cp)

@@ -78,7 +78,7 @@ _PROTOS = {
     "otvm_ppm_pool": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "otvm_ppm_head": (i32, [C.POINTER(PpmHeadParams), vp]),
     "otvm_ppm_conv_z": (i32, [C.POINTER(vp), i32, vp, vp, vp]),
-    "otvm_ppm_conv_add": (i32, [vp, i32, i32, vp, i32, vp]),
+    "otvm_ppm_conv_add": (i32, [vp, i32, i32, vp, i32, vp, vp]),
     "otvm_memory_read_ws_bytes": (i64, [i32, i32]),
     "otvm_memory_read": (i32, [vp, i32, C.POINTER(vp), C.POINTER(vp), i32, i32, vp, i32, vp, vp]),
     "otvm_bank_slot_bytes_f16x3": (i64, [i32]),

@@ -930,7 +930,11 @@ def test_ppm_conv_algebra_matches_conv_over_upsampled_maps(G):
     Z = torch.zeros(9 * 50 * 256, device=G.DEV)
     out = G.to_act(base)
     L.check(lib.otvm_ppm_conv_z(yp, ya[0].ld, w_ppm.data_ptr(), Z.data_ptr(), st), "ppm_conv_z")
-    L.check(lib.otvm_ppm_conv_add(Z.data_ptr(), H, W, out.ptr, out.ld, st), "ppm_conv_add")
+    stats = torch.zeros(64, dtype=torch.float64, device=G.DEV)
+    L.check(lib.otvm_ppm_conv_add(Z.data_ptr(), H, W, out.ptr, out.ld, stats.data_ptr(), st), "ppm_conv_add")
     torch.cuda.synchronize()
     got = G.from_act(out)
     assert G.maxdiff(got, want) <= 2e-5 * max(1.0, float(want.abs().max()))
+    gr = want.double().reshape(32, 8, -1)                              # fused GroupNorm(32) sums of the final tensor
+    ws = torch.stack([gr.sum((1, 2)), (gr * gr).sum((1, 2))], 1).flatten()
+    assert float((stats.cpu() - ws).abs().max()) <= 1e-5 * float(ws.abs().max())
