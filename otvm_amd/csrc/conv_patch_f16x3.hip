@@ -23,6 +23,23 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
+// timing probes for tools/build_variant.sh (results are WRONG with any of them set)
+#ifndef OTVM_PABL_NOMFMA
+#define OTVM_PABL_NOMFMA 0
+#endif
+#ifndef OTVM_PABL_NOLOAD
+#define OTVM_PABL_NOLOAD 0     // global loads of the first stage only
+#endif
+#ifndef OTVM_PABL_NOCOMMIT
+#define OTVM_PABL_NOCOMMIT 0   // split + LDS writes of the first stage only
+#endif
+#ifndef OTVM_PABL_NOLDSRD
+#define OTVM_PABL_NOLDSRD 0    // no fragment reads from LDS
+#endif
+#ifndef OTVM_PABL_NOEPI
+#define OTVM_PABL_NOEPI 0      // no output stores / residual loads
+#endif
+
 namespace {
 
 struct PatchArgs {
@@ -84,6 +101,12 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     _Float16* Bs = smem + PATCH_HALFS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef OTVM_PATCH_STAGGER
+    // timing experiment: the second workgroup of every CU starts half a tile late, so that one workgroup's epilogue / prologue
+    // meets the other's MFMA phase (later workgroups inherit the offset of the slot they take over)
+    if (blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < OTVM_PATCH_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
     // tile decode: channel tile fastest, then x, then y (neighbouring tiles share halo rows in L2)
     int bid = blockIdx.x;
     const int tile_n = bid % p.tiles_n; bid /= p.tiles_n;
@@ -181,10 +204,12 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             __syncthreads();                                            // the previous stage's LDS reads are done
-            commit(g);
+            if (!OTVM_PABL_NOCOMMIT || (cb == 0 && g == 0)) commit(g);
             __syncthreads();
-            if (g + 1 < NG) prefetch(cb, g + 1);
-            else if (cb + 1 < ncb) prefetch(cb + 1, 0);
+            if (!OTVM_PABL_NOLOAD) {
+                if (g + 1 < NG) prefetch(cb, g + 1);
+                else if (cb + 1 < ncb) prefetch(cb + 1, 0);
+            }
             // ---- TAPG taps out of LDS
             // (measured and rejected, round 2: a "row reuse" variant -- one filter column per weight stage, its 3 x TN weight
             // fragments in registers, every patch row of the column read once and used for all (output row, ky) pairs: a
@@ -197,9 +222,14 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                 f16x8 ah[TM], al[TM];
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
+#if OTVM_PABL_NOLDSRD
+                    const f16x8 one = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+                    ah[a] = one * (_Float16)(float)(lane + tap); al[a] = one;
+#else
                     const int o = ((wave * TM + a + ky * DIL) * PW + kx * DIL + frow) * LDP + 8 * fh;
                     ah[a] = *reinterpret_cast<const f16x8*>(&Ph[o]);
                     al[a] = *reinterpret_cast<const f16x8*>(&Pl[o]);
+#endif
                 }
                 // B fragments are read for GB channel tiles at a time, then three passes over the GB x TM accumulators:
                 // consecutive MFMAs never share an accumulator (a wide tile has TM = 1: the per-tile order
@@ -210,9 +240,18 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                     f16x8 bh[GB], bl[GB];
 #pragma unroll
                     for (int j = 0; j < GB; ++j) {
+#if OTVM_PABL_NOLDSRD
+                        const f16x8 one = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
+                        bh[j] = one; bl[j] = one * (_Float16)(float)lane;
+#else
                         bh[j] = *reinterpret_cast<const f16x8*>(&Bs[((tl * TN + b0 + j) * 2) * 512 + lane * 8]);
                         bl[j] = *reinterpret_cast<const f16x8*>(&Bs[((tl * TN + b0 + j) * 2 + 1) * 512 + lane * 8]);
+#endif
                     }
+#if OTVM_PABL_NOMFMA
+                    if (ah[0][0] == (_Float16)12345.f) acc[0][0][0] += (float)bh[0][0] + (float)bl[0][0] + (float)al[0][0];
+                    continue;
+#endif
 #pragma unroll
                     for (int j = 0; j < GB; ++j)
 #pragma unroll
@@ -236,6 +275,10 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     // ---- epilogue: accumulator tile -> wave-private LDS patch -> 16-byte row-major stores (see conv_f16x3.hip)
     const int col = lane & 31, rbase = (lane >> 5) * 4;
     __syncthreads();
+#if OTVM_PABL_NOEPI
+    if (acc[0][0][0] == 12345.678f) p.out[0] = acc[0][0][1];
+    if (acc[0][0][0] != 12345.678f) return;
+#endif
     {
         float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
         const int prow = lane >> 3, pc = (lane & 7) * 4;
