@@ -397,6 +397,14 @@ class HipEngine:
             L.check(self.lib.otvm_finite_guard(v.ptr, v.P, v.C, v.ld, limit, max(int(tag), 0), self.guard_flag.data_ptr(), stream),
                     "finite_guard " + what)
 
+    def scan_now(self, act, what, stream):
+        """Level 3: scan ``act`` and look at the verdict immediately (one synchronisation per call)."""
+        self.guard(act, what, stream)
+        v = int(self.guard_flag.item())
+        if v != GUARD_CLEAR:
+            self.guard_flag.fill_(GUARD_CLEAR)
+            raise FloatingPointError("otvm_amd: |x| >= 65504 (or inf / NaN) at the %s, frame %d" % (what, v))
+
     def _guard_raise(self, frame):
         self.guard_flag.fill_(GUARD_CLEAR)
         self._guard_host.fill_(GUARD_CLEAR)
@@ -1328,11 +1336,7 @@ class FramePlan:
                 if rc != 0:
                     L.check(rc, st[2])
                 if st[2].startswith("conv "):
-                    self.e.guard(st[5][1], "output of " + st[2], stream)
-                    v = int(self.e.guard_flag.item())
-                    if v != GUARD_CLEAR:
-                        self.e.guard_flag.fill_(GUARD_CLEAR)
-                        raise FloatingPointError("otvm_amd: |x| >= 65504 (or inf / NaN) at the %s, frame %d" % (st[2], v))
+                    self.e.scan_now(st[5][1], "output of " + st[2], stream)
             return
         if prof is None:
             if graphs_wanted(self.e.use_graphs, self.P):
@@ -1472,6 +1476,8 @@ class FramePlan:
             if prof is not None:
                 e1.record()
                 prof.append((st[2], st[3], e0, e1, st[4]))
+            if prof is None and self.e.check_level >= 3:
+                self.e.scan_now(st[5][1], "output of " + st[2], stream)
         self.e.guard(slot["k"], "memorised key", stream, slot["frame"])
         self.e.guard(slot["v"], "memorised value", stream, slot["frame"])
         if "packed_b" in slot:

@@ -461,6 +461,20 @@ def test_range_guard_raises_when_the_bank_leaves_fp16_range(synth_sd):
     m0(torch.ones(1, 1, 1, H, W, device="cuda"), fg, fg, tri_gt=torch.from_numpy(tri)[None, None].cuda(), first_frame=True,
        last_frame=True, max_memory_num=5)
     assert int(m0._engine.guard_flag.item()) == 2 ** 31 - 1
+    # level 3 (first run of a new checkpoint): every convolution's input and output is scanned; the offending LAYER is named
+    m3 = helpers.get_model_alpha(cfg, helpers.get_model_trimap(cfg, "Test", 12), "Test", 12)
+    m3.load_state_dict(sd, strict=True)
+    m3 = m3.cuda().eval()
+    m3._get_engine().check_level = 3
+    fg1 = torch.from_numpy(frames[1].astype(np.float32)).permute(2, 0, 1)[None, None].contiguous().cuda()
+    tri_d = torch.from_numpy(tri)[None, None].cuda()
+    ones = torch.ones(1, 1, 1, H, W, device="cuda")
+    with pytest.raises(FloatingPointError, match="KV_M_r4.Value"):
+        m3(ones, fg, fg, tri_gt=tri_d, first_frame=True, last_frame=False, memorize=True, max_memory_num=5)
+        m3(ones, fg1, fg1, tri_gt=tri_d, first_frame=False, last_frame=True, memorize=True, max_memory_num=5)
+    m0._engine.check_level = 3                                        # ... and a healthy checkpoint passes the full scan
+    m0(ones, fg, fg, tri_gt=tri_d, first_frame=True, last_frame=False, max_memory_num=5)
+    m0(ones, fg1, fg1, tri_gt=tri_d, first_frame=False, last_frame=True, max_memory_num=5)
 
 
 def test_batched_sequences_equal_single_runs(synth_sd, monkeypatch):
