@@ -35,7 +35,7 @@ extern "C" {
 #define OTVM_PREC_F16X3 1
 
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 14   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
+#define OTVM_ABI_VERSION 15   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
                                  4: otvm_conv_params.splitk_ws; 5: otvm_preprocess_params.fg_u8/bg_u8/u8_rgb;
                                  6: otvm_conv_params.tune + otvm_conv2d_candidates;
                                  7: folded GroupNorm tables on otvm_gn_apply's residual and otvm_upsample_bilinear's input;
@@ -45,7 +45,8 @@ const char* otvm_last_error(void);
                                      otvm_maxpool3x3s2_b);
                                  12: training forward (otvm_fba_head_train, otvm_upsample4_logits3, otvm_trimap_to_sm, otvm_loss_*);
                                  13: otvm_conv_params.w_wfrag + otvm_pack_wave_weight_f16x3 (one-wave 64x64 tile);
-                                 14: otvm_ppm_conv_z / otvm_ppm_conv_add (the PPM branches' share of conv_up1.0 without upsampling) */
+                                 14: otvm_ppm_conv_z / otvm_ppm_conv_add (the PPM branches' share of conv_up1.0 without upsampling);
+                                 15: otvm_stm_bottleneck_f16x3 (one kernel per 1/4-resolution bottleneck of the STM encoders) */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -148,6 +149,23 @@ int otvm_split_conv_weight_f16x3(const float* w_packed, int O, int O_pad, int K_
  * 64x64 tile -- the small-map configuration whose operands bypass LDS; goes into otvm_conv_params.w_wfrag.           */
 int64_t otvm_wave_weight_bytes_f16x3(int O_pad, int K_pad);
 int otvm_pack_wave_weight_f16x3(const void* w_hi, const void* w_lo, int O_pad, int K_pad, void* w_wfrag, void* stream);
+
+/* One torchvision Bottleneck of the STM encoders' 1/4-resolution stage (planes = 64, stride 1, eval-mode BatchNorm folded:
+ * STM.py:43-51,79-87) as ONE launch: t1 = relu(W1 x + b1), t2 = relu(W2 * t1 + b2), y = relu(W3 t2 + b3 + identity); the
+ * 64-channel intermediates stay in LDS, x is read once (with a one-pixel halo), y written once.
+ *   Cin = 256: identity block (identity = x).   Cin = 64: the stage's first block -- the projection Wd x is folded into the
+ *   last GEMM: w3f / s3 then belong to the concatenated filter [W3 | Wd] (K = 128) and b3 = b3 + bd.
+ *   w1f / w2f / w3f: otvm_pack_wave_weight_f16x3 of the split weights (K-major [O_pad][K_pad] from otvm_split_conv_weight_f16x3);
+ *   s*: their per-filter scales; b*: folded biases.  f16x3 arithmetic (OTVM_PREC_F16X3).                                  */
+typedef struct {
+    const float* x; int H, W, Cin, x_ld;            /* [H*W, Cin] view                                       */
+    float* y; int y_ld;                             /* [H*W, 256] view                                       */
+    const void* w1f; const void* w2f; const void* w3f;
+    const float* s1; const float* s2; const float* s3;
+    const float* b1; const float* b2; const float* b3;
+    int batch; int64_t x_bs, y_bs;                  /* images per launch, floats between consecutive images  */
+} otvm_stm_bottleneck_params;
+int otvm_stm_bottleneck_f16x3(const otvm_stm_bottleneck_params* p, void* stream);
 
 /* ---------------------------------------------------------------- GroupNorm(32) ----------------
  * nn.GroupNorm(32, C, eps=1e-5, affine) (layers_WS.py:26-27, FBA/models.py:272-276), two passes:

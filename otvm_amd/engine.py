@@ -50,6 +50,9 @@ PRE_ON_S2 = os.environ.get("OTVM_PRE_ON_S2", "1") != "0"           # preprocess 
 # candidate.  Built and verified in round 3, measured 20-90 % SLOWER than the 4-wave LDS tiles on every small-map shape
 # (scattered 32-byte A loads: 32 cache lines per load instruction through a 64 B/clk L1): off by default, no weight copy.
 WAVE_TILE = os.environ.get("OTVM_WAVE_TILE", "0") != "0"
+# round 3: each 1/4-resolution bottleneck of the STM encoders (res2.0-2, planes 64) as ONE kernel, intermediates in LDS
+# (csrc/bottleneck_f16x3.hip); f16x3 only.  0 = the three (four) convolution launches of round 2
+FUSE_STM_BLOCK = os.environ.get("OTVM_FUSE_STM_BLOCK", "1") != "0"
 FUSE_PPM_HEAD = os.environ.get("OTVM_PPM_HEAD", "1") != "0"
 # round 3: the PPM branches' third of conv_up1.0 computed from the 50 pooled pixels (otvm_ppm_conv_z / _add) instead of
 # convolving their upsampled copies; conv_up1.0 then reads layer 4 only.  OTVM_PPM_ALGEBRA=0 keeps the materialised form.
@@ -329,6 +332,15 @@ class HipEngine:
         self._keep.append((w, scale))
         self.W[name] = cw
 
+    def _wave_frag(self, cw):
+        """MFMA B-fragment-major copy of a split weight (otvm_pack_wave_weight_f16x3), built once."""
+        if cw.w_wfrag is None:
+            O_pad = cw.w_hi.numel() // cw.K_pad
+            cw.w_wfrag = torch.zeros(int(self.lib.otvm_wave_weight_bytes_f16x3(O_pad, cw.K_pad)), dtype=torch.uint8, device=self.dev)
+            L.check(self.lib.otvm_pack_wave_weight_f16x3(cw.w_hi.data_ptr(), cw.w_lo.data_ptr(), O_pad, cw.K_pad,
+                                                         cw.w_wfrag.data_ptr(), self._stream()), "pack_wave_weight")
+        return cw.w_wfrag
+
     def _fold_bn(self, bn):
         sd = self.sd
         n = sd[bn + ".weight"].numel()
@@ -365,6 +377,20 @@ class HipEngine:
                 self._pack(name, v, scale=scale, bias=bias)
             else:                                                        # KV heads, STM decoder: plain conv + bias
                 self._pack(name, v, bias=sd.get(name + ".bias"))
+        if FUSE_STM_BLOCK and self.precision == L.PREC_F16X3:
+            for enc in ("trimap.model.Encoder_M.", "trimap.model.Encoder_Q."):
+                if enc + "res2.0.conv3.weight" not in sd:
+                    continue
+                # first block: the projection shares the last GEMM -- one filter [scale3 W3 | scale_d Wd] over K = 128, split
+                # with ONE power-of-two scale per output channel; the bias is the sum of the two folded biases
+                s3, b3 = self._fold_bn(enc + "res2.0.bn3")
+                sdn, bdn = self._fold_bn(enc + "res2.0.downsample.1")
+                wcat = torch.cat([sd[enc + "res2.0.conv3.weight"] * s3[:, None, None, None],
+                                  sd[enc + "res2.0.downsample.0.weight"] * sdn[:, None, None, None]], dim=1)
+                self._pack(enc + "res2.0.conv3cat", wcat, bias=b3 + bdn)
+                for b in range(3):
+                    for cname in ("conv1", "conv2", "conv3cat" if b == 0 else "conv3"):
+                        self._wave_frag(self.W[enc + "res2.%d.%s" % (b, cname)])
         # Encoder_M stem: conv1_h(hid16) + conv1(rgb) + conv1_m(p_un) + conv1_o(p_fg) + conv1_a(alpha) (STM.py:63-66)
         e = "trimap.model.Encoder_M."
         wcat = torch.cat([sd[e + "conv1_h.weight"], sd[e + "conv1.weight"], sd[e + "conv1_m.weight"],
@@ -1062,6 +1088,23 @@ class FramePlan:
 
     def bn_bottleneck(self, S, x, p, planes, stride, has_ds, out, tag):
         Ho, Wo = x.H // stride, x.W // stride
+        W = self.e.W
+        c3 = W.get(p + (".conv3cat" if has_ds else ".conv3"))
+        if (FUSE_STM_BLOCK and self.e.precision == L.PREC_F16X3 and planes == 64 and stride == 1 and c3 is not None
+                and c3.w_wfrag is not None and x.C == (64 if has_ds else 256)):
+            # one launch, t1 / t2 never leave the CU (csrc/bottleneck_f16x3.hip)
+            c1, c2 = W[p + ".conv1"], W[p + ".conv2"]
+            q = L.StmBottleneckParams(x.ptr, x.H, x.W, x.C, x.ld, out.ptr, out.ld,
+                                      c1.w_wfrag.data_ptr(), c2.w_wfrag.data_ptr(), c3.w_wfrag.data_ptr(),
+                                      c1.w_scale.data_ptr(), c2.w_scale.data_ptr(), c3.w_scale.data_ptr(),
+                                      c1.bias.data_ptr(), c2.bias.data_ptr(), c3.bias.data_ptr(), x.B, x.bs, out.bs)
+            self._keep.append(q)
+            P = x.B * x.H * x.W
+            flops = 2 * P * (x.C * 64 + 9 * 64 * 64 + 64 * 256 + (x.C * 256 if has_ds else 0))
+            abytes = 4 * (P * x.C + P * 256 + x.C * 64 + 9 * 64 * 64 + 64 * 256 + (x.C * 256 if has_ds else 0))
+            S.append((self.lib.otvm_stm_bottleneck_f16x3, (C.byref(q),), "conv " + p + " (fused bottleneck)", flops, abytes,
+                      (x, out.ch(0, 256) if out.C > 256 else out)))
+            return
         t1 = self.buf(tag + "t1", x.H, x.W, planes)
         self.conv(S, x, p + ".conv1", t1, act=RELU)
         t2 = self.buf(tag + "t2", Ho, Wo, planes)

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3 = 0, 1
-ABI_VERSION = 14         # include/otvm_hip.h OTVM_ABI_VERSION
+ABI_VERSION = 15         # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -29,6 +29,12 @@ class ConvParams(C.Structure):
                 ("splitk_ws", vp), ("splitk_ws_bytes", i64),
                 ("batch", i32), ("in_bs", i64), ("out_bs", i64), ("res_bs", i64), ("gn_bs", i32), ("norm_bs", i32),
                 ("w_wfrag", vp)]
+
+
+class StmBottleneckParams(C.Structure):
+    _fields_ = [("x", vp), ("H", i32), ("W", i32), ("Cin", i32), ("x_ld", i32), ("y", vp), ("y_ld", i32),
+                ("w1f", vp), ("w2f", vp), ("w3f", vp), ("s1", vp), ("s2", vp), ("s3", vp), ("b1", vp), ("b2", vp), ("b3", vp),
+                ("batch", i32), ("x_bs", i64), ("y_bs", i64)]
 
 
 class GnApplyParams(C.Structure):
@@ -77,6 +83,7 @@ _PROTOS = {
     "otvm_ppm_pool_ws_bytes": (i64, [i32, i32]),
     "otvm_ppm_pool": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "otvm_ppm_head": (i32, [C.POINTER(PpmHeadParams), vp]),
+    "otvm_stm_bottleneck_f16x3": (i32, [C.POINTER(StmBottleneckParams), vp]),
     "otvm_ppm_conv_z": (i32, [C.POINTER(vp), i32, vp, vp, vp]),
     "otvm_ppm_conv_add": (i32, [vp, i32, i32, vp, i32, vp, vp]),
     "otvm_memory_read_ws_bytes": (i64, [i32, i32]),

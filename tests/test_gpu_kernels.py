@@ -938,3 +938,61 @@ def test_ppm_conv_algebra_matches_conv_over_upsampled_maps(G):
     gr = want.double().reshape(32, 8, -1)                              # fused GroupNorm(32) sums of the final tensor
     ws = torch.stack([gr.sum((1, 2)), (gr * gr).sum((1, 2))], 1).flatten()
     assert float((stats.cpu() - ws).abs().max()) <= 1e-5 * float(ws.abs().max())
+
+
+# ---------------------------------------------------------------------------------------------- fused bottleneck (ABI 15)
+@pytest.mark.parametrize("Cin,H,W", [(256, 8, 32), (256, 19, 45), (64, 16, 64), (64, 27, 70), (256, 68, 120)])
+def test_stm_bottleneck_fused_kernel(G, Cin, H, W):
+    """otvm_stm_bottleneck_f16x3 == relu(conv3(relu(conv2(relu(conv1 x)))) + identity) of the three (four) conv launches,
+    with BatchNorm folded (STM.py:79-87 / torchvision Bottleneck): against fp64 torch, and image-wise identical in a
+    batched launch; sizes that are not multiples of the 8x32 block exercise the halo and the edge masks."""
+    from otvm_amd import lib as L
+    from otvm_amd.engine import Act
+    lib = L.load()
+    B = 2
+    proj = Cin == 64
+    xs = [rnd(1, Cin, H, W, seed=30 + b).clamp_min(0) * 1.5 for b in range(B)]          # a ReLU output, as in the network
+    w1 = rnd(64, Cin, 1, 1, seed=1, scale=1.0 / math.sqrt(Cin))
+    w2 = rnd(64, 64, 3, 3, seed=2, scale=1.0 / math.sqrt(64 * 9))
+    w3 = rnd(256, 64, 1, 1, seed=3, scale=1.0 / math.sqrt(64))
+    wd = rnd(256, Cin, 1, 1, seed=4, scale=1.0 / math.sqrt(Cin))
+    sc = [rnd(n, seed=40 + i).abs() + 0.5 for i, n in enumerate((64, 64, 256, 256))]  # folded BatchNorm scales
+    bi = [rnd(n, seed=50 + i) * 0.3 for i, n in enumerate((64, 64, 256, 256))]
+    c1 = G.pack_weight(w1, scale=sc[0])
+    c2 = G.pack_weight(w2, scale=sc[1])
+    if proj:
+        c3 = G.pack_weight(torch.cat([w3 * sc[2][:, None, None, None], wd * sc[3][:, None, None, None]], dim=1))
+        b3 = (bi[2] + bi[3]).to(G.DEV)
+    else:
+        c3 = G.pack_weight(w3, scale=sc[2])
+        b3 = bi[2].to(G.DEV)
+    b1, b2 = bi[0].to(G.DEV), bi[1].to(G.DEV)
+    xb = _batched_act(G, xs)
+    bs_o = H * W * 256 + 64
+    ob = Act(torch.full((B * bs_o + 16,), float("nan"), device=G.DEV), H, W, 256, 256, 0, B=B, bs=bs_o)
+    q = L.StmBottleneckParams(xb.ptr, H, W, Cin, xb.ld, ob.ptr, ob.ld, c1.w_wfrag.data_ptr(), c2.w_wfrag.data_ptr(),
+                              c3.w_wfrag.data_ptr(), c1.w_scale.data_ptr(), c2.w_scale.data_ptr(), c3.w_scale.data_ptr(),
+                              b1.data_ptr(), b2.data_ptr(), b3.data_ptr(), B, xb.bs, ob.bs)
+    L.check(lib.otvm_stm_bottleneck_f16x3(C.byref(q), G.stream()), "fused bottleneck")
+    torch.cuda.synchronize()
+    for b in range(B):
+        x = xs[b].double()
+        t = F.relu(F.conv2d(x, w1.double() * sc[0].double()[:, None, None, None], bi[0].double()))
+        t = F.relu(F.conv2d(t, w2.double() * sc[1].double()[:, None, None, None], bi[1].double(), padding=1))
+        y = F.conv2d(t, w3.double() * sc[2].double()[:, None, None, None], bi[2].double())
+        idt = F.conv2d(x, wd.double() * sc[3].double()[:, None, None, None], bi[3].double()) if proj else x
+        want = F.relu(y + idt)
+        got = ob.torch(b).permute(2, 0, 1)[None].cpu().double()
+        assert torch.isfinite(got).all()
+        d = float((got - want).abs().max())
+        assert d <= 1e-5 * max(1.0, float(want.abs().max())), (b, d)
+        # a single-image launch gives the same bits
+        o1 = G.empty_act(H, W, 256)
+        q1 = L.StmBottleneckParams(xb.img(b).ptr, H, W, Cin, xb.ld, o1.ptr, o1.ld, c1.w_wfrag.data_ptr(), c2.w_wfrag.data_ptr(),
+                                   c3.w_wfrag.data_ptr(), c1.w_scale.data_ptr(), c2.w_scale.data_ptr(), c3.w_scale.data_ptr(),
+                                   b1.data_ptr(), b2.data_ptr(), b3.data_ptr(), 1, 0, 0)
+        L.check(lib.otvm_stm_bottleneck_f16x3(C.byref(q1), G.stream()), "fused bottleneck, one image")
+        torch.cuda.synchronize()
+        assert torch.equal(o1.torch(), ob.torch(b))
+    q.Cin = 128
+    assert lib.otvm_stm_bottleneck_f16x3(C.byref(q), G.stream()) != 0          # loud refusal, no fallback

@@ -1,0 +1,9 @@
+#!/bin/bash
+cd /root/repo
+mkdir -p gpurun_out/r03w
+O=gpurun_out/r03w
+timeout 600 python -m pytest tests/test_gpu_kernels.py -q -x -m gpu -k "stm_bottleneck" > $O/pytest_kernel.log 2>&1; echo "kernel rc $?" >> $O/pytest_kernel.log
+timeout 300 python tools/bottleneck_bench.py > $O/bnk_1080p.txt 2>&1
+timeout 300 python tools/bottleneck_bench.py --height 120 --width 208 > $O/bnk_480p.txt 2>&1
+export OTVM_HIP_LIB=$PWD/otvm_amd/csrc/build/variants/libotvm_bnk_timing.so
+timeout 300 python tools/bottleneck_bench.py > $O/bnk_1080p_timing.txt 2>&1
