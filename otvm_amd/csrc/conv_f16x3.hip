@@ -15,6 +15,7 @@
 // Tiling as conv_igemm.hip: BM x BN output tile per workgroup, K walked in chunks of 32 through LDS
 // (80-byte padded rows: conflict-free ds_read_b128), NW wave64 each owning TM x TN 32x32 accumulators.
 #include "common.h"
+#include <type_traits>
 #include <hip/hip_fp16.h>
 #include <stdlib.h>
 
@@ -410,20 +411,27 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
     // leaves as 16-byte row-major accesses: 4 store instructions per tile instead of 16, and bias / residual are
     // read as float4.  (With scalar accesses the residual read alone ran at 0.7 TB/s on the K=64 layers.)
     __syncthreads();                                   // all waves are done with the A/B stages
-    {
+    const bool vec_ok = ((p.out_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(outp) & 15) == 0) &&
+                        (!p.residual || (((p.res_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0)));
+    // Round 3: interior tiles (all BM rows and BN columns inside the output, 16-byte accesses possible) take a copy of the
+    // epilogue WITHOUT per-row predicates.  Stores count in vmcnt on gfx9, and for a store inside a divergent branch the
+    // compiler cannot count what is outstanding at the join: it waits for vmcnt(0) in every predicated row block -- i.e.
+    // for the previous store's acknowledgement from L2, 32 times per wave of the 256x256 tile (profiles/r03_fused_bottleneck.txt
+    // is where this showed up first).
+    const bool interior = vec_ok && m0 + BM <= p.M && n0 + BN <= p.Cout;          // workgroup-uniform
+    auto epilogue = [&](auto full_c) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_c)::value;
         float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
         const int prow = lane >> 3, pc = (lane & 7) * 4;
-        const bool vec_ok = ((p.out_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(outp) & 15) == 0) &&
-                            (!p.residual || (((p.res_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0)));
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int nb = n0 + (wn * TN + b) * 32;    // first column of this tile
-            if (nb >= p.Cout) continue;
+            if (!FULL && nb >= p.Cout) continue;
             const int n4 = nb + pc;                    // this lane's 4 columns in the row-major pass
             f32x4 sc4 = {0.f, 0.f, 0.f, 0.f}, bi4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (n4 + j < p.Cout) {
+                if (FULL || n4 + j < p.Cout) {
                     sc4[j] = p.wscale[n4 + j];
                     bi4[j] = p.bias ? p.bias[n4 + j] : 0.f;
                 }
@@ -434,12 +442,16 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
                 // residual: all four 16-byte loads of this tile are issued before anything waits on them (the
                 // load -> add -> store chain per row group was latency-bound: 1.5 TB/s on the K=64 residual layers)
                 f32x4 rres[4];
-                const bool res_vec = p.residual && vec_ok && n4 + 3 < p.Cout;
+                const bool res_vec = p.residual && vec_ok && (FULL || n4 + 3 < p.Cout);
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int m = mb + r4 * 8 + prow;
                     rres[r4] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (res_vec && m < p.M) rres[r4] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)m * p.res_ld + n4);
+                    if (FULL) {
+                        if (p.residual) rres[r4] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)m * p.res_ld + n4);   // (uniform branch)
+                    } else if (res_vec && m < p.M) {
+                        rres[r4] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)m * p.res_ld + n4);
+                    }
                 }
 #pragma unroll
                 for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
@@ -449,8 +461,8 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
                     const int m = mb + row;
                     f32x4 v = *reinterpret_cast<const f32x4*>(&patch[row * 36 + pc]);
                     v = v * sc4 + bi4;
-                    if (m < p.M) {
-                        if (vec_ok && n4 + 3 < p.Cout) {
+                    if (FULL || m < p.M) {
+                        if (FULL || (vec_ok && n4 + 3 < p.Cout)) {
                             v += rres[r4];
                             v.x = otvm_act(v.x, p.act); v.y = otvm_act(v.y, p.act);
                             v.z = otvm_act(v.z, p.act); v.w = otvm_act(v.w, p.act);
@@ -469,7 +481,9 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
                 }
             }
         }
-    }
+    };
+    if (interior) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
     // ---- fused GroupNorm statistics of the tile just written (sum / sum of squares per group, fp64 atomics)
     if (p.gn_stats) {
         // (sum, sumsq) per group of the tile, at most BN/2 groups; lives behind the waves' epilogue patches in the

@@ -15,6 +15,7 @@
 // One wave owns TM = TH/NW output rows (M tiles of 32 pixels) x TN = BN/32 channel tiles.  fp32 accumulate; epilogue
 // as conv_f16x3.hip (filter scale, bias, residual, activation, optional fused GroupNorm statistics).
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -279,18 +280,23 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     if (acc[0][0][0] == 12345.678f) p.out[0] = acc[0][0][1];
     if (acc[0][0][0] != 12345.678f) return;
 #endif
-    {
+    const bool vec_ok = ((p.out_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
+                        (!p.residual || (((p.res_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0)));
+    // interior blocks (every row, column and channel of the block inside the output) take a copy of the epilogue without
+    // per-row predicates: a store inside a divergent branch is preceded by s_waitcnt vmcnt(0), i.e. waits for the previous
+    // store's acknowledgement (stores count in vmcnt on gfx9) -- see conv_f16x3.hip
+    const bool interior = vec_ok && ty0 + TH <= p.H && tx0 + 32 <= p.W && n0 + BN <= p.Cout;      // workgroup-uniform
+    auto epilogue = [&](auto full_c) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_c)::value;
         float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
         const int prow = lane >> 3, pc = (lane & 7) * 4;
-        const bool vec_ok = ((p.out_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
-                            (!p.residual || (((p.res_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0)));
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int n4 = n0 + b * 32 + pc;
             f32x4 sc4 = {0.f, 0.f, 0.f, 0.f}, bi4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (n4 + j < p.Cout) {
+                if (FULL || n4 + j < p.Cout) {
                     sc4[j] = p.wscale[n4 + j];
                     bi4[j] = p.bias ? p.bias[n4 + j] : 0.f;
                 }
@@ -300,12 +306,12 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                 const int y = ty0 + wave * TM + a;
                 // residual: all four 16-byte loads of this tile are issued before anything waits on them
                 f32x4 rres[4];
-                const bool res_vec = p.residual && vec_ok && n4 + 3 < p.Cout;
+                const bool res_vec = p.residual && vec_ok && (FULL || n4 + 3 < p.Cout);
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int x = tx0 + r4 * 8 + prow;
                     rres[r4] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    if (res_vec && y < p.H && x < p.W)
+                    if (FULL ? (p.residual != nullptr) : (res_vec && y < p.H && x < p.W))
                         rres[r4] = *reinterpret_cast<const f32x4*>(p.residual + ((int64_t)y * p.W + x) * p.res_ld + n4);
                 }
 #pragma unroll
@@ -316,9 +322,9 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                     const int x = tx0 + xi;
                     f32x4 v = *reinterpret_cast<const f32x4*>(&patch[xi * 36 + pc]);
                     v = v * sc4 + bi4;
-                    if (y < p.H && x < p.W) {
+                    if (FULL || (y < p.H && x < p.W)) {
                         const int64_t m = (int64_t)y * p.W + x;
-                        if (vec_ok && n4 + 3 < p.Cout) {
+                        if (FULL || (vec_ok && n4 + 3 < p.Cout)) {
                             v += rres[r4];
                             v.x = otvm_act(v.x, p.act); v.y = otvm_act(v.y, p.act);
                             v.z = otvm_act(v.z, p.act); v.w = otvm_act(v.w, p.act);
@@ -337,7 +343,9 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                 }
             }
         }
-    }
+    };
+    if (interior) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
 
     // ---- fused GroupNorm statistics (sum / sum of squares per group, fp64 atomics)
     if (p.gn_stats) {

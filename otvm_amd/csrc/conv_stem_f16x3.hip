@@ -13,6 +13,7 @@
 // straight into registers, one k-step ahead.  Epilogue as conv_patch_f16x3.hip (scale, bias, activation, optional fused
 // GroupNorm statistics).
 #include "common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -164,17 +165,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     // ---- epilogue: accumulator tile -> wave-private LDS patch -> 16-byte row-major stores (see conv_f16x3.hip)
     const int col = lane & 31, rbase = (lane >> 5) * 4;
     __syncthreads();
-    {
+    const bool vec_ok = ((p.out_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
+    // interior blocks: epilogue copy without per-row predicates (no vmcnt(0) in front of every store, see conv_f16x3.hip)
+    const bool interior = vec_ok && ty0 + TH <= p.Ho && tx0 + 32 <= p.Wo && TN * 32 <= p.Cout;    // workgroup-uniform
+    auto epilogue = [&](auto full_c) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_c)::value;
         float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
         const int prow = lane >> 3, pc = (lane & 7) * 4;
-        const bool vec_ok = ((p.out_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int n4 = b * 32 + pc;
             f32x4 sc4 = {0.f, 0.f, 0.f, 0.f}, bi4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (n4 + j < p.Cout) {
+                if (FULL || n4 + j < p.Cout) {
                     sc4[j] = p.wscale[n4 + j];
                     bi4[j] = p.bias ? p.bias[n4 + j] : 0.f;
                 }
@@ -190,9 +194,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     const int x = tx0 + xi;
                     f32x4 v = *reinterpret_cast<const f32x4*>(&patch[xi * 36 + pc]);
                     v = v * sc4 + bi4;
-                    if (y < p.Ho && x < p.Wo) {
+                    if (FULL || (y < p.Ho && x < p.Wo)) {
                         const int64_t m = (int64_t)y * p.Wo + x;
-                        if (vec_ok && n4 + 3 < p.Cout) {
+                        if (FULL || (vec_ok && n4 + 3 < p.Cout)) {
                             v.x = otvm_act(v.x, p.act); v.y = otvm_act(v.y, p.act);
                             v.z = otvm_act(v.z, p.act); v.w = otvm_act(v.w, p.act);
                             *reinterpret_cast<f32x4*>(p.out + m * p.out_ld + n4) = v;
@@ -205,7 +209,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
             }
         }
-    }
+    };
+    if (interior) epilogue(std::true_type{});
+    else epilogue(std::false_type{});
     // ---- fused GroupNorm statistics (sum / sum of squares per group, fp64 atomics), as conv_patch_f16x3.hip
     if (p.gn_stats) {
         __shared__ double gred[2 * 64];
