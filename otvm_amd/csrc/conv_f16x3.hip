@@ -419,6 +419,61 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
     // for the previous store's acknowledgement from L2, 32 times per wave of the 256x256 tile (profiles/r03_fused_bottleneck.txt
     // is where this showed up first).
     const bool interior = vec_ok && m0 + BM <= p.M && n0 + BN <= p.Cout;          // workgroup-uniform
+    // vmcnt retires in order: waiting for a load that was issued AFTER a store also waits for that store.  So the interior
+    // path fetches the scale / bias vectors of all TN column tiles up front and requests the residual of tile t + 1 before
+    // the stores of tile t go out -- nothing in it ever waits for a store.  Activation and residual are compile-time here:
+    // a uniform branch inside the tile loop would split it into basic blocks and bring the conservative vmcnt(0) back.
+    auto epilogue_full = [&](auto act_c, auto res_c) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_c)::value;
+        constexpr bool RES = decltype(res_c)::value;
+        float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
+        const int prow = lane >> 3, pc = (lane & 7) * 4;
+        f32x4 sc4[TN], bi4[TN];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+            const int n4 = n0 + (wn * TN + b) * 32 + pc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc4[b][j] = p.wscale[n4 + j];
+            bi4[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (p.bias) {
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bi4[b][j] = p.bias[n0 + (wn * TN + b) * 32 + pc + j];
+        }
+        auto load_res = [&](int t, f32x4 (&r)[4]) __attribute__((always_inline)) {
+            const int b = t / TM, a = t - b * TM;
+            const int n4 = n0 + (wn * TN + b) * 32 + pc;
+            const int mb = m0 + (wm * TM + a) * 32;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                r[r4] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)(mb + r4 * 8 + prow) * p.res_ld + n4);
+        };
+        f32x4 rnext[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (RES) load_res(0, rnext);
+#pragma unroll
+        for (int t = 0; t < TM * TN; ++t) {
+            const int b = t / TM, a = t - b * TM;
+            const int n4 = n0 + (wn * TN + b) * 32 + pc;
+            const int mb = m0 + (wm * TM + a) * 32;
+            f32x4 rres[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) rres[r4] = rnext[r4];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
+            if (RES && t + 1 < TM * TN) load_res(t + 1, rnext);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int row = r4 * 8 + prow;
+                f32x4 v = *reinterpret_cast<const f32x4*>(&patch[row * 36 + pc]);
+                v = v * sc4[b] + bi4[b];
+                if (RES) v += rres[r4];
+                v.x = otvm_act(v.x, ACT); v.y = otvm_act(v.y, ACT); v.z = otvm_act(v.z, ACT); v.w = otvm_act(v.w, ACT);
+                *reinterpret_cast<f32x4*>(outp + (int64_t)(mb + row) * p.out_ld + n4) = v;
+            }
+        }
+    };
     auto epilogue = [&](auto full_c) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_c)::value;
         float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
@@ -482,8 +537,15 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
             }
         }
     };
-    if (interior) epilogue(std::true_type{});
-    else epilogue(std::false_type{});
+    if (interior) {
+        using std::integral_constant;
+        const bool r = p.residual != nullptr;
+        if (p.act == OTVM_ACT_RELU) { if (r) epilogue_full(integral_constant<int, OTVM_ACT_RELU>{}, std::true_type{}); else epilogue_full(integral_constant<int, OTVM_ACT_RELU>{}, std::false_type{}); }
+        else if (p.act == OTVM_ACT_LEAKY) { if (r) epilogue_full(integral_constant<int, OTVM_ACT_LEAKY>{}, std::true_type{}); else epilogue_full(integral_constant<int, OTVM_ACT_LEAKY>{}, std::false_type{}); }
+        else { if (r) epilogue_full(integral_constant<int, OTVM_ACT_NONE>{}, std::true_type{}); else epilogue_full(integral_constant<int, OTVM_ACT_NONE>{}, std::false_type{}); }
+    } else {
+        epilogue(std::false_type{});
+    }
     // ---- fused GroupNorm statistics of the tile just written (sum / sum of squares per group, fp64 atomics)
     if (p.gn_stats) {
         // (sum, sumsq) per group of the tile, at most BN/2 groups; lives behind the waves' epilogue patches in the

@@ -286,6 +286,56 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     // per-row predicates: a store inside a divergent branch is preceded by s_waitcnt vmcnt(0), i.e. waits for the previous
     // store's acknowledgement (stores count in vmcnt on gfx9) -- see conv_f16x3.hip
     const bool interior = vec_ok && ty0 + TH <= p.H && tx0 + 32 <= p.W && n0 + BN <= p.Cout;      // workgroup-uniform
+    // interior path, specialised on activation and residual (no uniform branches inside the tile loop), scale / bias of
+    // all column tiles fetched up front, the residual of tile t + 1 requested before the stores of tile t: vmcnt retires
+    // in order, so nothing here ever waits for a store (conv_f16x3.hip has the long version of this comment)
+    auto epilogue_full = [&](auto act_c, auto res_c) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_c)::value;
+        constexpr bool RES = decltype(res_c)::value;
+        float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
+        const int prow = lane >> 3, pc = (lane & 7) * 4;
+        f32x4 sc4[TN], bi4[TN];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc4[b][j] = p.wscale[n0 + b * 32 + pc + j];
+            bi4[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (p.bias) {
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bi4[b][j] = p.bias[n0 + b * 32 + pc + j];
+        }
+        auto load_res = [&](int t, f32x4 (&r)[4]) __attribute__((always_inline)) {
+            const int b = t / TM, a = t - b * TM;
+            const int64_t m0r = (int64_t)(ty0 + wave * TM + a) * p.W + tx0 + prow;
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4)
+                r[r4] = *reinterpret_cast<const f32x4*>(p.residual + (m0r + r4 * 8) * p.res_ld + n0 + b * 32 + pc);
+        };
+        f32x4 rnext[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        if (RES) load_res(0, rnext);
+#pragma unroll
+        for (int t = 0; t < TM * TN; ++t) {
+            const int b = t / TM, a = t - b * TM;
+            const int64_t m0r = (int64_t)(ty0 + wave * TM + a) * p.W + tx0 + prow;
+            f32x4 rres[4];
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) rres[r4] = rnext[r4];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
+            if (RES && t + 1 < TM * TN) load_res(t + 1, rnext);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(&patch[(r4 * 8 + prow) * 36 + pc]);
+                v = v * sc4[b] + bi4[b];
+                if (RES) v += rres[r4];
+                v.x = otvm_act(v.x, ACT); v.y = otvm_act(v.y, ACT); v.z = otvm_act(v.z, ACT); v.w = otvm_act(v.w, ACT);
+                *reinterpret_cast<f32x4*>(p.out + (m0r + r4 * 8) * p.out_ld + n0 + b * 32 + pc) = v;
+            }
+        }
+    };
     auto epilogue = [&](auto full_c) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_c)::value;
         float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
@@ -344,8 +394,15 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
             }
         }
     };
-    if (interior) epilogue(std::true_type{});
-    else epilogue(std::false_type{});
+    if (interior) {
+        using std::integral_constant;
+        const bool r = p.residual != nullptr;
+        if (p.act == OTVM_ACT_RELU) { if (r) epilogue_full(integral_constant<int, OTVM_ACT_RELU>{}, std::true_type{}); else epilogue_full(integral_constant<int, OTVM_ACT_RELU>{}, std::false_type{}); }
+        else if (p.act == OTVM_ACT_LEAKY) { if (r) epilogue_full(integral_constant<int, OTVM_ACT_LEAKY>{}, std::true_type{}); else epilogue_full(integral_constant<int, OTVM_ACT_LEAKY>{}, std::false_type{}); }
+        else { if (r) epilogue_full(integral_constant<int, OTVM_ACT_NONE>{}, std::true_type{}); else epilogue_full(integral_constant<int, OTVM_ACT_NONE>{}, std::false_type{}); }
+    } else {
+        epilogue(std::false_type{});
+    }
 
     // ---- fused GroupNorm statistics (sum / sum of squares per group, fp64 atomics)
     if (p.gn_stats) {

@@ -168,6 +168,40 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const bool vec_ok = ((p.out_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0);
     // interior blocks: epilogue copy without per-row predicates (no vmcnt(0) in front of every store, see conv_f16x3.hip)
     const bool interior = vec_ok && ty0 + TH <= p.Ho && tx0 + 32 <= p.Wo && TN * 32 <= p.Cout;    // workgroup-uniform
+    // interior path specialised on the activation (no uniform branches between the stores), scale / bias fetched up front
+    auto epilogue_full = [&](auto act_c) __attribute__((always_inline)) {
+        constexpr int ACT = decltype(act_c)::value;
+        float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
+        const int prow = lane >> 3, pc = (lane & 7) * 4;
+        f32x4 sc4[TN], bi4[TN];
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sc4[b][j] = p.wscale[b * 32 + pc + j];
+            bi4[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (p.bias) {
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bi4[b][j] = p.bias[b * 32 + pc + j];
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                const int64_t m0r = (int64_t)(ty0 + wave * TM + a) * p.Wo + tx0 + prow;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&patch[(r4 * 8 + prow) * 36 + pc]);
+                    v = v * sc4[b] + bi4[b];
+                    v.x = otvm_act(v.x, ACT); v.y = otvm_act(v.y, ACT); v.z = otvm_act(v.z, ACT); v.w = otvm_act(v.w, ACT);
+                    *reinterpret_cast<f32x4*>(p.out + (m0r + r4 * 8) * p.out_ld + b * 32 + pc) = v;
+                }
+            }
+    };
     auto epilogue = [&](auto full_c) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_c)::value;
         float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
@@ -210,8 +244,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
         }
     };
-    if (interior) epilogue(std::true_type{});
-    else epilogue(std::false_type{});
+    if (interior) {
+        if (p.act == OTVM_ACT_RELU) epilogue_full(std::integral_constant<int, OTVM_ACT_RELU>{});
+        else if (p.act == OTVM_ACT_LEAKY) epilogue_full(std::integral_constant<int, OTVM_ACT_LEAKY>{});
+        else epilogue_full(std::integral_constant<int, OTVM_ACT_NONE>{});
+    } else {
+        epilogue(std::false_type{});
+    }
     // ---- fused GroupNorm statistics (sum / sum of squares per group, fp64 atomics), as conv_patch_f16x3.hip
     if (p.gn_stats) {
         __shared__ double gred[2 * 64];
