@@ -33,7 +33,8 @@ PEAK_TFLOPS = {"f32": 157.3, "f16x3": 2500.0 / 3.0}
 POWER_LIMITED_PEAK = {"f16x3": 1650.0 / 3.0}       # tools/probes/mfma_probe.hip, random hi/lo operands, 256 CUs: 1598 - 1710 TFLOP/s f16 over four
                                                     # boxes (profiles/r02_mfma_power_ceiling.txt: 1659)
 KERNEL_NAME = {"f32": "all otvm_conv2d launches: conv_igemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
-               "f16x3": "all otvm_conv2d launches: conv_igemm_f16x3_kernel + conv_patch_f16x3_kernel + conv_stem_f16x3_kernel (+ split-K finish); "
+               "f16x3": "all convolution launches of the plan: conv_igemm_f16x3_kernel + conv_patch_f16x3_kernel + conv_stem_f16x3_kernel "
+                        "(+ split-K finish) + stm_bottleneck_f16x3_kernel (three / four fused convolutions of an STM res2 block); "
                         "3x v_mfma_f32_32x32x16_f16 per fp32-equivalent MAC"}
 
 

@@ -17,6 +17,8 @@ def group(n):
         return "conv (implicit GEMM)"
     if "conv_patch" in n:
         return "conv (patch)"
+    if "stm_bottleneck" in n:
+        return "conv (fused bottleneck)"
     if "gn_apply" in n or "gn_stats" in n:
         return "gn_apply"
     if "memory_read" in n or "bank_pack" in n:
