@@ -284,7 +284,7 @@ def main():
         traffic = None
         import glob
         tpaths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_conv_traffic_%s_%dx%d.json" % (eng.precision_name, W, H))))
-        if tpaths:                                          # the most recent round's passes
+        if tpaths and args.batch <= 1:                      # the most recent round's passes (collected with one sequence per step)
             tj = json.load(open(tpaths[-1]))                # bytes of all conv kernels per frame / otvm_conv2d calls per frame
             traffic = tj["traffic_bytes_per_frame"] / (n / nrep) if "traffic_bytes_per_frame" in tj else tj.get("traffic_bytes_per_launch")
         result["roofline"] = {
