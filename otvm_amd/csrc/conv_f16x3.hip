@@ -122,7 +122,7 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
     // fragment reads 1 -- the parts ADD because a workgroup's phases are serialised by its two barriers per chunk and the
     // two workgroups of a CU run in step.  Converting chunk c+1 between the two k-steps of chunk c lets one wave's VALU /
     // LDS work issue under its own MFMAs.
-    constexpr bool DBUF = DB || (BM == 256 && BN >= 128 && WM * WN == 8);   // (the 4-wave 256x128 / 128x256 tiles: one stage, two workgroups per CU)
+    constexpr bool DBUF = DB || (BM == 256 && BN >= 128 && WM * WN == 8) || (BM == 256 && BN == 256);   // (the 4-wave 256x128 / 128x256 tiles: one stage, two workgroups per CU)
     __shared__ __attribute__((aligned(16))) _Float16 smem[(DBUF ? 2 : 1) * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -453,35 +453,37 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
         f32x4 rnext[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         if (RES) load_res(0, rnext);
 #pragma unroll
-        for (int t = 0; t < TM * TN; ++t) {
-            const int b = t / TM, a = t - b * TM;
-            const int n4 = n0 + (wn * TN + b) * 32 + pc;
-            const int mb = m0 + (wm * TM + a) * 32;
-            f32x4 rres[4];
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) rres[r4] = rnext[r4];
+            for (int a = 0; a < TM; ++a) {                // (two short loops: a single 16-trip loop is not unrolled, and a
+                const int t = b * TM + a;                 //  dynamically indexed accumulator array goes to scratch)
+                const int n4 = n0 + (wn * TN + b) * 32 + pc;
+                const int mb = m0 + (wm * TM + a) * 32;
+                f32x4 rres[4];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
-            if (RES && t + 1 < TM * TN) load_res(t + 1, rnext);
+                for (int r4 = 0; r4 < 4; ++r4) rres[r4] = rnext[r4];
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const int row = r4 * 8 + prow;
-                f32x4 v = *reinterpret_cast<const f32x4*>(&patch[row * 36 + pc]);
-                v = v * sc4[b] + bi4[b];
-                if (RES) v += rres[r4];
-                v.x = otvm_act(v.x, ACT); v.y = otvm_act(v.y, ACT); v.z = otvm_act(v.z, ACT); v.w = otvm_act(v.w, ACT);
-                *reinterpret_cast<f32x4*>(outp + (int64_t)(mb + row) * p.out_ld + n4) = v;
+                for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
+                if (RES && t + 1 < TM * TN) load_res(t + 1, rnext);
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const int row = r4 * 8 + prow;
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&patch[row * 36 + pc]);
+                    v = v * sc4[b] + bi4[b];
+                    if (RES) v += rres[r4];
+                    v.x = otvm_act(v.x, ACT); v.y = otvm_act(v.y, ACT); v.z = otvm_act(v.z, ACT); v.w = otvm_act(v.w, ACT);
+                    *reinterpret_cast<f32x4*>(outp + (int64_t)(mb + row) * p.out_ld + n4) = v;
+                }
             }
-        }
     };
     auto epilogue = [&](auto full_c) __attribute__((always_inline)) {
         constexpr bool FULL = decltype(full_c)::value;
         float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
         const int prow = lane >> 3, pc = (lane & 7) * 4;
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
+        otvm_static_for<TN>([&](auto b_c) __attribute__((always_inline)) {
+            constexpr int b = decltype(b_c)::value;
             const int nb = n0 + (wn * TN + b) * 32;    // first column of this tile
-            if (!FULL && nb >= p.Cout) continue;
+            if (!FULL && nb >= p.Cout) return;
             const int n4 = nb + pc;                    // this lane's 4 columns in the row-major pass
             f32x4 sc4 = {0.f, 0.f, 0.f, 0.f}, bi4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -491,8 +493,8 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
                     bi4[j] = p.bias ? p.bias[n4 + j] : 0.f;
                 }
             }
-#pragma unroll
-            for (int a = 0; a < TM; ++a) {
+            otvm_static_for<TM>([&](auto a_c) __attribute__((always_inline)) {
+                constexpr int a = decltype(a_c)::value;
                 const int mb = m0 + (wm * TM + a) * 32;
                 // residual: all four 16-byte loads of this tile are issued before anything waits on them (the
                 // load -> add -> store chain per row group was latency-bound: 1.5 TB/s on the K=64 residual layers)
@@ -534,8 +536,8 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
                         }
                     }
                 }
-            }
-        }
+            });
+        });
     };
     if (interior) {
         using std::integral_constant;
@@ -1004,11 +1006,11 @@ int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream);    //
 // splitk_finish_kernel), or the 3x3 patch kernel.  otvm_conv_params.tune forces one (the host's plan-time autotuner,
 // otvm_amd/engine.py, times the candidates of otvm_conv2d_candidates on the device); 0 = the heuristic below.
 enum { T256x256 = 0, T256x128, T128x128, T128x64, T64x64, T256x64, T256x32, T256x128W4, T128x256W4, T64x64W1, T64x64D, T128x64D,
-       T_COUNT, T_STEM = 12, T_PATCH = 14 };
-static_assert(T_COUNT <= T_STEM, "tile codes collide with the stem / patch codes");
+       T_STEM = 12, T256x256W4 = 13, T_PATCH = 14, T_COUNT = 15 };
 static inline int tune_code(int tile, int S) { return (tile + 1) * 16 + S; }
-static const int TILE_BM[T_COUNT] = {256, 256, 128, 128, 64, 256, 256, 256, 128, 64, 64, 128};
-static const int TILE_BN[T_COUNT] = {256, 128, 128, 64, 64, 64, 32, 128, 256, 64, 64, 64};
+static inline bool is_gemm_tile(int t) { return (t >= 0 && t < T_STEM) || t == T256x256W4; }
+static const int TILE_BM[T_COUNT] = {256, 256, 128, 128, 64, 256, 256, 256, 128, 64, 64, 128, 0, 256, 0};
+static const int TILE_BN[T_COUNT] = {256, 128, 128, 64, 64, 64, 32, 128, 256, 64, 64, 64, 0, 256, 0};
 
 static int launch_wave(Conv3Args& a, hipStream_t s, int ksplit) {
     a.tiles_m = otvm_ceil_div(a.M, 64);
@@ -1042,6 +1044,13 @@ static int launch_tile(int tile, Conv3Args& a, hipStream_t s, int S) {
         // pipelined small tiles: two LDS stages, one barrier per chunk, the next chunk converted under the MFMAs
         case T64x64D: return launch3<64, 64, 2, 2, true>(a, s, S);
         case T128x64D: return launch3<128, 64, 2, 2, true>(a, s, S);
+        // 256x256 with FOUR waves: every wave owns 128x128 (4x4 accumulator tiles, 256 registers), one wave per SIMD.  Per
+        // 16-deep k-step a wave reads 16 fragments for 48 MFMAs, the 8-wave tile 12 for 24: a third less LDS traffic per
+        // MFMA (tools/probes/lds_probe.hip: ~13 clocks per wave-wide b128 access with four waves issuing, so the 8-wave
+        // tile's fragment reads take about as long as its MFMAs).  Measured: 256->256 3x3 at 272x480 0.462 vs 0.479 ms, but
+        // 512->512 0.445 vs 0.408, 2048->256 1.45 vs 1.15, the 1x1 layers 20-40 % slower -- a single wave per SIMD has
+        // nothing to overlap its own fragment reads with.  Kept as a forced configuration (tune code 225), not a candidate.
+        case T256x256W4: return launch3<256, 256, 2, 2>(a, s, S);
     }
     otvm_set_error("otvm_conv2d(f16x3): unknown tile %d", tile);
     return 1;
@@ -1049,7 +1058,7 @@ static int launch_tile(int tile, Conv3Args& a, hipStream_t s, int S) {
 
 // is (tile, S) a legal configuration of this layer?
 static bool config_ok(const otvm_conv_params* p, int tile, int S) {
-    if (tile < 0 || tile >= T_COUNT || S < 1 || S > 8) return false;
+    if (!is_gemm_tile(tile) || S < 1 || S > 8) return false;
     const int64_t M = (int64_t)p->Ho * p->Wo;
     // the weight arrays hold O_pad = Cout rounded up to 128 rows (include/otvm_hip.h): a 256-wide N tile may only be
     // used when that is a multiple of 256, or its last tile would read rows past the allocation
@@ -1057,7 +1066,7 @@ static bool config_ok(const otvm_conv_params* p, int tile, int S) {
     if (p->in_scale) return false;                                  // fused input normalisation: patch kernel only
     // the 4-wave big tiles hold 128 accumulator registers per lane: only their wave-uniform-tap-walk variants fit two
     // waves per SIMD without spilling
-    if ((tile == T256x128W4 || tile == T128x256W4) && !f16x3_fast_layout(p->kh * p->kw, p->Cin)) return false;
+    if ((tile == T256x128W4 || tile == T128x256W4 || tile == T256x256W4) && !f16x3_fast_layout(p->kh * p->kw, p->Cin)) return false;
     // the wave tile reads fragment-major weights and walks whole 32-channel blocks: fast layout + w_wfrag only
     if ((tile == T64x64D || tile == T128x64D) && !f16x3_fast_layout(p->kh * p->kw, p->Cin)) return false;
     if (tile == T64x64W1 && !(p->w_wfrag && f16x3_fast_layout(p->kh * p->kw, p->Cin) && (p->in_ld & 3) == 0)) return false;
@@ -1105,6 +1114,8 @@ extern "C" int otvm_conv2d_candidates(const otvm_conv_params* p, int* out, int m
     if (p->in_scale) return n;
     const int64_t M = (int64_t)p->Ho * p->Wo;
     const int nchunks = p->K_pad / 32;
+    // (T256x256W4 is legal when forced but not offered: it won one of seven large layers by 3.5 % and lost the others by
+    //  6-40 %, profiles/r03_lds_and_wait_counters.md)
     static const int tiles_wide[] = {T256x256, T256x128, T128x128, T128x64, T64x64, T256x128W4, T128x256W4, T64x64W1, T64x64D, T128x64D};
     static const int tiles_64[] = {T256x64, T128x64, T64x64, T64x64W1, T64x64D, T128x64D};
     static const int tiles_32[] = {T256x32, T64x64};

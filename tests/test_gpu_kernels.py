@@ -798,6 +798,8 @@ BATCH_CONV_CASES = [
     (1024, 128, 1, 1, 1, 12, 16, False, 0, True, (9 + 1) * 16 + 4),    # one-wave tile, K split over 4, statistics pass
     (256, 256, 3, 1, 1, 16, 24, True, 1, False, (10 + 1) * 16 + 2),    # pipelined 64x64 tile, K split over 2
     (512, 128, 1, 1, 1, 17, 23, False, 0, True, (11 + 1) * 16 + 1),    # pipelined 128x64 tile + fused statistics
+    (256, 256, 3, 1, 1, 32, 40, True, 1, False, (13 + 1) * 16 + 1),    # 4-wave 256x256 tile (4x4 accumulator tiles per wave): interior tiles
+    (256, 256, 1, 1, 1, 33, 40, False, 0, True, (13 + 1) * 16 + 1),    # same, edge tile + fused statistics
 ]
 
 

@@ -65,7 +65,7 @@ def main():
             tunes = [0] + [int(codes[i]) for i in range(n)]
         else:
             tunes = [int(v) for v in args.tune.split(",")]
-        names = {0: "256x256", 1: "256x128", 2: "128x128", 3: "128x64", 4: "64x64", 5: "256x64", 6: "256x32", 7: "256x128w4", 8: "128x256w4", 9: "wave64", 10: "64x64D", 11: "128x64D", 12: "stem", 14: "patch"}
+        names = {0: "256x256", 1: "256x128", 2: "128x128", 3: "128x64", 4: "64x64", 5: "256x64", 6: "256x32", 7: "256x128w4", 8: "128x256w4", 9: "wave64", 10: "64x64D", 11: "128x64D", 12: "stem", 13: "256x256w4", 14: "patch"}
         for tune in tunes:
             p.tune = tune
             for _ in range(3):
