@@ -132,8 +132,9 @@ int otvm_conv2d(const otvm_conv_params* p, void* stream);
  * number; a code goes into otvm_conv_params.tune.  All configurations compute the same convolution (results differ
  * by fp32 summation order only); the host times them on the device once per layer shape and keeps the fastest.    */
 int otvm_conv2d_candidates(const otvm_conv_params* p, int* out, int max_n);
-/* 1 when otvm_conv2d would run the layer on a kernel that implements in_scale / in_shift (f16x3 3x3 stride-1 patch
- * kernel), else 0: the caller then applies otvm_gn_apply as a separate pass.                                       */
+/* 1 when otvm_conv2d would run the layer on a kernel that implements in_scale / in_shift -- f16x3: the 3x3 stride-1 patch
+ * kernel, or (round 3) any implicit-GEMM tile on a layer with Cin % 32 == 0 and no in_relu -- else 0: the caller then applies
+ * otvm_gn_apply as a separate pass.  Bit-identical to that two-pass route in the same configuration.                       */
 int otvm_conv2d_accepts_input_norm(const otvm_conv_params* p);
 
 /* f16x3: derive the split weights from a packed fp32 weight (see otvm_pack_conv_weight):

@@ -75,6 +75,10 @@ struct Conv3Args {
     int64_t in_bs, out_bs, res_bs; int gn_bs;
     // wave kernel (conv_wave_f16x3_kernel): the split weights in MFMA B-fragment order, see otvm_pack_wave_weight_f16x3
     const _Float16* wf;
+    // fused normalisation of the input (NORM_IN kernels: the producer's GroupNorm apply folded into the A staging):
+    // x' = x * in_scale[c] + in_shift[c], then x' > 0 ? x' : x' * in_slope (1 = none, 0 = ReLU, 0.01 = LeakyReLU), zero in the
+    // conv's padding; tables from otvm_gn_table, image b's table norm_bs floats behind image 0's
+    const float* in_scale; const float* in_shift; float in_slope; int norm_bs;
 };
 
 constexpr int BK = 32;
@@ -96,7 +100,7 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
 
 // FAST: Cin % 32 == 0 and <= 32 taps -> a K chunk never straddles a tap, so the tap walk is wave-uniform
 // (scalar registers) and the per-row work per chunk shrinks to one add and one mask test.
-template <int BM, int BN, int WM, int WN, bool FAST, bool RELU_IN, bool DB = false>
+template <int BM, int BN, int WM, int WN, bool FAST, bool RELU_IN, bool DB = false, bool NORM_IN = false>
 __global__ __launch_bounds__(WM* WN * 64)
 __attribute__((amdgpu_waves_per_eu((BM * BN == 32768 && WM * WN == 4) ? 2 : 1, (BM * BN == 32768 && WM * WN == 4) ? 2 : 10)))
 void conv_igemm_f16x3_kernel(const Conv3Args pa) {
@@ -107,7 +111,9 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
         p.out += zb * p.out_bs;
         if (p.residual) p.residual += zb * p.res_bs;
         if (p.gn_stats) p.gn_stats += zb * p.gn_bs;
+        if (NORM_IN) { p.in_scale += zb * p.norm_bs; p.in_shift += zb * p.norm_bs; }
     }
+    static_assert(!NORM_IN || (FAST && !RELU_IN), "the fused input normalisation exists on the whole-chunk path only");
     constexpr int NT = WM * WN * 64;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int A_ROWS = NT / 8, A_LD = BM / A_ROWS;        // 8 float4 per 32-wide row
@@ -200,6 +206,7 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
         f32x4 ra[A_LD];
         unsigned okmask;            // bit i: ra[i] holds image data (else padding -> zero)
         f16x8 rbh[B_LD], rbl[B_LD];
+        f32x4 nsc, nsh;             // NORM_IN: scale / shift of this thread's four channels of the chunk
     };
     RegSet rs[PF];
 #pragma unroll
@@ -214,6 +221,11 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
         if (FAST) {
             const int delta = (u_ky * p.dil * p.W + u_kx * p.dil) * p.in_ld + (u_cb << 5);   // scalar
             const unsigned bit = 1u << u_tap;
+            if (NORM_IN) {
+                const int cn = (valid ? (u_cb << 5) : 0) + ak;
+                R.nsc = *reinterpret_cast<const f32x4*>(p.in_scale + cn);
+                R.nsh = *reinterpret_cast<const f32x4*>(p.in_shift + cn);
+            }
 #pragma unroll
             for (int i = 0; i < A_LD; ++i) {
                 // UNCONDITIONAL load (padding lanes read element 0 and are zeroed afterwards): a branch around
@@ -277,6 +289,11 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
             f32x4 v = ra[i];
             if (RELU_IN) {
                 v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            if (NORM_IN) {                                  // the same arithmetic as otvm_gn_apply (and the patch kernel)
+                v = v * R.nsc + R.nsh;
+                v.x = v.x > 0.f ? v.x : v.x * p.in_slope; v.y = v.y > 0.f ? v.y : v.y * p.in_slope;
+                v.z = v.z > 0.f ? v.z : v.z * p.in_slope; v.w = v.w > 0.f ? v.w : v.w * p.in_slope;
             }
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             v = (okmask >> i) & 1u ? v : z;
@@ -912,7 +929,8 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
 static thread_local int g_batch = 1;
 static inline int a_batch(const Conv3Args&) { return g_batch; }
 
-template <int BM, int BN, int WM, int WN, bool DB = false>
+// FAST_ONLY: tiles that config_ok() only offers to whole-chunk layers do not instantiate the generic-decode kernels
+template <int BM, int BN, int WM, int WN, bool DB = false, bool FAST_ONLY = false>
 int launch3(Conv3Args& a, hipStream_t s, int ksplit = 1) {
     a.tiles_m = otvm_ceil_div(a.M, BM);
     a.tiles_n = otvm_ceil_div(a.Cout, BN);
@@ -924,14 +942,19 @@ int launch3(Conv3Args& a, hipStream_t s, int ksplit = 1) {
         otvm_set_error("otvm_conv2d(f16x3): input view too large for 32-bit offsets");
         return 1;
     }
+    if (a.in_scale && !(fast && !a.in_relu)) {
+        otvm_set_error("otvm_conv2d(f16x3): the fused input normalisation needs a whole-chunk layer (Cin %% 32 == 0) without in_relu");
+        return 1;
+    }
     if (fast) {
-        if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, true, DB>), grid, block, 0, s, a);
+        if (a.in_scale) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, false, DB, true>), grid, block, 0, s, a);
+        else if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, true, DB>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, false, DB>), grid, block, 0, s, a);
-    } else if (!DB) {
+    } else if constexpr (!DB && !FAST_ONLY) {
         if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, true, false>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, false, false>), grid, block, 0, s, a);
     } else {
-        otvm_set_error("otvm_conv2d(f16x3): the pipelined small tiles take whole-chunk layers only");
+        otvm_set_error("otvm_conv2d(f16x3): this tile takes whole-chunk layers only");
         return 1;
     }
     OTVM_CHECK_LAUNCH("otvm_conv2d(f16x3)");
@@ -1037,8 +1060,8 @@ static int launch_tile(int tile, Conv3Args& a, hipStream_t s, int S) {
         case T256x32: return launch3<256, 32, 4, 1>(a, s, S);
         // 4-wave workgroups with a single LDS stage (61 KB): two per CU, so one workgroup's epilogue (output stores,
         // GroupNorm sums) overlaps the other's main loop -- candidates for the short-K, output-heavy 1x1 layers
-        case T256x128W4: return launch3<256, 128, 2, 2>(a, s, S);
-        case T128x256W4: return launch3<128, 256, 2, 2>(a, s, S);
+        case T256x128W4: return launch3<256, 128, 2, 2, false, true>(a, s, S);
+        case T128x256W4: return launch3<128, 256, 2, 2, false, true>(a, s, S);
         // one-wave workgroups, operands straight from L2 into MFMA registers (small maps)
         case T64x64W1: return launch_wave(a, s, S);
         // pipelined small tiles: two LDS stages, one barrier per chunk, the next chunk converted under the MFMAs
@@ -1050,7 +1073,7 @@ static int launch_tile(int tile, Conv3Args& a, hipStream_t s, int S) {
         // tile's fragment reads take about as long as its MFMAs).  Measured: 256->256 3x3 at 272x480 0.462 vs 0.479 ms, but
         // 512->512 0.445 vs 0.408, 2048->256 1.45 vs 1.15, the 1x1 layers 20-40 % slower -- a single wave per SIMD has
         // nothing to overlap its own fragment reads with.  Kept as a forced configuration (tune code 225), not a candidate.
-        case T256x256W4: return launch3<256, 256, 2, 2>(a, s, S);
+        case T256x256W4: return launch3<256, 256, 2, 2, false, true>(a, s, S);
     }
     otvm_set_error("otvm_conv2d(f16x3): unknown tile %d", tile);
     return 1;
@@ -1063,7 +1086,8 @@ static bool config_ok(const otvm_conv_params* p, int tile, int S) {
     // the weight arrays hold O_pad = Cout rounded up to 128 rows (include/otvm_hip.h): a 256-wide N tile may only be
     // used when that is a multiple of 256, or its last tile would read rows past the allocation
     if (TILE_BN[tile] == 256 && !(p->Cout >= 256 && (otvm_ceil_div(p->Cout, 128) & 1) == 0)) return false;
-    if (p->in_scale) return false;                                  // fused input normalisation: patch kernel only
+    // fused input normalisation: the whole-chunk implicit-GEMM kernels (and the patch kernel), not the one-wave tile
+    if (p->in_scale && !(f16x3_fast_layout(p->kh * p->kw, p->Cin) && !p->in_relu && tile != T64x64W1)) return false;
     // the 4-wave big tiles hold 128 accumulator registers per lane: only their wave-uniform-tap-walk variants fit two
     // waves per SIMD without spilling
     if ((tile == T256x128W4 || tile == T128x256W4 || tile == T256x256W4) && !f16x3_fast_layout(p->kh * p->kw, p->Cin)) return false;
@@ -1111,7 +1135,6 @@ extern "C" int otvm_conv2d_candidates(const otvm_conv_params* p, int* out, int m
     auto add = [&](int code) { if (n < max_n) out[n++] = code; };
     if (otvm_conv2d_stem_eligible(p)) add(tune_code(T_STEM, 1));
     if (otvm_conv2d_patch_eligible(p)) add(tune_code(T_PATCH, 1));
-    if (p->in_scale) return n;
     const int64_t M = (int64_t)p->Ho * p->Wo;
     const int nchunks = p->K_pad / 32;
     // (T256x256W4 is legal when forced but not offered: it won one of seven large layers by 3.5 % and lost the others by
@@ -1134,6 +1157,11 @@ extern "C" int otvm_conv2d_candidates(const otvm_conv_params* p, int* out, int m
         }
     }
     return n;
+}
+
+// the whole-chunk implicit-GEMM kernels fold the producer's GroupNorm apply into their A staging (NORM_IN)
+int otvm_conv2d_igemm_accepts_input_norm(const otvm_conv_params* p) {
+    return p && p->precision == OTVM_PREC_F16X3 && f16x3_fast_layout(p->kh * p->kw, p->Cin) && !p->in_relu && p->w_hi ? 1 : 0;
 }
 
 int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
@@ -1161,6 +1189,11 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     a.M = p->Ho * p->Wo; a.taps = p->kh * p->kw; a.nchunks = p->K_pad / 32;
     a.split_stride = 0;
     a.wf = (const _Float16*)p->w_wfrag;
+    a.in_scale = p->in_scale; a.in_shift = p->in_shift;
+    a.in_slope = p->in_act == OTVM_ACT_RELU ? 0.f : (p->in_act == OTVM_ACT_LEAKY ? 0.01f : 1.f);
+    a.norm_bs = p->batch > 1 ? p->norm_bs : 0;
+    OTVM_REQUIRE(!p->in_scale || otvm_conv2d_igemm_accepts_input_norm(p),
+                 "otvm_conv2d: fused input normalisation on the implicit-GEMM path needs Cin %% 32 == 0 and no in_relu");
     g_batch = p->batch > 1 ? p->batch : 1;
     a.in_bs = g_batch > 1 ? p->in_bs : 0; a.out_bs = g_batch > 1 ? p->out_bs : 0; a.res_bs = g_batch > 1 ? p->res_bs : 0;
     a.gn_bs = g_batch > 1 ? p->gn_bs : 0;

@@ -534,9 +534,10 @@ static int patch_choice(const otvm_conv_params* p, bool forced = false) {
     return t8 >= t_patch ? 2 : 0;
 }
 
-// the fused input normalisation (otvm_conv_params.in_scale) exists on this path only
+// the fused input normalisation (otvm_conv_params.in_scale): this kernel, or the whole-chunk implicit-GEMM kernels
+int otvm_conv2d_igemm_accepts_input_norm(const otvm_conv_params* p);       // conv_f16x3.hip
 extern "C" int otvm_conv2d_accepts_input_norm(const otvm_conv_params* p) {
-    return p && p->precision == OTVM_PREC_F16X3 && patch_choice(p) != 0 ? 1 : 0;
+    return p && p->precision == OTVM_PREC_F16X3 && (patch_choice(p) != 0 || otvm_conv2d_igemm_accepts_input_norm(p)) ? 1 : 0;
 }
 
 int otvm_conv2d_patch_eligible(const otvm_conv_params* p) { return patch_choice(p, true) != 0 ? 1 : 0; }

@@ -50,6 +50,9 @@ PRE_ON_S2 = os.environ.get("OTVM_PRE_ON_S2", "1") != "0"           # preprocess 
 # candidate.  Built and verified in round 3, measured 20-90 % SLOWER than the 4-wave LDS tiles on every small-map shape
 # (scattered 32-byte A loads: 32 cache lines per load instruction through a 64 B/clk L1): off by default, no weight copy.
 WAVE_TILE = os.environ.get("OTVM_WAVE_TILE", "0") != "0"
+# round 3: GroupNorm apply folded into the staging of implicit-GEMM convs too (bn2 -> conv3 of every FBA bottleneck); 0 = only
+# into the 3x3 patch kernel, as in round 2
+FUSE_GN_APPLY_IGEMM = os.environ.get("OTVM_FUSE_GN_APPLY_IGEMM", "1") != "0"
 # round 3: each 1/4-resolution bottleneck of the STM encoders (res2.0-2, planes 64) as ONE kernel, intermediates in LDS
 # (csrc/bottleneck_f16x3.hip); f16x3 only.  0 = the three (four) convolution launches of round 2
 FUSE_STM_BLOCK = os.environ.get("OTVM_FUSE_STM_BLOCK", "1") != "0"
@@ -1067,9 +1070,13 @@ class FramePlan:
         cp = self.conv(S, x, p + ".conv1", t1)
         t2 = self.buf("bt2", Ho, Wo, planes)
         cp = self.gn_then_conv(S, t1, p + ".bn1", RELU, cp, p + ".conv2", t2, stride=stride, pad=dil, dil=dil)
-        self.gn(S, t2, p + ".bn2", RELU, conv_p=cp)
         t3 = self.buf("bt3", Ho, Wo, planes * 4)
-        cp3 = self.conv(S, t2, p + ".conv3", t3)
+        if FUSE_GN_APPLY_IGEMM:
+            # round 3: bn2's apply pass is folded into conv3's staging (the implicit-GEMM kernels take in_scale / in_shift too)
+            cp3 = self.gn_then_conv(S, t2, p + ".bn2", RELU, cp, p + ".conv3", t3)
+        else:
+            self.gn(S, t2, p + ".bn2", RELU, conv_p=cp)
+            cp3 = self.conv(S, t2, p + ".conv3", t3)
         res_norm = None
         if has_ds:
             idt = self.buf("btd", Ho, Wo, planes * 4)

@@ -185,8 +185,8 @@ def test_conv_big_tile_fused_groupnorm_stats(G):
 
 @pytest.mark.parametrize("Cin,Cout,dil,H,W,act", [(64, 64, 1, 37, 70, 1), (64, 32, 1, 20, 33, 2), (256, 256, 2, 320, 320, 1)])
 def test_conv_fused_input_groupnorm(G, Cin, Cout, dil, H, W, act):
-    """GroupNorm apply of the producer folded into the patch conv's staging (otvm_conv_params.in_scale): equals
-    otvm_gn_apply followed by the plain conv, including the zero padding of the NORMALISED tensor at the border."""
+    """GroupNorm apply of the producer folded into the conv's staging (otvm_conv_params.in_scale; these shapes take the patch
+    kernel): equals otvm_gn_apply followed by the plain conv, including the zero padding of the NORMALISED tensor at the border."""
     from otvm_amd import lib as L
     lib = L.load()
     x = rnd(1, Cin, H, W, seed=80) * 1.7 + 0.3
@@ -217,11 +217,88 @@ def test_conv_fused_input_groupnorm(G, Cin, Cout, dil, H, W, act):
     out2 = G.empty_act(H, W, max(4, Cout))
     G.conv2d(xa2, cw, out2, bias_d, pad=dil, dil=dil, precision=1)
     assert torch.equal(G.from_act(out2, Cout), got)
-    # layers the patch kernel does not take reject the request loudly
+    # combinations no kernel implements are rejected loudly: with in_relu, or in exact fp32
     w1 = rnd(Cout, Cin, 1, 1, seed=85)
     cw1 = G.pack_weight(w1)
     with pytest.raises(RuntimeError):
-        G.conv2d(xa, cw1, out, None, precision=1, in_norm=(tab.data_ptr(), tab.data_ptr() + 4 * Cin, act))
+        G.conv2d(xa, cw1, out, None, precision=1, in_relu=1, in_norm=(tab.data_ptr(), tab.data_ptr() + 4 * Cin, act))
+    with pytest.raises(RuntimeError):
+        G.conv2d(xa, cw1, out, None, precision=0, in_norm=(tab.data_ptr(), tab.data_ptr() + 4 * Cin, act))
+
+
+IGEMM_NORM_CASES = [
+    # Cin, Cout, k, stride, dil, H, W, input act, residual, out act, fused statistics, tune code (0 = heuristic)
+    (64, 256, 1, 1, 1, 37, 70, 1, False, 0, True, 0),                  # bn2 -> conv3 of a layer-1 bottleneck (+ statistics of bn3)
+    (128, 512, 1, 1, 1, 20, 33, 1, False, 0, True, (1 + 1) * 16 + 1),  # 256x128 tile
+    (512, 2048, 1, 1, 1, 24, 40, 1, False, 0, False, (0 + 1) * 16 + 1),   # 256x256 tile
+    (128, 128, 3, 2, 1, 41, 57, 1, False, 0, True, 0),                 # 3x3 stride 2 (first block of a stage): zero padding of the NORMALISED tensor
+    (256, 256, 3, 1, 2, 24, 40, 2, True, 1, False, (2 + 1) * 16 + 1),  # dilated 3x3 on the implicit-GEMM path, LeakyReLU input, residual + ReLU
+    (1024, 256, 1, 1, 1, 17, 23, 1, False, 0, False, (3 + 1) * 16 + 4),   # 128x64 tile, K split over 4 workgroups
+    (256, 128, 1, 1, 1, 30, 34, 0, False, 0, False, (10 + 1) * 16 + 1),   # pipelined 64x64 tile, no input activation
+    (256, 256, 1, 1, 1, 33, 40, 1, False, 0, False, (8 + 1) * 16 + 1),    # 4-wave 128x256 tile
+]
+
+
+@pytest.mark.parametrize("case", IGEMM_NORM_CASES, ids=lambda c: "c%d_%d_k%d_s%d_d%d_t%d" % (c[0], c[1], c[2], c[3], c[4], c[11]))
+def test_conv_fused_input_groupnorm_implicit_gemm(G, case):
+    """The same fusion on the implicit-GEMM kernels (whole 32-channel chunks: every GroupNorm'd tensor): bit-identical to
+    otvm_gn_apply followed by the plain conv in the same configuration, batched launch == single launches."""
+    from otvm_amd import lib as L
+    from otvm_amd.engine import Act, conv_params
+    lib = L.load()
+    Cin, Cout, k, stride, dil, H, W, iact, use_res, act, gn, tune = case
+    pad = dil * (k - 1) // 2
+    B = 2
+    xs = [rnd(1, Cin, H, W, seed=90 + b) * 1.7 + 0.3 for b in range(B)]
+    w = rnd(Cout, Cin, k, k, seed=81, scale=1.0 / math.sqrt(Cin * k * k))
+    bias = rnd(Cout, seed=82).to(G.DEV)
+    gamma, beta = rnd(Cin, seed=83).abs() + 0.5, rnd(Cin, seed=84) * 0.2
+    g_d, b_d = gamma.to(G.DEV), beta.to(G.DEV)
+    cw = G.pack_weight(w)
+    Ho, Wo = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1, (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    xb = _batched_act(G, xs)
+    rs = [rnd(1, Cout, Ho, Wo, seed=60 + b) for b in range(B)]
+    rb = _batched_act(G, rs) if use_res else None
+    stats_in = torch.zeros(B * 64, dtype=torch.float64, device=G.DEV)
+    L.check(lib.otvm_gn_stats_b(xb.ptr, H * W, Cin, xb.ld, stats_in.data_ptr(), B, xb.bs, 64, G.stream()))
+    tab = torch.zeros(B * 2 * Cin, device=G.DEV)
+    L.check(lib.otvm_gn_table_b(stats_in.data_ptr(), H * W, Cin, g_d.data_ptr(), b_d.data_ptr(), tab.data_ptr(),
+                                tab.data_ptr() + 4 * Cin, B, 64, 2 * Cin, G.stream()))
+    ws = torch.empty(8 << 20, device=G.DEV)
+    ob = Act(torch.full((B * (Ho * Wo * Cout + 64) + 16,), float("nan"), device=G.DEV), Ho, Wo, Cout, Cout, 0, B=B, bs=Ho * Wo * Cout + 64)
+    st_b = torch.zeros(B * 128, dtype=torch.float64, device=G.DEV)
+    p = conv_params(xb, cw, ob, bias, stride, pad, dil, act, 0, rb, 1, (tab.data_ptr(), tab.data_ptr() + 4 * Cin, iact, 2 * Cin), ws)
+    p.tune = tune
+    if gn:
+        p.gn_stats, p.gn_bs = st_b.data_ptr(), 128
+    assert lib.otvm_conv2d_accepts_input_norm(C.byref(p)) == 1
+    L.check(lib.otvm_conv2d(C.byref(p), G.stream()), "conv with fused input normalisation")
+    torch.cuda.synchronize()
+    for b in range(B):
+        # two-pass route on image b: apply pass into a copy, then the plain conv in the same configuration
+        xa = G.to_act(xs[b])
+        L.check(lib.otvm_gn_apply(xa.ptr, H * W, Cin, xa.ld, stats_in.data_ptr() + 8 * 64 * b, g_d.data_ptr(), b_d.data_ptr(), 0, 0, 0, 0, 0,
+                                  iact, xa.ptr, xa.ld, G.stream()))
+        o1 = G.empty_act(Ho, Wo, Cout)
+        st1 = torch.zeros(64, dtype=torch.float64, device=G.DEV)
+        p1 = conv_params(xa, cw, o1, bias, stride, pad, dil, act, 0, None if rb is None else rb.img(b), 1, None, ws)
+        p1.tune = tune
+        if gn:
+            p1.gn_stats = st1.data_ptr()
+        L.check(lib.otvm_conv2d(C.byref(p1), G.stream()), "plain conv")
+        torch.cuda.synchronize()
+        assert torch.equal(ob.torch(b), o1.torch()), "image %d" % b
+        if gn:
+            got = st_b[b * 128:b * 128 + 64]
+            assert float((got - st1).abs().max()) <= 1e-9 * float(st1.abs().max())
+        xn = F.group_norm(xs[b], 32, gamma, beta, 1e-5)
+        xn = F.relu(xn) if iact == 1 else (F.leaky_relu(xn, 0.01) if iact == 2 else xn)
+        want = F.conv2d(xn, w, bias.cpu(), stride, pad, dil)
+        if use_res:
+            want = want + rs[b]
+        want = F.relu(want) if act == 1 else want
+        gotc = ob.torch(b).permute(2, 0, 1)[None].cpu()
+        assert float((gotc - want).abs().max()) <= 3e-5 * max(1.0, float(want.abs().max()))
 
 
 def test_f16x3_is_fp32_class(G):
