@@ -45,17 +45,30 @@ def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     deps = [os.path.join(HERE, "common.h"), os.path.join(os.path.dirname(PKG), "include", "otvm_hip.h"), __file__]
-    objs, relink = [], force
+    objs, relink, jobs = [], force, []
     for src, extra in SOURCES:
         s = os.path.join(HERE, src)
         o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _newer(s, o) or any(_newer(d, o) for d in deps):
-            cmd = [hipcc] + COMMON + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o]
-            if verbose:
-                print(" ".join(cmd))
-            subprocess.check_call(cmd)
+            jobs.append([hipcc] + COMMON + extra + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", s, "-o", o])
             relink = True
+    # the translation units are independent: compile them side by side (conv_f16x3.hip alone takes minutes), longest first
+    if jobs:
+        jobs.sort(key=lambda c: -os.path.getsize(c[-3]))
+        running, failed = [], []
+        limit = max(1, min(len(jobs), (os.cpu_count() or 2)))
+        while jobs or running:
+            while jobs and len(running) < limit:
+                cmd = jobs.pop(0)
+                if verbose:
+                    print(" ".join(cmd), flush=True)
+                running.append((cmd, subprocess.Popen(cmd)))
+            cmd, pr = running.pop(0)
+            if pr.wait() != 0:
+                failed.append(cmd)
+        if failed:
+            raise subprocess.CalledProcessError(1, failed[0])
     if relink or not os.path.exists(LIB):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
