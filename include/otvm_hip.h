@@ -35,7 +35,7 @@ extern "C" {
 #define OTVM_PREC_F16X3 1
 
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 15   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
+#define OTVM_ABI_VERSION 16   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
                                  4: otvm_conv_params.splitk_ws; 5: otvm_preprocess_params.fg_u8/bg_u8/u8_rgb;
                                  6: otvm_conv_params.tune + otvm_conv2d_candidates;
                                  7: folded GroupNorm tables on otvm_gn_apply's residual and otvm_upsample_bilinear's input;
@@ -46,7 +46,9 @@ const char* otvm_last_error(void);
                                  12: training forward (otvm_fba_head_train, otvm_upsample4_logits3, otvm_trimap_to_sm, otvm_loss_*);
                                  13: otvm_conv_params.w_wfrag + otvm_pack_wave_weight_f16x3 (one-wave 64x64 tile);
                                  14: otvm_ppm_conv_z / otvm_ppm_conv_add (the PPM branches' share of conv_up1.0 without upsampling);
-                                 15: otvm_stm_bottleneck_f16x3 (one kernel per 1/4-resolution bottleneck of the STM encoders) */
+                                 15: otvm_stm_bottleneck_f16x3 (one kernel per 1/4-resolution bottleneck of the STM encoders);
+                                 16: otvm_conv_params.gn_gamma ... gn_counter (the GroupNorm scale / shift table of the OUTPUT
+                                     written by the conv's last workgroup instead of a separate otvm_gn_table launch) */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -124,6 +126,16 @@ typedef struct {
     const void* w_wfrag;                            /* f16x3, optional (ABI 13): the split weights in MFMA B-fragment order for
                                                        the one-wave 64x64 tile (otvm_pack_wave_weight_f16x3); layers with
                                                        Cin % 32 == 0; NULL = that tile is never a candidate               */
+    /* ---- ABI 16, optional, with gn_stats: the per-channel table otvm_gn_table would compute from the finished statistics
+     * (scale[c] = rstd[g] gamma[c], shift[c] = beta[c] - mean[g] scale[c]; same arithmetic, same bits) is written by the
+     * LAST workgroup of the launch to finish (each workgroup takes a ticket from *gn_counter after its statistics are in;
+     * the counter re-arms itself to 0).  Consumers that normalise on the fly (in_scale / in_shift of the next conv, the
+     * resampling kernels) then need no launch in between.  gn_counter: one zero-initialised unsigned per image.  Paths
+     * that finish the statistics in a pass of their own (split K, exact fp32) launch the table kernel internally.      */
+    const float* gn_gamma; const float* gn_beta;    /* GroupNorm weight / bias, Cout floats                              */
+    float* gn_scale_out; float* gn_shift_out;       /* Cout floats each; image b's tables gn_tab_bs floats behind image 0 */
+    unsigned* gn_counter;
+    int gn_tab_bs;
 } otvm_conv_params;
 int otvm_conv2d(const otvm_conv_params* p, void* stream);
 /* The legal kernel configurations of a layer (f16x3): the patch kernel where the shape allows it, and the implicit-GEMM

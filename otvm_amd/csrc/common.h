@@ -40,6 +40,57 @@ __device__ __forceinline__ void otvm_static_for(F&& f) {
     otvm_static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+// ABI 16: the GroupNorm scale / shift table of a conv's OUTPUT, written by the last workgroup of the launch (see
+// otvm_conv_params.gn_counter).  Same arithmetic as gn_table_kernel (groupnorm.hip).
+struct OtvmGnTail {
+    const float* gamma; const float* beta; float* scale; float* shift; unsigned* counter; int tab_bs;   // scale == nullptr: none
+};
+static inline OtvmGnTail otvm_gn_tail_of(const otvm_conv_params* p) {
+    OtvmGnTail t;
+    t.gamma = p->gn_gamma; t.beta = p->gn_beta; t.scale = p->gn_stats ? p->gn_scale_out : nullptr; t.shift = p->gn_shift_out;
+    t.counter = p->gn_counter; t.tab_bs = p->batch > 1 ? p->gn_tab_bs : 0;
+    return t;
+}
+// Called by ALL threads of EVERY workgroup of the launch after the workgroup's atomicAdds into `stats` (image zb's block);
+// `total` = workgroups per image.  Contains __syncthreads.
+// `lds`: 65 floats of LDS nobody else uses any more (the 256x256 tile has no static LDS to spare).
+__device__ __forceinline__ void otvm_gn_table_tail(double* stats, int64_t P, int C, const OtvmGnTail& t, int zb, unsigned total,
+                                                   float* lds) {
+    if (!t.scale) return;                                  // (uniform)
+    float* tail_mean = lds;
+    float* tail_rstd = lds + 32;
+    volatile unsigned* tail_last = reinterpret_cast<volatile unsigned*>(lds + 64);
+    // this thread's statistics atomics have been acknowledged (they execute at device scope, past the XCD's L2) before the
+    // workgroup takes its ticket.  NOT __threadfence(): a device-scope release on this multi-XCD part writes the XCD's whole
+    // L2 back -- every workgroup of every conv did that and the frame rate fell from 42.7 to 35.2
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (threadIdx.x == 0) *tail_last = atomicAdd(t.counter + zb, 1u) == total - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!*tail_last) return;
+    const int cg = C / 32;
+    if (threadIdx.x < 32) {
+        const double cnt = (double)P * cg;
+        const double sum = atomicAdd(&stats[threadIdx.x * 2], 0.0), sq = atomicAdd(&stats[threadIdx.x * 2 + 1], 0.0);   // coherent reads
+        const double mean = sum / cnt;
+        double var = sq / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        tail_mean[threadIdx.x] = (float)mean;
+        tail_rstd[threadIdx.x] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+    float* scale = t.scale + (int64_t)zb * t.tab_bs;
+    float* shift = t.shift + (int64_t)zb * t.tab_bs;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cg;
+        const float a = tail_rstd[g] * t.gamma[c];
+        scale[c] = a;
+        shift[c] = t.beta[c] - tail_mean[g] * a;
+    }
+    if (threadIdx.x == 0) t.counter[zb] = 0;               // re-armed for the next launch
+}
+
 __device__ __forceinline__ float otvm_act(float v, int act) {
     if (act == OTVM_ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == OTVM_ACT_LEAKY) return v > 0.f ? v : 0.01f * v;

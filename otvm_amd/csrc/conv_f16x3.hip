@@ -79,6 +79,7 @@ struct Conv3Args {
     // x' = x * in_scale[c] + in_shift[c], then x' > 0 ? x' : x' * in_slope (1 = none, 0 = ReLU, 0.01 = LeakyReLU), zero in the
     // conv's padding; tables from otvm_gn_table, image b's table norm_bs floats behind image 0's
     const float* in_scale; const float* in_shift; float in_slope; int norm_bs;
+    OtvmGnTail tail;             // ABI 16: the output's GroupNorm table, written by the last workgroup (common.h)
 };
 
 constexpr int BK = 32;
@@ -613,6 +614,8 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
             const int g = n0 / cg + (i >> 1);
             if (g < 32 && gred[i] != 0.0) atomicAdd(&p.gn_stats[2 * g + (i & 1)], gred[i]);
         }
+        __syncthreads();                                    // gred is free again: scratch of the table tail
+        otvm_gn_table_tail(p.gn_stats, p.M, p.Cout, p.tail, blockIdx.z, gridDim.x * gridDim.y, reinterpret_cast<float*>(gred));
     }
 }
 
@@ -884,6 +887,8 @@ __global__ __launch_bounds__(64) void conv_wave_f16x3_kernel(const Conv3Args pa)
             const int g = n0 / cg + (i >> 1);
             if (g < 32 && gred[i] != 0.0) atomicAdd(&p.gn_stats[2 * g + (i & 1)], gred[i]);
         }
+        __syncthreads();
+        otvm_gn_table_tail(p.gn_stats, p.M, p.Cout, p.tail, blockIdx.z, gridDim.x * gridDim.y, reinterpret_cast<float*>(gred));
     }
 }
 
@@ -1110,7 +1115,7 @@ static int run_config(const otvm_conv_params* p, Conv3Args& a, int tile, int S, 
     const int ldp = (p->Cout + 3) & ~3;
     Conv3Args b = a;
     b.out = (float*)p->splitk_ws; b.out_ld = ldp; b.split_stride = M * ldp; b.out_bs = (int64_t)S * M * ldp;
-    b.bias = nullptr; b.residual = nullptr; b.act = OTVM_ACT_NONE; b.gn_stats = nullptr;
+    b.bias = nullptr; b.residual = nullptr; b.act = OTVM_ACT_NONE; b.gn_stats = nullptr; b.tail.scale = nullptr;
     const int rc = launch_tile(tile, b, s, S);
     if (rc) return rc;
     int64_t blocks = (M * (ldp / 4) + 255) / 256;
@@ -1119,8 +1124,13 @@ static int run_config(const otvm_conv_params* p, Conv3Args& a, int tile, int S, 
                        (int64_t)M * ldp, M, p->Cout, ldp, p->bias, p->residual, p->res_ld, p->act, p->out,
                        p->out_ld, a.out_bs, a.res_bs);
     OTVM_CHECK_LAUNCH("otvm_conv2d(split-K finish)");
-    if (p->gn_stats)
-        return otvm_gn_stats_b(p->out, M, p->Cout, p->out_ld, p->gn_stats, g_batch, a.out_bs, a.gn_bs, (void*)s);
+    if (p->gn_stats) {
+        const int rc2 = otvm_gn_stats_b(p->out, M, p->Cout, p->out_ld, p->gn_stats, g_batch, a.out_bs, a.gn_bs, (void*)s);
+        if (rc2 || !a.tail.scale) return rc2;
+        // the statistics were finished by a pass of their own: the table is one more (tiny) launch here, not the caller's
+        return otvm_gn_table_b(p->gn_stats, M, p->Cout, p->gn_gamma, p->gn_beta, p->gn_scale_out, p->gn_shift_out, g_batch,
+                               a.gn_bs, a.tail.tab_bs, (void*)s);
+    }
     return 0;
 }
 
@@ -1189,6 +1199,7 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     a.M = p->Ho * p->Wo; a.taps = p->kh * p->kw; a.nchunks = p->K_pad / 32;
     a.split_stride = 0;
     a.wf = (const _Float16*)p->w_wfrag;
+    a.tail = otvm_gn_tail_of(p);
     a.in_scale = p->in_scale; a.in_shift = p->in_shift;
     a.in_slope = p->in_act == OTVM_ACT_RELU ? 0.f : (p->in_act == OTVM_ACT_LEAKY ? 0.01f : 1.f);
     a.norm_bs = p->batch > 1 ? p->norm_bs : 0;

@@ -324,7 +324,18 @@ extern "C" int otvm_conv2d(const otvm_conv_params* p, void* stream) {
     OTVM_REQUIRE(!p->in_scale == !p->in_shift, "otvm_conv2d: in_scale and in_shift go together");
     OTVM_REQUIRE(!p->in_scale || otvm_conv2d_accepts_input_norm(p),
                  "otvm_conv2d: fused input normalisation requested for a layer otvm_conv2d_accepts_input_norm() rejects");
+    OTVM_REQUIRE(!p->gn_scale_out || (p->gn_stats && p->gn_shift_out && p->gn_gamma && p->gn_beta && p->gn_counter),
+                 "otvm_conv2d: gn_scale_out needs gn_stats, gn_shift_out, gn_gamma, gn_beta and gn_counter");
     if (p->precision == OTVM_PREC_F16X3) return otvm_conv2d_f16x3_impl(p, stream);
+    if (p->gn_scale_out) {            // exact fp32: the kernels below leave the table to one more launch
+        otvm_conv_params q = *p;
+        q.gn_scale_out = nullptr;
+        const int rc = otvm_conv2d(&q, stream);
+        if (rc) return rc;
+        const int nb = p->batch > 1 ? p->batch : 1;
+        return otvm_gn_table_b(p->gn_stats, (int64_t)p->Ho * p->Wo, p->Cout, p->gn_gamma, p->gn_beta, p->gn_scale_out, p->gn_shift_out,
+                               nb, nb > 1 ? p->gn_bs : 0, nb > 1 ? p->gn_tab_bs : 0, stream);
+    }
     ConvArgs a;
     a.in = p->in; a.w = p->w; a.bias = p->bias; a.residual = p->residual; a.out = p->out; a.gn_stats = p->gn_stats;
     a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.in_ld = p->in_ld; a.K_pad = p->K_pad; a.res_ld = p->res_ld;

@@ -53,6 +53,7 @@ struct PatchArgs {
     const float* in_scale; const float* in_shift; int in_act;
     // batch: image blockIdx.y of every tensor lives *_bs elements behind image 0
     int64_t in_bs, out_bs, res_bs; int gn_bs, norm_bs, batch;
+    OtvmGnTail tail;             // ABI 16: the output's GroupNorm table, written by the last workgroup (common.h)
 };
 
 constexpr int CB = 16;           // channels per stage = one MFMA k-step
@@ -451,6 +452,8 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
             const int g = n0 / cg + (i >> 1);
             if (g < 32 && gred[i] != 0.0) atomicAdd(&p.gn_stats[2 * g + (i & 1)], gred[i]);
         }
+        __syncthreads();
+        otvm_gn_table_tail(p.gn_stats, (int64_t)p.H * p.W, p.Cout, p.tail, blockIdx.y, gridDim.x, reinterpret_cast<float*>(gred));
     }
 }
 
@@ -559,6 +562,7 @@ static int patch_run(const otvm_conv_params* p, void* stream, int choice) {
     a.n_pad32 = (p->Cout + 31) / 32 * 32; a.in_relu = p->in_relu; a.act = p->act;
     hipStream_t s = (hipStream_t)stream;
     a.in_scale = p->in_scale; a.in_shift = p->in_shift; a.in_act = p->in_act;
+    a.tail = otvm_gn_tail_of(p);
     a.batch = p->batch > 1 ? p->batch : 1;
     a.in_bs = a.batch > 1 ? p->in_bs : 0; a.out_bs = a.batch > 1 ? p->out_bs : 0; a.res_bs = a.batch > 1 ? p->res_bs : 0;
     a.gn_bs = a.batch > 1 ? p->gn_bs : 0; a.norm_bs = a.batch > 1 ? p->norm_bs : 0;

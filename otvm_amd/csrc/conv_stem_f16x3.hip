@@ -29,6 +29,7 @@ struct StemArgs {
     int H, W, Cin, in_ld, Ho, Wo, Cout, out_ld, act, groups;
     int tiles_x, tiles_y;
     int64_t in_bs, out_bs; int gn_bs;     // batch: image blockIdx.y lives *_bs elements behind image 0
+    OtvmGnTail tail;                      // ABI 16: the output's GroupNorm table, written by the last workgroup (common.h)
 };
 
 constexpr int TH = 8, TW = 32, NW = 4, NT = NW * 64;
@@ -297,6 +298,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const int g = i >> 1;
             if (g < 32 && gred[i] != 0.0) atomicAdd(&p.gn_stats[2 * g + (i & 1)], gred[i]);
         }
+        __syncthreads();
+        otvm_gn_table_tail(p.gn_stats, (int64_t)p.Ho * p.Wo, p.Cout, p.tail, blockIdx.y, gridDim.x, reinterpret_cast<float*>(gred));
     }
 }
 
@@ -361,6 +364,7 @@ int otvm_conv2d_stem_f16x3(const otvm_conv_params* p, void* stream) {
     StemArgs a;
     a.in = p->in; a.wf = (const _Float16*)p->w_frag; a.wscale = p->w_scale; a.bias = p->bias; a.out = p->out;
     a.gn_stats = p->gn_stats;
+    a.tail = otvm_gn_tail_of(p);
     a.H = p->H; a.W = p->W; a.Cin = p->Cin; a.in_ld = p->in_ld; a.Ho = p->Ho; a.Wo = p->Wo; a.Cout = p->Cout;
     a.out_ld = p->out_ld; a.act = p->act; a.groups = (p->Cin + 7) / 8;
     a.tiles_x = otvm_ceil_div(p->Wo, TW);

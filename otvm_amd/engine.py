@@ -53,6 +53,9 @@ WAVE_TILE = os.environ.get("OTVM_WAVE_TILE", "0") != "0"
 # round 3: GroupNorm apply folded into the staging of implicit-GEMM convs too (bn2 -> conv3 of every FBA bottleneck); 0 = only
 # into the 3x3 patch kernel, as in round 2
 FUSE_GN_APPLY_IGEMM = os.environ.get("OTVM_FUSE_GN_APPLY_IGEMM", "1") != "0"
+# round 3 (ABI 16): the GroupNorm scale / shift table of a conv's output is written by that conv's last workgroup; 0 = one
+# otvm_gn_table launch per table (42 per frame)
+FUSE_GN_TABLE = os.environ.get("OTVM_FUSE_GN_TABLE", "1") != "0"
 # round 3: each 1/4-resolution bottleneck of the STM encoders (res2.0-2, planes 64) as ONE kernel, intermediates in LDS
 # (csrc/bottleneck_f16x3.hip); f16x3 only.  0 = the three (four) convolution launches of round 2
 FUSE_STM_BLOCK = os.environ.get("OTVM_FUSE_STM_BLOCK", "1") != "0"
@@ -1001,8 +1004,15 @@ class FramePlan:
         self.n_gn += 1
         self._fused_stats.append((producer_p, idx))
         tab = self.raw("gntab_" + gn_name, 2 * x.C * self.B)             # [B][scale C | shift C]
-        S.append(("gn_table", (x.P, x.C, sd[gn_name + ".weight"].data_ptr(), sd[gn_name + ".bias"].data_ptr(),
-                               tab.data_ptr(), tab.data_ptr() + 4 * x.C), idx, 2 * x.C, "gn_table " + gn_name))
+        if FUSE_GN_TABLE and isinstance(producer_p, L.ConvParams):
+            # round 3 (ABI 16): the producing conv's last workgroup writes the table -- no launch between producer and consumer
+            cnt = self.raw("gncnt_" + gn_name, self.B, torch.int32)
+            producer_p.gn_gamma, producer_p.gn_beta = sd[gn_name + ".weight"].data_ptr(), sd[gn_name + ".bias"].data_ptr()
+            producer_p.gn_scale_out, producer_p.gn_shift_out = tab.data_ptr(), tab.data_ptr() + 4 * x.C
+            producer_p.gn_counter, producer_p.gn_tab_bs = cnt.data_ptr(), 2 * x.C
+        else:
+            S.append(("gn_table", (x.P, x.C, sd[gn_name + ".weight"].data_ptr(), sd[gn_name + ".bias"].data_ptr(),
+                                   tab.data_ptr(), tab.data_ptr() + 4 * x.C), idx, 2 * x.C, "gn_table " + gn_name))
         return tab.data_ptr(), tab.data_ptr() + 4 * x.C, 2 * x.C
 
     def gn_then_conv(self, S, x, gn_name, gn_act, producer_p, wname, out, **kw):

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3 = 0, 1
-ABI_VERSION = 15         # include/otvm_hip.h OTVM_ABI_VERSION
+ABI_VERSION = 16         # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -28,7 +28,8 @@ class ConvParams(C.Structure):
                 ("tune", i32),
                 ("splitk_ws", vp), ("splitk_ws_bytes", i64),
                 ("batch", i32), ("in_bs", i64), ("out_bs", i64), ("res_bs", i64), ("gn_bs", i32), ("norm_bs", i32),
-                ("w_wfrag", vp)]
+                ("w_wfrag", vp),
+                ("gn_gamma", vp), ("gn_beta", vp), ("gn_scale_out", vp), ("gn_shift_out", vp), ("gn_counter", vp), ("gn_tab_bs", i32)]
 
 
 class StmBottleneckParams(C.Structure):

@@ -1075,3 +1075,68 @@ def test_stm_bottleneck_fused_kernel(G, Cin, H, W):
         assert torch.equal(o1.torch(), ob.torch(b))
     q.Cin = 128
     assert lib.otvm_stm_bottleneck_f16x3(C.byref(q), G.stream()) != 0          # loud refusal, no fallback
+
+
+# ---------------------------------------------------------------------------------------------- table by the last workgroup (ABI 16)
+TAIL_CASES = [
+    # Cin, Cout, k, stride, H, W, tune code (0 = heuristic)
+    (64, 256, 1, 1, 37, 70, 0),                       # implicit GEMM, many tiles
+    (256, 64, 1, 1, 40, 56, 0),                       # Cout = 64: two channels per group
+    (64, 64, 3, 1, 40, 56, 0),                        # patch kernel
+    (24, 64, 7, 2, 64, 96, 0),                        # stem kernel
+    (1024, 128, 1, 1, 12, 16, (3 + 1) * 16 + 4),      # K split over 4 workgroups: statistics pass + internal table launch
+    (256, 256, 3, 1, 16, 24, (9 + 1) * 16 + 1),       # one-wave tile
+    (512, 128, 1, 1, 17, 23, (11 + 1) * 16 + 1),      # pipelined 128x64 tile
+    (128, 2048, 1, 1, 33, 31, (0 + 1) * 16 + 1),      # 256x256 tile (no static LDS to spare): 64 channels per group
+]
+
+
+@pytest.mark.parametrize("case", TAIL_CASES, ids=lambda c: "c%d_%d_k%d_s%d_t%d" % (c[0], c[1], c[2], c[3], c[6]))
+def test_conv_writes_groupnorm_table_of_its_output(G, case):
+    """otvm_conv_params.gn_scale_out: the last workgroup of the conv writes the scale / shift table otvm_gn_table would
+    compute from the finished statistics -- same bits, per image, and the ticket counter re-arms itself (second launch)."""
+    from otvm_amd import lib as L
+    from otvm_amd.engine import Act, conv_params
+    lib = L.load()
+    Cin, Cout, k, stride, H, W, tune = case
+    pad = 3 if k == 7 else (k - 1) // 2
+    B = 2
+    xs = [rnd(1, Cin, H, W, seed=110 + b) for b in range(B)]
+    w = rnd(Cout, Cin, k, k, seed=5, scale=1.0 / math.sqrt(Cin * k * k))
+    cw = G.pack_weight(w, i_pad=24 if Cin == 24 else None)
+    bias = rnd(Cout, seed=6).to(G.DEV)
+    gamma, beta = (rnd(Cout, seed=7).abs() + 0.5).to(G.DEV), (rnd(Cout, seed=8) * 0.2).to(G.DEV)
+    Ho, Wo = (H + 2 * pad - (k - 1) - 1) // stride + 1, (W + 2 * pad - (k - 1) - 1) // stride + 1
+    xb = _batched_act(G, xs, cw.I_pad)
+    ob = Act(torch.zeros(B * (Ho * Wo * Cout + 64) + 16, device=G.DEV), Ho, Wo, Cout, Cout, 0, B=B, bs=Ho * Wo * Cout + 64)
+    ws = torch.empty(8 << 20, device=G.DEV)
+    counter = torch.zeros(B, dtype=torch.int32, device=G.DEV)
+    for rep in range(2):
+        stats = torch.zeros(B * 128, dtype=torch.float64, device=G.DEV)
+        tab = torch.full((B * (2 * Cout + 8),), float("nan"), device=G.DEV)
+        p = conv_params(xb, cw, ob, bias, stride, pad, 1, 0, 0, None, 1, None, ws)
+        p.tune = tune
+        p.gn_stats, p.gn_bs = stats.data_ptr(), 128
+        p.gn_gamma, p.gn_beta = gamma.data_ptr(), beta.data_ptr()
+        p.gn_scale_out, p.gn_shift_out = tab.data_ptr(), tab.data_ptr() + 4 * Cout
+        p.gn_counter, p.gn_tab_bs = counter.data_ptr(), 2 * Cout + 8
+        L.check(lib.otvm_conv2d(C.byref(p), G.stream()), "conv with table")
+        torch.cuda.synchronize()
+        want = torch.full_like(tab, float("nan"))
+        L.check(lib.otvm_gn_table_b(stats.data_ptr(), Ho * Wo, Cout, gamma.data_ptr(), beta.data_ptr(), want.data_ptr(),
+                                    want.data_ptr() + 4 * Cout, B, 128, 2 * Cout + 8, G.stream()))
+        torch.cuda.synchronize()
+        for b in range(B):
+            o = b * (2 * Cout + 8)
+            assert torch.equal(tab[o:o + 2 * Cout], want[o:o + 2 * Cout]), "image %d, launch %d" % (b, rep)
+            assert torch.isfinite(tab[o:o + 2 * Cout]).all()
+        assert int(counter.abs().sum()) == 0                                   # re-armed
+    # the statistics it was computed from are the conv output's: table == GroupNorm of the output (image 1)
+    y = F.conv2d(xs[1], w, bias.cpu(), stride, pad)
+    var, mean = torch.var_mean(y.double().reshape(32, -1), dim=1, unbiased=False)
+    rstd = (1.0 / torch.sqrt(var + 1e-5)).float().repeat_interleave(Cout // 32)
+    o = 2 * Cout + 8
+    assert float((tab[o:o + Cout].cpu() - rstd * gamma.cpu()).abs().max()) <= 2e-4 * float((rstd * gamma.cpu()).abs().max())
+    # gn_scale_out without the statistics is refused
+    p.gn_stats = 0
+    assert lib.otvm_conv2d(C.byref(p), G.stream()) != 0
