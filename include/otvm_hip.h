@@ -148,6 +148,9 @@ int otvm_conv2d_candidates(const otvm_conv_params* p, int* out, int max_n);
  * kernel, or (round 3) any implicit-GEMM tile on a layer with Cin % 32 == 0 and no in_relu -- else 0: the caller then applies
  * otvm_gn_apply as a separate pass.  Bit-identical to that two-pass route in the same configuration.                       */
 int otvm_conv2d_accepts_input_norm(const otvm_conv_params* p);
+/* 0 = no kernel takes it, 1 = the patch kernel would run this layer, 2 = an implicit-GEMM tile (which normalises every input
+ * element once per tap: worth it for 1x1 layers, not for 3x3 layers with many channels -- the host's choice).  (ABI 16) */
+int otvm_conv2d_input_norm_kind(const otvm_conv_params* p);
 
 /* f16x3: derive the split weights from a packed fp32 weight (see otvm_pack_conv_weight):
  * row o is scaled by 2^-e (|w| <= 1), w_hi = fp16(w), w_lo = fp16(w - w_hi), w_scale[o] = 2^e.

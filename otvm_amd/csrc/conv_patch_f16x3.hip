@@ -542,6 +542,14 @@ int otvm_conv2d_igemm_accepts_input_norm(const otvm_conv_params* p);       // co
 extern "C" int otvm_conv2d_accepts_input_norm(const otvm_conv_params* p) {
     return p && p->precision == OTVM_PREC_F16X3 && (patch_choice(p) != 0 || otvm_conv2d_igemm_accepts_input_norm(p)) ? 1 : 0;
 }
+// which kernel family would take it: 0 none, 1 the patch kernel (the heuristic's choice for this layer), 2 an implicit-GEMM tile.
+// A host may prefer a separate apply pass over 2 for a KxK layer: the implicit GEMM stages (and normalises) every input
+// element once per tap -- on the 3x3 512-channel layers that cost 40 us per launch against 20 for the pass it replaced.
+extern "C" int otvm_conv2d_input_norm_kind(const otvm_conv_params* p) {
+    if (!p || p->precision != OTVM_PREC_F16X3) return 0;
+    if (patch_choice(p) != 0) return 1;
+    return otvm_conv2d_igemm_accepts_input_norm(p) ? 2 : 0;
+}
 
 int otvm_conv2d_patch_eligible(const otvm_conv_params* p) { return patch_choice(p, true) != 0 ? 1 : 0; }
 

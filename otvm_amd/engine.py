@@ -53,6 +53,7 @@ WAVE_TILE = os.environ.get("OTVM_WAVE_TILE", "0") != "0"
 # round 3: GroupNorm apply folded into the staging of implicit-GEMM convs too (bn2 -> conv3 of every FBA bottleneck); 0 = only
 # into the 3x3 patch kernel, as in round 2
 FUSE_GN_APPLY_IGEMM = os.environ.get("OTVM_FUSE_GN_APPLY_IGEMM", "1") != "0"
+FUSE_GN_APPLY_IGEMM_KXK = os.environ.get("OTVM_FUSE_GN_APPLY_IGEMM_KXK", "0") != "0"   # also into 3x3 implicit-GEMM layers (measured: a loss)
 # round 3 (ABI 16): the GroupNorm scale / shift table of a conv's output is written by that conv's last workgroup; 0 = one
 # otvm_gn_table launch per table (42 per frame)
 FUSE_GN_TABLE = os.environ.get("OTVM_FUSE_GN_TABLE", "1") != "0"
@@ -1024,7 +1025,11 @@ class FramePlan:
         if FUSE_GN_APPLY and FUSE_GN_STATS and producer_p is not None:
             probe = conv_params(x, w, out, w.bias, kw.get("stride", 1), kw.get("pad", 0), kw.get("dil", 1), kw.get("act", NONE),
                                 0, kw.get("residual"), self.e.precision, (1, 1, gn_act))
-            if self.lib.otvm_conv2d_accepts_input_norm(C.byref(probe)):
+            kind = self.lib.otvm_conv2d_input_norm_kind(C.byref(probe))
+            # the implicit-GEMM tiles normalise every input element once per TAP: a win for 1x1 layers (bn2 -> conv3), a loss
+            # on the 3x3 layers the patch kernel does not take (layer 3 / 4 of the FBA encoder: 0.145 vs 0.126 ms and 0.434 vs
+            # 0.394 ms per launch against a 13-20 us apply pass) -- those keep their pass
+            if kind == 1 or (kind == 2 and (w.kh * w.kw == 1 or FUSE_GN_APPLY_IGEMM_KXK)):
                 sc, sh, nbs = self.gn_table_step(S, x, gn_name, producer_p)
                 return self.conv(S, x, wname, out, in_norm=(sc, sh, gn_act, nbs), **kw)
         self.gn(S, x, gn_name, gn_act, conv_p=producer_p)

@@ -77,6 +77,7 @@ _PROTOS = {
     "otvm_gn_stats": (i32, [vp, i64, i32, i32, vp, vp]),
     "otvm_gn_table": (i32, [vp, i64, i32, vp, vp, vp, vp, vp]),
     "otvm_conv2d_accepts_input_norm": (i32, [C.POINTER(ConvParams)]),
+    "otvm_conv2d_input_norm_kind": (i32, [C.POINTER(ConvParams)]),
     "otvm_conv2d_candidates": (i32, [C.POINTER(ConvParams), C.POINTER(i32), i32]),
     "otvm_gn_apply": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, i32, vp]),
     "otvm_maxpool3x3s2": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
