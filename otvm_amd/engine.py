@@ -35,7 +35,8 @@ FUSE_GN_APPLY = os.environ.get("OTVM_FUSE_GN_APPLY", "1") != "0"
 # host's issue time (6-7 ms) is of the order of the device time (padded frame below 2^20 pixels: 480p runs 7 ms frames).
 _GRAPHS_ENV = os.environ.get("OTVM_GRAPHS")
 USE_GRAPHS = None if _GRAPHS_ENV in (None, "", "auto") else (_GRAPHS_ENV != "0")
-GRAPH_AUTO_PIXELS = 1 << 20
+# (end of round 3: 1080p too -- 43.78 vs 43.60 frames/s, host issue time 20.6 -> 3.4 ms per frame; 4K frames take > 100 ms, direct launches)
+GRAPH_AUTO_PIXELS = 1 << 22
 
 
 def graphs_wanted(setting, padded_pixels):

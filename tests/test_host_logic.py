@@ -385,9 +385,10 @@ def test_rank_affinity_and_graph_policy(monkeypatch):
     assert D.pin_rank_affinity(0, 1, cpus) is None                   # single rank: untouched
     assert D.pin_rank_affinity(3, 64, cpus) is None                  # fewer cores than ranks: untouched
     monkeypatch.delenv("WORLD_SIZE", raising=False)
-    assert engine.graphs_wanted(None, 1088 * 1920) is False and engine.graphs_wanted(None, 480 * 832) is True
+    assert engine.graphs_wanted(None, 2176 * 3840) is False and engine.graphs_wanted(None, 1088 * 1920) is True
+    assert engine.graphs_wanted(None, 480 * 832) is True
     monkeypatch.setenv("WORLD_SIZE", "8")
-    assert engine.graphs_wanted(None, 1088 * 1920) is True
+    assert engine.graphs_wanted(None, 2176 * 3840) is True
     assert engine.graphs_wanted(False, 480 * 832) is False and engine.graphs_wanted(True, 1088 * 1920) is True
     monkeypatch.delenv("OTVM_DIST_BACKEND", raising=False)
     assert D.dist_backend() == "nccl" and D.reduce_device("cuda:3") == "cuda:3"
