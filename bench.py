@@ -131,12 +131,12 @@ def main():
     T = Wm + K                                              # frames of the clip: warm-up then timed
     from otvm_amd.synth_data import disc_trimap
     model, sd = build_model(dev, precision=args.precision)
-    if dist is not None and world > 1:
+    if dist is not None:
         # every rank launches rank 0's kernel configurations (identical fp32 summation orders on all ranks): rank 0 builds
         # and times its plan first, the others adopt its choices before building theirs
         from otvm_amd.engine import share_tune_cache
         if rank == 0:
-            model._get_engine().plan(H, W)
+            model._get_engine().plan(H, W, max(1, args.batch))     # (the tuner's signature carries the batch size)
             torch.cuda.synchronize(dev)
         share_tune_cache(0)
     NB = max(1, args.batch)
@@ -237,6 +237,9 @@ def main():
                    "batch": NB,
                    "T_read_timed_frames": {"mean": sum(timed_T) / float(K), "histogram": hist}},
         "ranks_seen": ranks_seen,
+        # the collectives of this run (rank count, max time, per-rank gather, tune-cache broadcast) ran on this backend;
+        # "nccl" = RCCL; None = plain process, no process group
+        "dist_backend": None if dist is None else dist.get_backend(),
         # wall time the host spends inside model() per step: issue time when the launch lists are replayed as graphs; with
         # direct launches the HIP queue fills up and the host blocks in launches, so this approaches ms_per_step
         "host_issue_ms_per_frame": 1000.0 * host_issue_s / K,

@@ -483,16 +483,14 @@ extern "C" int otvm_stm_bottleneck_f16x3(const otvm_stm_bottleneck_params* q, vo
     a.tiles_x = otvm_ceil_div(q->W, TW); a.tiles_y = otvm_ceil_div(q->H, TH);
     const int batch = q->batch > 1 ? q->batch : 1;
     a.x_bs = batch > 1 ? q->x_bs : 0; a.y_bs = batch > 1 ? q->y_bs : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)stm_bottleneck_f16x3_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void*)stm_bottleneck_f16x3_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    {
+        static std::atomic<bool> done256[OTVM_MAX_DEVICES], done64[OTVM_MAX_DEVICES];
+        hipError_t e = otvm_reserve_lds_once(done256, stm_bottleneck_f16x3_kernel<256>, LDS_BYTES);
+        if (e == hipSuccess) e = otvm_reserve_lds_once(done64, stm_bottleneck_f16x3_kernel<64>, LDS_BYTES);
         if (e != hipSuccess) {
             otvm_set_error("otvm_stm_bottleneck_f16x3: cannot reserve %d bytes of LDS: %s", LDS_BYTES, hipGetErrorString(e));
             return 2;
         }
-        attr_set = true;
     }
     const dim3 grid(a.tiles_x * a.tiles_y, batch), block(256);
     if (q->Cin == 256) hipLaunchKernelGGL(stm_bottleneck_f16x3_kernel<256>, grid, block, LDS_BYTES, (hipStream_t)stream, a);

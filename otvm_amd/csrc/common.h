@@ -28,6 +28,22 @@ void otvm_set_error(const char* fmt, ...);
 
 static inline int otvm_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: done once per (kernel, device), not once per
+// process (a process driving engines on several GPUs).  `done`: one zero-initialised flag array per kernel.
+#include <atomic>
+constexpr int OTVM_MAX_DEVICES = 64;
+template <class K>
+static inline hipError_t otvm_reserve_lds_once(std::atomic<bool> (&done)[OTVM_MAX_DEVICES], K kernel, int bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const bool track = dev >= 0 && dev < OTVM_MAX_DEVICES;
+    if (track && done[dev].load(std::memory_order_acquire)) return hipSuccess;
+    e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e == hipSuccess && track) done[dev].store(true, std::memory_order_release);
+    return e;
+}
+
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}).  `#pragma unroll` is a
 // request the unroller may decline for a large body; an accumulator array indexed by a loop that stayed rolled lives in
 // scratch memory (found on the 4x4-tile kernel: 1 KB of scratch, 10x slower)
@@ -88,7 +104,8 @@ __device__ __forceinline__ void otvm_gn_table_tail(double* stats, int64_t P, int
         scale[c] = a;
         shift[c] = t.beta[c] - tail_mean[g] * a;
     }
-    if (threadIdx.x == 0) t.counter[zb] = 0;               // re-armed for the next launch
+    // re-armed for the next launch (an atomic store: the counter is only ever touched by device-scope atomics)
+    if (threadIdx.x == 0) __hip_atomic_store(t.counter + zb, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 __device__ __forceinline__ float otvm_act(float v, int act) {

@@ -112,13 +112,41 @@ def batch_groups(indices, keys, lengths, batch):
     order = sorted(indices, key=lambda i: (str(keys[i]), -lengths[i], i))
     groups, cur = [], []
     for i in order:
-        if cur and (keys[i] != keys[cur[0]] or len(cur) == batch):
+        # (a sequence without a key -- no frames, resolution unknown -- never shares a batch)
+        if cur and (keys[i] is None or keys[i] != keys[cur[0]] or len(cur) == batch):
             groups.append(cur)
             cur = []
         cur.append(i)
     if cur:
         groups.append(cur)
     return groups
+
+
+def planned_batch_shapes(lengths, keys, world, batch):
+    """Every (key, group size) that batch_groups produces on ANY rank of a ``world``-rank run: the plans rank 0 has to build
+    (and time) before engine.share_tune_cache, so that all ranks launch identical configurations for every batched plan --
+    the tuner's signature carries the batch size."""
+    shapes = set()
+    n = len(lengths)
+    for r in range(world):
+        mine = shard_sequences(n, r, world, lengths)
+        if batch > 1:
+            for grp in batch_groups(mine, {i: keys[i] for i in mine}, lengths, batch):
+                shapes.add((keys[grp[0]], len(grp)))
+        else:
+            shapes.update((keys[i], 1) for i in mine)
+    return shapes
+
+
+def default_batch(padded_pixels):
+    """Sequences per lock-step launch when the caller does not say (`eval_cli --batch 0`): a throughput run (configs[3]: six
+    sequences per GPU) steps 2 clips at 1080p (+5 % aggregate) and 4 at <= 480p (+41 %: the small maps of one 480p frame
+    cannot fill 256 CUs); 4K frames fill the chip alone."""
+    if padded_pixels <= 640 * 1024:
+        return 4
+    if padded_pixels <= (1 << 22):
+        return 2
+    return 1
 
 
 def run_sharded(sequences, matte_fn, rank=0, world=1, device="cpu", reference_fn=None, batch=1, matte_batch_fn=None, key_fn=None):

@@ -133,8 +133,8 @@ def share_tune_cache(src=0):
     on the rank that matted it.  Call it after ``src`` has built the plans of the resolutions in play (bench.py, eval_cli)
     and before the other ranks build theirs.  No-op without a process group."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return
+    if not (dist.is_available() and dist.is_initialized()):
+        return                                               # (a one-rank group still broadcasts: the RCCL path is exercised)
     obj = [dict(_TUNE_CACHE) if dist.get_rank() == src else None]
     dist.broadcast_object_list(obj, src=src)
     if dist.get_rank() != src:

@@ -159,7 +159,10 @@ def run_video_matte_batch(model, clips, trimaps=None, alphas=None, backgrounds=N
     Clips may differ in LENGTH: the batch runs max(T_b) steps, a clip that has ended keeps feeding its last frame (its
     outputs from then on are discarded) -- sequences are independent (all recurrent state is per sequence), so
     this changes no result of the others; the frame flags follow the frame index, which the clips share.
-    Each returned dict equals run_video_matte of that clip alone (bit for bit under the same kernel configurations).
+    Each returned dict's alpha / alpha_u8 / trimap / metrics equal run_video_matte of that clip alone (bit for bit under the
+    same kernel configurations).  bank_frames follows the SHARED schedule: ``last_frame`` is keyed to the longest clip, so a
+    shorter clip's final entry still lists the frame whose memorize is pending -- the stand-alone run, whose last frame
+    memorises nothing, does not (the one documented difference).
     Returns a list of B dicts (alpha, alpha_u8, trimap, bank_frames[, metrics])."""
     B = len(clips)
     lens = [len(c) for c in clips]
@@ -181,6 +184,13 @@ def run_video_matte_batch(model, clips, trimaps=None, alphas=None, backgrounds=N
             if f.dtype == torch.uint8 and (bk is None or bk.dtype == torch.uint8):
                 fg = f.to(dev, non_blocking=True)
                 bg = fg if bk is None else bk.to(dev, non_blocking=True)
+                # frames handed over by the IO pipeline's prefetcher carry their upload event: the launch stream waits for
+                # it before anything reads them (as run_video_matte does; the batched step makes no promise to the engine
+                # about its inputs, so its side streams order themselves behind the launch stream)
+                for src in (f, bk):
+                    ev = getattr(src, "_otvm_ready", None) if src is not None else None
+                    if ev is not None:
+                        torch.cuda.current_stream(dev).wait_event(ev)
                 H, W = fg.shape[:2]
                 rgb = bool(frames_are_rgb)
             else:

@@ -192,8 +192,34 @@ def op_fixtures():
     return out
 
 
+# BASELINE configs[1] geometry (832x480, no padding), produced by the reference itself: pins the oracle -- and through it the
+# HIP path -- at a size where the split-K route and the small-map tiles carry most layers.  skip=3 / max=3 so that frames 2
+# and 3 read two memory slots (frame 3 after a replace-last).  ~4 s per frame on 8 threads.
+FULLSIZE = ("c480_832x480_s3m3", 480, 832, 4, "demo", 3, 3, 12, 7)
+
+
+def fullsize_fixture():
+    name, H, W, T, style, skip, max_num, dk, cs = FULLSIZE
+    res = run_sequence(H, W, T, style, skip, max_num, dk, cs)
+    alt = self_noise(H, W, T, style, skip, max_num, dk, cs)
+    noise = [float(np.abs(alt["alpha"][t] - res["alpha"][t]).max()) for t in range(T)]
+    flips = [int((alt["trimap"][t].argmax(0) != res["trimap"][t].argmax(0)).sum()) for t in range(T)]
+    # alpha as float32 (the compared quantity); the trimap as its class map + the winning probability in fp16 (the 3-channel
+    # fp32 probabilities would be 19 MB)
+    tri = res["trimap"]
+    np.savez_compressed(os.path.join(HERE, "seq_%s.npz" % name), alpha=res["alpha"], bank=res["bank"],
+                        trimap_cls=tri.argmax(1).astype(np.uint8), trimap_top=tri.max(1).astype(np.float16),
+                        key_probe=res["key_probe"])
+    meta = dict(H=H, W=W, T=T, style=style, skip=skip, max_num=max_num, dilate_kernel=dk, clip_seed=cs, weight_seed=0,
+                bank=res["bank"].tolist(), reference_self_noise_alpha_maxabs=noise, reference_self_noise_trimap_flips=flips)
+    json.dump({name: meta}, open(os.path.join(HERE, "fullsize.json"), "w"), indent=1)
+    print(name, "bank", res["bank"].tolist(), "alpha mean %.4f" % res["alpha"].mean(), "self-noise", noise, flips)
+
+
 def main():
     torch.set_num_threads(8)
+    if "--c480" in sys.argv:
+        return fullsize_fixture()
     meta = {}
     for (name, H, W, T, style, skip, max_num, dk, cs) in SEQUENCES:
         res = run_sequence(H, W, T, style, skip, max_num, dk, cs)

@@ -40,9 +40,15 @@ def from_act(a, Cc=None):
 
 def pack_weight(w, ws=False, scale=None, i_pad=None):
     from otvm_amd import engine
-    engine.WAVE_TILE = True                      # kernel tests cover the one-wave tile too (off by default in the product)
-    cw = pack_conv_weight(L.load(), DEV, w.contiguous().to(DEV), ws, None if scale is None else scale.contiguous().to(DEV),
-                          i_pad, split=True, stream=stream())
+    # kernel tests cover the one-wave tile too (off by default in the product): the switch is flipped for THIS weight only and
+    # restored, so tests collected later run the shipped configuration whatever the test order
+    old = engine.WAVE_TILE
+    engine.WAVE_TILE = True
+    try:
+        cw = pack_conv_weight(L.load(), DEV, w.contiguous().to(DEV), ws, None if scale is None else scale.contiguous().to(DEV),
+                              i_pad, split=True, stream=stream())
+    finally:
+        engine.WAVE_TILE = old
     torch.cuda.synchronize()
     return cw
 

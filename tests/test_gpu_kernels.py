@@ -147,6 +147,21 @@ def test_conv_fuzz_all_routes(G):
     assert r.returncode == 0 and "conv_fuzz: 80 cases" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_gn_table_tail_stress_short(G):
+    """tools/gn_tail_stress.py, short form: the GroupNorm table written by a conv's LAST workgroup (common.h::
+    otvm_gn_table_tail -- device-scope statistics atomics, a workgroup-scope fence, a ticket) against otvm_gn_table over the
+    finished statistics, bit for bit, on five layer shapes x 150 launches.  The ordering argument rests on gfx950 behaviour
+    (device-scope atomics are acknowledged past the XCD's L2 once vmcnt reaches 0), not on the HIP memory model: this test is
+    the guard should a compiler or ISA change break it."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gn_tail_stress.py"), "--reps", "150"],
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and "gn_tail_stress: 0 mismatches" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_kernel_fuzz_non_conv(G):
     """tools/kernel_fuzz.py: GroupNorm (incl. group widths that are not multiples of 4), upsampling, pooling, PPM pooling,
     memory read and the distance encoding on randomised shapes against torch / the oracle."""

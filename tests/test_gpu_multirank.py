@@ -65,7 +65,7 @@ def test_two_ranks_on_one_gpu_through_eval_cli(tmp_path):
     env["OTVM_TUNE_FILE"] = os.path.join(str(tmp_path), "tune.json")   # both runs launch the same kernel configurations
     env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    common = ["--data", root, "--synthetic-weights", "--skip", "3", "--trimap", "narrow"]
+    common = ["--data", root, "--synthetic-weights", "--skip", "3", "--trimap", "narrow", "--batch", "1"]
     out1, out2 = os.path.join(str(tmp_path), "out1"), os.path.join(str(tmp_path), "out2")
     j1, j2 = os.path.join(str(tmp_path), "s1.json"), os.path.join(str(tmp_path), "s2.json")
     r = subprocess.run([sys.executable, "-m", "otvm_amd.eval_cli"] + common + ["--out", out1, "--summary-json", j1],
@@ -94,3 +94,61 @@ def test_two_ranks_on_one_gpu_through_eval_cli(tmp_path):
     for k in ("sad", "mse", "mse_mean", "dtssd_mean", "dtssd_sum_err2", "dtssd_mask_sum"):
         assert abs(g1[k] - g2[k]) <= 1e-12 * max(1.0, abs(g1[k])), (k, g1[k], g2[k])
     assert s2["fps"] > 0
+    assert len(set(s2["tune_digests"])) == 1 and s2["batch"] == 1
+    # ---- the same two ranks with lock-step batches (the default of a multi-rank run; here forced to 2): rank 1 steps its two
+    # clips through a (64, 96, 2) plan, whose convolution configurations are timed per batch size.  Rank 0 -- which steps ONE
+    # clip -- must have built and timed that plan too before the ranks adopted its choices: the digests of the
+    # configurations each rank launched are equal, and the PNGs stay within one 8-bit step of the single-rank run (another
+    # tile = another fp32 summation order, nothing else).
+    out3, j3 = os.path.join(str(tmp_path), "out3"), os.path.join(str(tmp_path), "s3.json")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), "-m", "otvm_amd.eval_cli"] + common[:-2] +
+                       ["--batch", "2", "--out", out3, "--summary-json", j3], cwd=ROOT, env=env2, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    s3 = json.load(open(j3))
+    assert s3["batch"] == 2 and len(s3["tune_digests"]) == 2 and len(set(s3["tune_digests"])) == 1, s3["tune_digests"]
+    assert s3["frames"] == sum(lengths)
+    for clip, T in zip(names, lengths):
+        for t in range(T):
+            rel = os.path.join("alpha", "test", "s4_OTVM", "pred", clip, "%05d.png" % t)
+            a1, a3 = np.asarray(Image.open(os.path.join(out1, rel))), np.asarray(Image.open(os.path.join(out3, rel)))
+            assert int(np.abs(a1.astype(np.int16) - a3.astype(np.int16)).max()) <= 1, rel
+
+
+def test_rccl_with_one_rank_through_bench_and_eval_cli(tmp_path):
+    """RCCL itself (backend "nccl", the default) EXECUTED: a one-rank torch.distributed launch is legal on one GPU.  bench.py
+    and eval_cli then initialise the process group on RCCL with the rank's device, broadcast the tuned configurations
+    (share_tune_cache), count the ranks with an all-reduce of ones (`ranks_seen`) and reduce the metric sums with the SUM / MAX
+    all-reduces of dist.reduce_metrics -- the code path `bench.py --gpus 8` / `eval_cli --gpus 8` takes on a node
+    (reference: one device per process, eval.py:42,80)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env.pop("OTVM_DIST_BACKEND", None)                      # the default: nccl = RCCL
+    env["OTVM_TUNE_FILE"] = os.path.join(str(tmp_path), "tune.json")
+    launch = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+              "--master-port"]
+    r = subprocess.run(launch + [str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "2",
+                                 "--no-cpu-baseline", "--no-roofline", "--height", "480", "--width", "832"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["value"] > 0 and res["steps"] == 3
+    assert res["dist_backend"] == "nccl" and res["ranks_seen"] == 1, (res["dist_backend"], res["ranks_seen"])
+    assert len(res["per_rank"]) == 1
+    root = os.path.join(str(tmp_path), "data")
+    os.makedirs(root)
+    lengths = [3, 2]
+    _v108_tree(root, lengths)
+    out, js = os.path.join(str(tmp_path), "out"), os.path.join(str(tmp_path), "s.json")
+    r = subprocess.run(launch + [str(_free_port()), "-m", "otvm_amd.eval_cli", "--data", root, "--synthetic-weights", "--skip", "3",
+                                 "--trimap", "narrow", "--out", out, "--summary-json", js],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    s = json.load(open(js))
+    assert s["shards"] == [[0, 1]] and s["frames"] == sum(lengths) and len(s["tune_digests"]) == 1
+    assert s["gt_metrics"]["frames"] == sum(lengths)

@@ -101,6 +101,29 @@ def test_oracle_sequence_vs_reference(name, synth_sd):
     np.testing.assert_array_equal(out[2][0, 0].numpy(), gold["tri_gt"])
 
 
+def test_oracle_fullsize_sequence_vs_reference(synth_sd):
+    """BASELINE configs[1] geometry: a 4-frame 832x480 clip matted by the REFERENCE itself (tests/golden/make_golden.py
+    --c480; skip 3 / max 3, frames 2 and 3 read two memory slots) against the oracle.  Pins the oracle at a size where the
+    memory read runs over 2 x 1560 positions and every pyramid level has its real aspect ratio -- the golden sequences above
+    are <= 100 x 150."""
+    import json
+    meta = json.load(open(os.path.join(GOLDEN, "fullsize.json")))["c480_832x480_s3m3"]
+    gold = load_golden("c480_832x480_s3m3")
+    orc = O.OtvmOracle(synth_sd, dilate_kernel=meta["dilate_kernel"])
+    for t, (a, fg, bg, tri_gt) in enumerate(clip_inputs(meta)):
+        out = orc.frame(a, fg, bg, tri_gt=tri_gt, frame_id=t, **frame_flags(meta, t))
+        assert len(orc.bank) == gold["bank"][t]
+        da = float(np.abs(out[3][0, 0, 0].numpy() - gold["alpha"][t]).max())
+        tri = out[1][0, 0].numpy()
+        flips = int((tri.argmax(0) != gold["trimap_cls"][t]).sum())
+        dtop = float(np.abs(tri.max(0) - gold["trimap_top"][t].astype(np.float32)).max())
+        print("c480 t=%d alpha %.2e class flips %d top-prob %.2e (reference's own reorder noise: %.1e, %d flips)"
+              % (t, da, flips, dtop, meta["reference_self_noise_alpha_maxabs"][t], meta["reference_self_noise_trimap_flips"][t]))
+        # bitwise on the generating machine; elsewhere the fp32 contract (and the reference's own reorder noise flips 0-2 of
+        # 399 360 output classes at this size)
+        assert da <= 1e-3 and flips <= 8 and dtop <= 5e-3, (t, da, flips, dtop)
+
+
 def test_oracle_stages_vs_reference(synth_sd):
     """Per-stage tensors of two consecutive frames (reference forward hooks) against the oracle's captures."""
     from otvm_amd.synth_data import synthetic_clip
