@@ -35,7 +35,7 @@ extern "C" {
 #define OTVM_PREC_F16X3 1
 
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 16   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
+#define OTVM_ABI_VERSION 17   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
                                  4: otvm_conv_params.splitk_ws; 5: otvm_preprocess_params.fg_u8/bg_u8/u8_rgb;
                                  6: otvm_conv_params.tune + otvm_conv2d_candidates;
                                  7: folded GroupNorm tables on otvm_gn_apply's residual and otvm_upsample_bilinear's input;
@@ -48,7 +48,9 @@ const char* otvm_last_error(void);
                                  14: otvm_ppm_conv_z / otvm_ppm_conv_add (the PPM branches' share of conv_up1.0 without upsampling);
                                  15: otvm_stm_bottleneck_f16x3 (one kernel per 1/4-resolution bottleneck of the STM encoders);
                                  16: otvm_conv_params.gn_gamma ... gn_counter (the GroupNorm scale / shift table of the OUTPUT
-                                     written by the conv's last workgroup instead of a separate otvm_gn_table launch) */
+                                     written by the conv's last workgroup instead of a separate otvm_gn_table launch);
+                                 17: otvm_gram_f16 / otvm_gn_predict (GroupNorm statistics of a 1x1 convolution's output predicted
+                                     from its input's Gram matrix: the normalisation moves into that convolution's epilogue) */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -136,7 +138,22 @@ typedef struct {
     float* gn_scale_out; float* gn_shift_out;       /* Cout floats each; image b's tables gn_tab_bs floats behind image 0 */
     unsigned* gn_counter;
     int gn_tab_bs;
+    /* ---- ABI 17, 1x1 layers on the implicit-GEMM route (f16x3) only: a layer whose epilogue carries a PREDICTED
+     * normalisation of its output (otvm_gn_predict writes w_scale / bias per frame and per image).                      */
+    int ws_bs;                                      /* floats between the images' w_scale / bias arrays (0 = shared)      */
+    const float* res_scale;                         /* optional, with residual: residual' = residual * res_scale[c] (the
+                                                       GroupNorm scale of a raw identity-path tensor, otvm_gn_table; its shift
+                                                       belongs into bias -- otvm_gn_predict_params.res_shift); Cout floats,
+                                                       image b's table res_scale_bs floats behind image 0                 */
+    int res_scale_bs;
+    const float* in_res; int in_res_ld; int64_t in_res_bs;
+                                                    /* optional, with in_scale, layers for which otvm_conv2d_accepts_input_residual()
+                                                       returns 1 (3x3 patch kernel, <= 64 output channels): the input is the raw
+                                                       input of a residual block's last GroupNorm whose apply pass is skipped,
+                                                       in' = in_act(in * in_scale[c] + in_shift[c] + in_res) -- the arithmetic of
+                                                       otvm_gn_apply with a residual; in_res = the block's identity, same shape   */
 } otvm_conv_params;
+int otvm_conv2d_accepts_input_residual(const otvm_conv_params* p);
 int otvm_conv2d(const otvm_conv_params* p, void* stream);
 /* The legal kernel configurations of a layer (f16x3): the patch kernel where the shape allows it, and the implicit-GEMM
  * tiles 256x256 ... 64x64, each alone or with the K range of every output tile shared by S = 2..8 workgroups
@@ -211,6 +228,40 @@ typedef struct {
     int batch; int64_t x_bs, res_bs, out_bs; int stats_bs, norm_bs;
 } otvm_gn_apply_params;
 int otvm_gn_apply_b(const otvm_gn_apply_params* p, void* stream);
+
+/* ---- GroupNorm statistics of a 1x1 convolution's output, PREDICTED from its input (ABI 17; csrc/gram.hip) ------------
+ * FBA bottleneck tail (resnet_GN_WS.py:66-86): out = relu(GroupNorm(conv3(x')) + identity), x' = relu(GroupNorm(conv2 ...)).
+ * y = W x' is linear, so the sums the GroupNorm of y needs follow from the input:  sum y = v_g . s,  sum y^2 = <G, M_g>  with
+ * s = sum_p x'_p, G = sum_p x'_p x'_p^T (this call) and v_g = sum_{c in g} w_c, M_g = sum_{c in g} w_c w_c^T (per checkpoint).
+ * otvm_gram_f16 : x = the RAW GroupNorm input of x' ([P][ld] fp32, C channels), in_scale / in_shift / in_act = its folded
+ *                 normalisation (tables of otvm_gn_table; NULL = x is x' already).  Writes per pixel chunk k (nk =
+ *                 otvm_gram_chunks(P, C, &pch) chunks of pch pixels) the block-upper-triangular partial Gram matrix
+ *                 gpart[k][blk][bs*bs] (bs = otvm_gram_block(C); blocks (bi <= bj) row-major; otvm_gram_entries(C) floats per
+ *                 chunk) and the partial channel sums spart[k][C].  passes = 1: operands rounded to fp16 (round to nearest;
+ *                 the statistics average the rounding noise out), 3: the f16x3 split of the convolutions.
+ * otvm_gn_predict: adds the partials in fp64, contracts them with Mp[entries][32] (fp32, entry-major; off-diagonal blocks
+ *                 carrying the factor 2 of the symmetric half) and v[32][C] (fp64), and writes  scale_eff[c] = wscale[c] * rstd_g * gamma[c],
+ *                 bias_eff[c] = beta[c] - mean_g * rstd_g * gamma[c] (+ res_shift[c])  -- the values the consuming conv takes
+ *                 as otvm_conv_params.w_scale / bias.  sums = zeroed [32][2] fp64, counter = zeroed uint32 per image (both
+ *                 are left zeroed); stat_out (optional) receives (mean, rstd) per group.  Batched like otvm_gn_*_b.           */
+typedef struct otvm_gram_params {
+    const float* x; int64_t P; int C, ld;
+    const float* in_scale; const float* in_shift; int in_act;
+    float* gpart; float* spart; int passes;
+    int batch; int64_t x_bs; int norm_bs;            /* image b: x + b * x_bs, tables + b * norm_bs; partials are packed per image */
+} otvm_gram_params;
+int otvm_gram_block(int C);
+int64_t otvm_gram_entries(int C);
+int otvm_gram_chunks(int64_t P, int C, int* pch_out);
+int otvm_gram_f16(const otvm_gram_params* p, void* stream);
+typedef struct otvm_gn_predict_params {
+    const float* gpart; const float* spart; int64_t P; int C, Cout;
+    const float* Mp; const double* v; double* sums; unsigned* counter;
+    const float* wscale; const float* gamma; const float* beta; const float* res_shift;
+    float* scale_eff; float* bias_eff; float* stat_out;
+    int batch, sums_bs, tab_bs, rs_bs;               /* image b: sums + b * sums_bs doubles, tables + b * tab_bs floats */
+} otvm_gn_predict_params;
+int otvm_gn_predict(const otvm_gn_predict_params* p, void* stream);
 
 /* ---------------------------------------------------------------- pooling / resampling ---------*/
 /* F.max_pool2d(3, 2, 1) (resnet_GN_WS.py:98, torchvision resnet maxpool in STM.py:47,83) */

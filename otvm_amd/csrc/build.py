@@ -18,6 +18,7 @@ SOURCES = [
     ("conv_stem_f16x3.hip", []),
     ("bottleneck_f16x3.hip", []),
     ("groupnorm.hip", []),
+    ("gram.hip", []),
     ("resample.hip", ["-ffp-contract=off"]),
     ("glue.hip", ["-ffp-contract=off"]),
     ("edt.hip", ["-ffp-contract=off"]),
@@ -69,7 +70,7 @@ def build(force=False, verbose=False):
                 failed.append(cmd)
         if failed:
             raise subprocess.CalledProcessError(1, failed[0])
-    if relink or not os.path.exists(LIB):
+    if relink or not os.path.exists(LIB) or any(_newer(o, LIB) for o in objs):   # (an object compiled by hand counts)
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd))

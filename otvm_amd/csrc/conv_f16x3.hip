@@ -80,6 +80,9 @@ struct Conv3Args {
     // conv's padding; tables from otvm_gn_table, image b's table norm_bs floats behind image 0's
     const float* in_scale; const float* in_shift; float in_slope; int norm_bs;
     OtvmGnTail tail;             // ABI 16: the output's GroupNorm table, written by the last workgroup (common.h)
+    // ABI 17: per-image w_scale / bias (a predicted normalisation of the output, csrc/gram.hip) and a per-channel scale on the
+    // residual (the GroupNorm scale of a raw identity-path tensor; its shift is part of bias)
+    int ws_bs; const float* res_scale; int rs_bs;
 };
 
 constexpr int BK = 32;
@@ -113,6 +116,9 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
         if (p.residual) p.residual += zb * p.res_bs;
         if (p.gn_stats) p.gn_stats += zb * p.gn_bs;
         if (NORM_IN) { p.in_scale += zb * p.norm_bs; p.in_shift += zb * p.norm_bs; }
+        p.wscale += zb * p.ws_bs;
+        if (p.bias) p.bias += zb * p.ws_bs;
+        if (p.res_scale) p.res_scale += zb * p.rs_bs;
     }
     static_assert(!NORM_IN || (FAST && !RELU_IN), "the fused input normalisation exists on the whole-chunk path only");
     constexpr int NT = WM * WN * 64;
@@ -436,14 +442,16 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
     // compiler cannot count what is outstanding at the join: it waits for vmcnt(0) in every predicated row block -- i.e.
     // for the previous store's acknowledgement from L2, 32 times per wave of the 256x256 tile (profiles/r03_fused_bottleneck.txt
     // is where this showed up first).
-    const bool interior = vec_ok && m0 + BM <= p.M && n0 + BN <= p.Cout;          // workgroup-uniform
+    const bool interior = vec_ok && m0 + BM <= p.M && n0 + BN <= p.Cout &&           // workgroup-uniform
+                          !(p.residual && p.res_scale && p.act != OTVM_ACT_RELU);
     // vmcnt retires in order: waiting for a load that was issued AFTER a store also waits for that store.  So the interior
     // path fetches the scale / bias vectors of all TN column tiles up front and requests the residual of tile t + 1 before
     // the stores of tile t go out -- nothing in it ever waits for a store.  Activation and residual are compile-time here:
     // a uniform branch inside the tile loop would split it into basic blocks and bring the conservative vmcnt(0) back.
     auto epilogue_full = [&](auto act_c, auto res_c) __attribute__((always_inline)) {
         constexpr int ACT = decltype(act_c)::value;
-        constexpr bool RES = decltype(res_c)::value;
+        constexpr bool RES = decltype(res_c)::value != 0;         // 0: no residual, 1: residual, 2: residual * res_scale[c]
+        constexpr bool RSC = decltype(res_c)::value == 2;
         float* patch = reinterpret_cast<float*>(smem) + wave * (32 * 36);
         const int prow = lane >> 3, pc = (lane & 7) * 4;
         f32x4 sc4[TN], bi4[TN];
@@ -469,6 +477,12 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
                 r[r4] = *reinterpret_cast<const f32x4*>(p.residual + (int64_t)(mb + r4 * 8 + prow) * p.res_ld + n4);
         };
         f32x4 rnext[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+        // ABI 17: the residual's own per-channel scale (one vector per column tile, fetched up front like scale / bias)
+        f32x4 rs4[RSC ? TN : 1];
+        if (RSC) {
+#pragma unroll
+            for (int b = 0; b < (RSC ? TN : 1); ++b) rs4[b] = *reinterpret_cast<const f32x4*>(p.res_scale + n0 + (wn * TN + b) * 32 + pc);
+        }
         if (RES) load_res(0, rnext);
 #pragma unroll
         for (int b = 0; b < TN; ++b)
@@ -488,7 +502,8 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
                     const int row = r4 * 8 + prow;
                     f32x4 v = *reinterpret_cast<const f32x4*>(&patch[row * 36 + pc]);
                     v = v * sc4[b] + bi4[b];
-                    if (RES) v += rres[r4];
+                    if (RSC) v += rres[r4] * rs4[RSC ? b : 0];
+                    else if (RES) v += rres[r4];
                     v.x = otvm_act(v.x, ACT); v.y = otvm_act(v.y, ACT); v.z = otvm_act(v.z, ACT); v.w = otvm_act(v.w, ACT);
                     *reinterpret_cast<f32x4*>(outp + (int64_t)(mb + row) * p.out_ld + n4) = v;
                 }
@@ -503,12 +518,13 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
             const int nb = n0 + (wn * TN + b) * 32;    // first column of this tile
             if (!FULL && nb >= p.Cout) return;
             const int n4 = nb + pc;                    // this lane's 4 columns in the row-major pass
-            f32x4 sc4 = {0.f, 0.f, 0.f, 0.f}, bi4 = {0.f, 0.f, 0.f, 0.f};
+            f32x4 sc4 = {0.f, 0.f, 0.f, 0.f}, bi4 = {0.f, 0.f, 0.f, 0.f}, rs4 = {1.f, 1.f, 1.f, 1.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (FULL || n4 + j < p.Cout) {
                     sc4[j] = p.wscale[n4 + j];
                     bi4[j] = p.bias ? p.bias[n4 + j] : 0.f;
+                    if (p.residual && p.res_scale) rs4[j] = p.res_scale[n4 + j];
                 }
             }
             otvm_static_for<TM>([&](auto a_c) __attribute__((always_inline)) {
@@ -538,7 +554,7 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
                     v = v * sc4 + bi4;
                     if (FULL || m < p.M) {
                         if (FULL || (vec_ok && n4 + 3 < p.Cout)) {
-                            v += rres[r4];
+                            v += rres[r4] * rs4;
                             v.x = otvm_act(v.x, p.act); v.y = otvm_act(v.y, p.act);
                             v.z = otvm_act(v.z, p.act); v.w = otvm_act(v.w, p.act);
                             *reinterpret_cast<f32x4*>(outp + (int64_t)m * p.out_ld + n4) = v;
@@ -547,7 +563,7 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
                             for (int j = 0; j < 4; ++j) {
                                 if (n4 + j < p.Cout) {
                                     float x = v[j];
-                                    if (p.residual) x += p.residual[(int64_t)m * p.res_ld + n4 + j];
+                                    if (p.residual) x += p.residual[(int64_t)m * p.res_ld + n4 + j] * rs4[j];
                                     outp[(int64_t)m * p.out_ld + n4 + j] = otvm_act(x, p.act);
                                 }
                             }
@@ -560,9 +576,12 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
     if (interior) {
         using std::integral_constant;
         const bool r = p.residual != nullptr;
-        if (p.act == OTVM_ACT_RELU) { if (r) epilogue_full(integral_constant<int, OTVM_ACT_RELU>{}, std::true_type{}); else epilogue_full(integral_constant<int, OTVM_ACT_RELU>{}, std::false_type{}); }
-        else if (p.act == OTVM_ACT_LEAKY) { if (r) epilogue_full(integral_constant<int, OTVM_ACT_LEAKY>{}, std::true_type{}); else epilogue_full(integral_constant<int, OTVM_ACT_LEAKY>{}, std::false_type{}); }
-        else { if (r) epilogue_full(integral_constant<int, OTVM_ACT_NONE>{}, std::true_type{}); else epilogue_full(integral_constant<int, OTVM_ACT_NONE>{}, std::false_type{}); }
+        using I0 = integral_constant<int, 0>;
+        using I1 = integral_constant<int, 1>;
+        if (r && p.res_scale) epilogue_full(integral_constant<int, OTVM_ACT_RELU>{}, integral_constant<int, 2>{});   // (the bottleneck tail: always ReLU; other activations take the predicated copy)
+        else if (p.act == OTVM_ACT_RELU) { if (r) epilogue_full(integral_constant<int, OTVM_ACT_RELU>{}, I1{}); else epilogue_full(integral_constant<int, OTVM_ACT_RELU>{}, I0{}); }
+        else if (p.act == OTVM_ACT_LEAKY) { if (r) epilogue_full(integral_constant<int, OTVM_ACT_LEAKY>{}, I1{}); else epilogue_full(integral_constant<int, OTVM_ACT_LEAKY>{}, I0{}); }
+        else { if (r) epilogue_full(integral_constant<int, OTVM_ACT_NONE>{}, I1{}); else epilogue_full(integral_constant<int, OTVM_ACT_NONE>{}, I0{}); }
     } else {
         epilogue(std::false_type{});
     }
@@ -650,6 +669,8 @@ __global__ __launch_bounds__(64) void conv_wave_f16x3_kernel(const Conv3Args pa)
         p.out += zb * p.out_bs;
         if (p.residual) p.residual += zb * p.res_bs;
         if (p.gn_stats) p.gn_stats += zb * p.gn_bs;
+        p.wscale += zb * p.ws_bs;
+        if (p.bias) p.bias += zb * p.ws_bs;
     }
     constexpr int BM = 64, BN = 64, TM = 2, TN = 2, PF = OTVM_WAVE_PF;
     __shared__ __attribute__((aligned(16))) float patch[32 * 36];
@@ -908,10 +929,13 @@ __global__ __launch_bounds__(256) void pack_wave_weight_kernel(const _Float16* _
 __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restrict__ part, int S, int64_t stride, int64_t M,
                                                             int Cout, int ldp, const float* __restrict__ bias,
                                                             const float* __restrict__ residual, int res_ld, int act,
-                                                            float* __restrict__ out, int out_ld, int64_t out_bs, int64_t res_bs) {
+                                                            float* __restrict__ out, int out_ld, int64_t out_bs, int64_t res_bs,
+                                                            int ws_bs, const float* __restrict__ res_scale, int rs_bs) {
     part += (int64_t)blockIdx.y * S * stride;                   // image blockIdx.y
     out += blockIdx.y * out_bs;
     if (residual) residual += blockIdx.y * res_bs;
+    if (bias) bias += blockIdx.y * ws_bs;
+    if (res_scale) res_scale += blockIdx.y * rs_bs;
     const unsigned Q = (unsigned)ldp >> 2;
     const unsigned total = (unsigned)M * Q;                     // split layers are small: M * ldp / 4 < 2^32 (host check)
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -923,7 +947,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(const float* __restr
         for (int j = 0; j < 4; ++j) {
             if (c + j < Cout) {
                 float x = v[j] + (bias ? bias[c + j] : 0.f);
-                if (residual) x += residual[m * res_ld + c + j];
+                if (residual) x += residual[m * res_ld + c + j] * (res_scale ? res_scale[c + j] : 1.f);
                 out[m * out_ld + c + j] = otvm_act(x, act);
             }
         }
@@ -1099,6 +1123,7 @@ static bool config_ok(const otvm_conv_params* p, int tile, int S) {
     // the wave tile reads fragment-major weights and walks whole 32-channel blocks: fast layout + w_wfrag only
     if ((tile == T64x64D || tile == T128x64D) && !f16x3_fast_layout(p->kh * p->kw, p->Cin)) return false;
     if (tile == T64x64W1 && !(p->w_wfrag && f16x3_fast_layout(p->kh * p->kw, p->Cin) && (p->in_ld & 3) == 0)) return false;
+    if (tile == T64x64W1 && p->res_scale) return false;           // (the one-wave tile's epilogue has no residual scale)
     if (S > 1) {
         const int nchunks = p->K_pad / 32;
         const int ldp = (p->Cout + 3) & ~3;
@@ -1115,14 +1140,14 @@ static int run_config(const otvm_conv_params* p, Conv3Args& a, int tile, int S, 
     const int ldp = (p->Cout + 3) & ~3;
     Conv3Args b = a;
     b.out = (float*)p->splitk_ws; b.out_ld = ldp; b.split_stride = M * ldp; b.out_bs = (int64_t)S * M * ldp;
-    b.bias = nullptr; b.residual = nullptr; b.act = OTVM_ACT_NONE; b.gn_stats = nullptr; b.tail.scale = nullptr;
+    b.bias = nullptr; b.residual = nullptr; b.res_scale = nullptr; b.act = OTVM_ACT_NONE; b.gn_stats = nullptr; b.tail.scale = nullptr;
     const int rc = launch_tile(tile, b, s, S);
     if (rc) return rc;
     int64_t blocks = (M * (ldp / 4) + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)blocks, g_batch), dim3(256), 0, s, (const float*)p->splitk_ws, S,
                        (int64_t)M * ldp, M, p->Cout, ldp, p->bias, p->residual, p->res_ld, p->act, p->out,
-                       p->out_ld, a.out_bs, a.res_bs);
+                       p->out_ld, a.out_bs, a.res_bs, a.ws_bs, a.res_scale, a.rs_bs);
     OTVM_CHECK_LAUNCH("otvm_conv2d(split-K finish)");
     if (p->gn_stats) {
         const int rc2 = otvm_gn_stats_b(p->out, M, p->Cout, p->out_ld, p->gn_stats, g_batch, a.out_bs, a.gn_bs, (void*)s);
@@ -1145,6 +1170,7 @@ extern "C" int otvm_conv2d_candidates(const otvm_conv_params* p, int* out, int m
     auto add = [&](int code) { if (n < max_n) out[n++] = code; };
     if (otvm_conv2d_stem_eligible(p)) add(tune_code(T_STEM, 1));
     if (otvm_conv2d_patch_eligible(p)) add(tune_code(T_PATCH, 1));
+    if (p->in_res) return n;                                       // (the patch kernel only)
     const int64_t M = (int64_t)p->Ho * p->Wo;
     const int nchunks = p->K_pad / 32;
     // (T256x256W4 is legal when forced but not offered: it won one of seven large layers by 3.5 % and lost the others by
@@ -1177,6 +1203,10 @@ int otvm_conv2d_igemm_accepts_input_norm(const otvm_conv_params* p) {
 int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     OTVM_REQUIRE(p->w_hi && p->w_lo && p->w_scale, "otvm_conv2d: precision f16x3 needs w_hi / w_lo / w_scale");
     const int forced_tile = p->tune ? p->tune / 16 - 1 : -1, forced_S = p->tune & 15;
+    OTVM_REQUIRE(!p->in_res || (otvm_conv2d_patch_eligible(p) && (!p->tune || forced_tile == T_PATCH)),
+                 "otvm_conv2d: in_res (identity inside the fused input normalisation) is a patch-kernel feature");
+    const bool gemm_only = (p->batch > 1 && p->ws_bs) || (p->residual && p->res_scale);   // ABI 17 fields: implicit GEMM only
+    OTVM_REQUIRE(!gemm_only || (p->kh == 1 && p->kw == 1), "otvm_conv2d: ws_bs / res_scale are for 1x1 layers (implicit-GEMM route)");
     if (forced_tile == T_STEM || (!p->tune && otvm_conv2d_stem_eligible(p))) {
         OTVM_REQUIRE(otvm_conv2d_stem_eligible(p), "otvm_conv2d: tune asks for the stem kernel on a layer it cannot take");
         return otvm_conv2d_stem_f16x3(p, stream);
@@ -1208,6 +1238,10 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     g_batch = p->batch > 1 ? p->batch : 1;
     a.in_bs = g_batch > 1 ? p->in_bs : 0; a.out_bs = g_batch > 1 ? p->out_bs : 0; a.res_bs = g_batch > 1 ? p->res_bs : 0;
     a.gn_bs = g_batch > 1 ? p->gn_bs : 0;
+    a.ws_bs = g_batch > 1 ? p->ws_bs : 0;
+    a.res_scale = p->residual ? p->res_scale : nullptr; a.rs_bs = g_batch > 1 ? p->res_scale_bs : 0;
+    OTVM_REQUIRE(!a.res_scale || (((uintptr_t)a.res_scale & 15) == 0 && (a.rs_bs & 3) == 0 && p->Cout % 4 == 0),
+                 "otvm_conv2d: res_scale must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int64_t M = a.M;
     if (p->tune) {

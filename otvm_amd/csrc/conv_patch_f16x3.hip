@@ -54,6 +54,9 @@ struct PatchArgs {
     // batch: image blockIdx.y of every tensor lives *_bs elements behind image 0
     int64_t in_bs, out_bs, res_bs; int gn_bs, norm_bs, batch;
     OtvmGnTail tail;             // ABI 16: the output's GroupNorm table, written by the last workgroup (common.h)
+    // ABI 17 (INRES kernels): the input is the raw GroupNorm input of a residual block's LAST normalisation, whose apply pass
+    // was skipped: x' = in_act(x * in_scale[c] + in_shift[c] + in_res), in_res = the block's (materialised) identity
+    const float* in_res; int in_res_ld; int64_t in_res_bs;
 };
 
 constexpr int CB = 16;           // channels per stage = one MFMA k-step
@@ -74,14 +77,15 @@ __device__ __forceinline__ void split4p(const f32x4 v, f16x4& hi, f16x4& lo) {
 // fragments of its BN output channels, copied verbatim from the fragment-major weight array (1-KiB blocks).
 // TAPG = 9: one weight stage per channel stage (narrow layers); TAPG = 3: wide layers (BN = 256), where nine taps of
 // weights (144 KiB) would not fit beside the patch.
-template <int TH, int BN, int NW, int DIL, int TAPG>
+template <int TH, int BN, int NW, int DIL, int TAPG, bool INRES = false>
 __global__ __launch_bounds__(NW * 64)
-__attribute__((amdgpu_waves_per_eu((TAPG == 3 && BN <= 32) ? 3 : 1, (TAPG == 3 && BN <= 32) ? 3 : 10)))
+__attribute__((amdgpu_waves_per_eu((TAPG == 3 && BN <= 32 && !INRES) ? 3 : 1, (TAPG == 3 && BN <= 32 && !INRES) ? 3 : 10)))
 void conv_patch_f16x3_kernel(const PatchArgs pa) {
     PatchArgs p = pa;
     {
         const int zb = blockIdx.y;
         p.in += zb * p.in_bs;
+        if (INRES) p.in_res += zb * p.in_res_bs;
         p.out += zb * p.out_bs;
         if (p.residual) p.residual += zb * p.res_bs;
         if (p.gn_stats) p.gn_stats += zb * p.gn_bs;
@@ -132,6 +136,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     constexpr int NP = (NPIX * 4 + NT - 1) / NT;                       // patch float4 per thread
     constexpr int NB = (B_PIECES + NT - 1) / NT;                       // B 16-byte pieces per thread
     f32x4 rp[NP];
+    f32x4 rr[INRES ? NP : 1];                                          // INRES: the identity's values of the same elements
     f16x8 rb[NB];
     f32x4 rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};      // input-normalisation table of this thread's quad
     auto prefetch = [&](int cb, int g) __attribute__((always_inline)) {
@@ -159,8 +164,10 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                     const int pix = idx >> 2, c4 = (idx & 3) * 4;
                     const int py = pix / PW, px = pix - py * PW;
                     const int iy = ty0 - DIL + py, ix = tx0 - DIL + px;
-                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
                         v = *reinterpret_cast<const f32x4*>(p.in + ((int64_t)iy * p.W + ix) * p.in_ld + cb * CB + c4);
+                        if (INRES) rr[k] = *reinterpret_cast<const f32x4*>(p.in_res + ((int64_t)iy * p.W + ix) * p.in_res_ld + cb * CB + c4);
+                    }
                 }
                 rp[k] = v;
             }
@@ -184,6 +191,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                         const int iy = ty0 - DIL + py, ix = tx0 - DIL + px;
                         const bool inb = (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
                         v = v * rsc + rsh;
+                        if (INRES && inb) v += rr[INRES ? k : 0];       // the arithmetic of otvm_gn_apply: (x a + b) + residual, then act
                         v.x = otvm_act(v.x, p.in_act); v.y = otvm_act(v.y, p.in_act);
                         v.z = otvm_act(v.z, p.in_act); v.w = otvm_act(v.w, p.in_act);
                         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -493,12 +501,12 @@ __global__ __launch_bounds__(256) void pack_patch_weight_kernel(const float* __r
     }
 }
 
-template <int TH, int BN, int NW, int DIL, int TAPG = 9>
+template <int TH, int BN, int NW, int DIL, int TAPG = 9, bool INRES = false>
 int launch_patch(PatchArgs& a, hipStream_t s) {
     a.tiles_x = otvm_ceil_div(a.W, 32);
     a.tiles_y = otvm_ceil_div(a.H, TH);
     a.tiles_n = otvm_ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL, TAPG>), dim3(a.tiles_x * a.tiles_y * a.tiles_n, a.batch), dim3(NW * 64), 0, s, a);
+    hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL, TAPG, INRES>), dim3(a.tiles_x * a.tiles_y * a.tiles_n, a.batch), dim3(NW * 64), 0, s, a);
     OTVM_CHECK_LAUNCH("otvm_conv2d(patch f16x3)");
     return 0;
 }
@@ -551,7 +559,15 @@ extern "C" int otvm_conv2d_input_norm_kind(const otvm_conv_params* p) {
     return otvm_conv2d_igemm_accepts_input_norm(p) ? 2 : 0;
 }
 
-int otvm_conv2d_patch_eligible(const otvm_conv_params* p) { return patch_choice(p, true) != 0 ? 1 : 0; }
+// ABI 17: in_res (the identity added inside the fused input normalisation) exists on the narrow dilation-1 patch tiles
+extern "C" int otvm_conv2d_accepts_input_residual(const otvm_conv_params* p) {
+    return p && p->precision == OTVM_PREC_F16X3 && patch_choice(p) == 1 && p->dil == 1 && p->in_scale && !p->in_relu ? 1 : 0;
+}
+
+int otvm_conv2d_patch_eligible(const otvm_conv_params* p) {
+    if (p->in_res && !otvm_conv2d_accepts_input_residual(p)) return 0;
+    return patch_choice(p, true) != 0 ? 1 : 0;
+}
 
 static int patch_run(const otvm_conv_params* p, void* stream, int choice);
 
@@ -574,6 +590,12 @@ static int patch_run(const otvm_conv_params* p, void* stream, int choice) {
     a.batch = p->batch > 1 ? p->batch : 1;
     a.in_bs = a.batch > 1 ? p->in_bs : 0; a.out_bs = a.batch > 1 ? p->out_bs : 0; a.res_bs = a.batch > 1 ? p->res_bs : 0;
     a.gn_bs = a.batch > 1 ? p->gn_bs : 0; a.norm_bs = a.batch > 1 ? p->norm_bs : 0;
+    a.in_res = p->in_res; a.in_res_ld = p->in_res_ld; a.in_res_bs = a.batch > 1 ? p->in_res_bs : 0;
+    if (p->in_res) {
+        OTVM_REQUIRE(otvm_conv2d_accepts_input_residual(p) && !is_wide && (p->in_res_ld & 3) == 0 && ((uintptr_t)p->in_res & 15) == 0,
+                     "otvm_conv2d: in_res needs in_scale on a 3x3 stride-1 dilation-1 layer with <= 64 output channels");
+        return p->Cout <= 32 ? launch_patch<8, 32, 4, 1, 3, true>(a, s) : launch_patch<8, 64, 4, 1, 9, true>(a, s);
+    }
     if (is_wide) {
         if (p->dil == 1) return launch_patch<8, 256, 8, 1, 3>(a, s);
         if (p->dil == 2) return launch_patch<8, 256, 8, 2, 3>(a, s);

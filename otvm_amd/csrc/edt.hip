@@ -18,28 +18,52 @@ typedef float edt_f32x4 __attribute__((ext_vector_type(4)));
 typedef float edt_f32x2 __attribute__((ext_vector_type(2)));
 constexpr int EDT_INF = 1 << 14;     // > any image side handled (asserted on the host side)
 
-__global__ void classify_kernel(const float* __restrict__ probs, int64_t P, const uint8_t* __restrict__ cls_override,
-                                uint8_t* __restrict__ cls_out, int* __restrict__ flags, float* __restrict__ x11, int x11_ld,
-                                float* __restrict__ d80, int d80_ld) {
+// Round 4: the three kernels below were 0.30-0.34 ms of a 1080p frame on its serial chain (STM decoder -> encoding -> FBA
+// encoder) for ~0.2 GB of algorithmic traffic (profiles/r03_kernel_traffic_gbps_1080p.md: 0.08-0.23 of HBM speed).  What cost:
+//   classify : besides the class map it scattered the two soft channels into x11 (16 of every 48 bytes) and d80 (8 of
+//              every 320 bytes) -- 4.2 M partial-sector writes;
+//   columns  : 60 workgroups at 1080p, every thread walking its 68 rows three times with one dependent byte load per step;
+//   rows     : one workgroup per (class, row) writing 12 of every 48 bytes of x11, twice per pixel.
+// Now: classify writes the class map only (quads of pixels per thread); the column pass keeps a thread's rows in registers
+// (all loads of a segment in flight at once, both classes from one read, 16-bit distances out); the row pass handles both
+// classes of an image row in one workgroup and writes channels 3..11 of x11 and the two soft channels of d80 once.
+__global__ __launch_bounds__(256) void classify_kernel(const float* __restrict__ probs, int64_t P,
+                                                       const uint8_t* __restrict__ cls_override, uint8_t* __restrict__ cls_out,
+                                                       int* __restrict__ flags) {
     int has_bg = 0, has_fg = 0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
-        const float p0 = probs[i], p1 = probs[P + i], p2 = probs[2 * P + i];
-        int cls;
-        if (cls_override) {
-            cls = cls_override[i];
-        } else {                          // tri.max(dim)[1]: first maximal index (alpha/model.py:42)
-            cls = 0;
-            float m = p0;
-            if (p1 > m) { m = p1; cls = 1; }
-            if (p2 > m) { cls = 2; }
+    const bool vec = (P & 3) == 0 && ((reinterpret_cast<uintptr_t>(probs) | reinterpret_cast<uintptr_t>(cls_out) |
+                                        reinterpret_cast<uintptr_t>(cls_override)) & 15) == 0;
+    auto argmax3 = [](float p0, float p1, float p2) {   // tri.max(dim)[1]: first maximal index (alpha/model.py:42)
+        int cls = 0;
+        float m = p0;
+        if (p1 > m) { m = p1; cls = 1; }
+        if (p2 > m) { cls = 2; }
+        return cls;
+    };
+    if (vec) {
+        const int64_t Q = P >> 2;
+        for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < Q; q += (int64_t)gridDim.x * blockDim.x) {
+            uchar4 c;
+            if (cls_override) {
+                c = *reinterpret_cast<const uchar4*>(cls_override + 4 * q);
+            } else {
+                const edt_f32x4 a = *reinterpret_cast<const edt_f32x4*>(probs + 4 * q);
+                const edt_f32x4 b = *reinterpret_cast<const edt_f32x4*>(probs + P + 4 * q);
+                const edt_f32x4 d = *reinterpret_cast<const edt_f32x4*>(probs + 2 * P + 4 * q);
+                c.x = (uint8_t)argmax3(a.x, b.x, d.x); c.y = (uint8_t)argmax3(a.y, b.y, d.y);
+                c.z = (uint8_t)argmax3(a.z, b.z, d.z); c.w = (uint8_t)argmax3(a.w, b.w, d.w);
+            }
+            *reinterpret_cast<uchar4*>(cls_out + 4 * q) = c;
+            has_bg |= (c.x == 0) | (c.y == 0) | (c.z == 0) | (c.w == 0);
+            has_fg |= (c.x == 2) | (c.y == 2) | (c.z == 2) | (c.w == 2);
         }
-        cls_out[i] = (uint8_t)cls;
-        has_bg |= (cls == 0);
-        has_fg |= (cls == 2);
-        // trimap2_soft = [tri[:,0], tri[:,2]] (alpha/model.py:51) -> x11 channels 9, 10; one 16-byte store over channels
-        // 8..11: channel 8 (last distance encoding) is written by edt_rows_encode afterwards, 11 is the zero pad
-        *reinterpret_cast<edt_f32x4*>(x11 + i * x11_ld + 8) = edt_f32x4{0.f, p0, p2, 0.f};
-        *reinterpret_cast<edt_f32x2*>(d80 + i * d80_ld + 70) = edt_f32x2{p0, p2};   // two_chan_trimap (FBA/models.py:378, :418)
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+            const int cls = cls_override ? (int)cls_override[i] : argmax3(probs[i], probs[P + i], probs[2 * P + i]);
+            cls_out[i] = (uint8_t)cls;
+            has_bg |= (cls == 0);
+            has_fg |= (cls == 2);
+        }
     }
     // one flag write per class is enough: a wave looks first (L2 read) and only the first arrivals issue the atomic
     // (16 k waves doing an atomicOr on the same two words serialised at L2: 0.16 of the kernel's 0.20 ms)
@@ -49,133 +73,191 @@ __global__ void classify_kernel(const float* __restrict__ probs, int64_t P, cons
         atomicOr(&flags[1], 1);
 }
 
-// phase 1: distance to the nearest class pixel within the column.  A column is cut into EDT_SEG segments, one thread
-// each (a workgroup = 64 columns x EDT_SEG segments, lanes along x: coalesced rows): every thread finds the first and
-// last seed of its segment, the carries (nearest seed above / below the segment) come from the other segments'
-// entries in LDS, then a down-scan and an up-scan over the segment write g.  (One thread per whole column -- 3840
-// threads at 1080p -- took 0.43 ms; integer arithmetic, same result.)
-constexpr int EDT_SEG = 16;
+// phase 1: distance to the nearest class pixel within the column, both classes from one read of the class map.  A column
+// is cut into EDT_SEGS segments, one thread each (a workgroup = EDT_XB columns x EDT_SEGS segments, lanes along x).  A
+// thread loads ALL rows of its segment into registers first (<= LEN_MAX independent byte loads in flight -- the first
+// version walked its rows three times with a dependent load per step: 78-108 us at 1080p on 60 workgroups), notes the
+// first / last seed of either class, takes the carries (nearest seed above / below the segment) from the other segments'
+// entries in LDS, and runs the down- and the up-scan in registers.  g: uint16 [2][H][W] (EDT_INF = "no seed in the column").
+constexpr int EDT_SEGS = 64, EDT_XB = 16;
 
-__global__ __launch_bounds__(64 * EDT_SEG) void edt_columns_kernel(const uint8_t* __restrict__ cls, int H, int W,
-                                                                    int* __restrict__ g) {
-    __shared__ int first_s[EDT_SEG][64], last_s[EDT_SEG][64];
-    const int lx = threadIdx.x & 63, seg = threadIdx.x >> 6;
-    const int cols_per_class = (W + 63) / 64;
-    const int k = blockIdx.x / cols_per_class, x = (blockIdx.x - k * cols_per_class) * 64 + lx;
-    const uint8_t target = k == 0 ? 0 : 2;
-    const int len = (H + EDT_SEG - 1) / EDT_SEG;
-    const int y0 = seg * len, y1 = y0 + len < H ? y0 + len : H;
+template <int LEN_MAX>
+__global__ __launch_bounds__(EDT_XB * EDT_SEGS) void edt_columns_kernel(const uint8_t* __restrict__ cls, int H, int W, int len,
+                                                                         uint16_t* __restrict__ g) {
+    __shared__ int first_s[2][EDT_SEGS][EDT_XB], last_s[2][EDT_SEGS][EDT_XB];
+    const int lx = threadIdx.x % EDT_XB, seg = threadIdx.x / EDT_XB;
+    const int x = blockIdx.x * EDT_XB + lx;
+    const int y0 = seg * len;
+    const int y1 = y0 + len < H ? y0 + len : H;            // (y1 <= y0: this segment lies below the image)
     const bool live = x < W;
-    int first = -1, last = -1;
-    if (live) {
-        for (int y = y0; y < y1; ++y) {
-            if (cls[(int64_t)y * W + x] == target) {
-                if (first < 0) first = y;
-                last = y;
+    uint8_t c[LEN_MAX];
+#pragma unroll
+    for (int j = 0; j < LEN_MAX; ++j) {
+        const int y = y0 + j;
+        c[j] = (live && j < len && y < H) ? cls[(int64_t)y * W + x] : (uint8_t)255;
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint8_t target = k == 0 ? 0 : 2;
+        int first = -1, last = -1;
+#pragma unroll
+        for (int j = 0; j < LEN_MAX; ++j) {
+            if (c[j] == target) {
+                if (first < 0) first = y0 + j;
+                last = y0 + j;
             }
         }
+        first_s[k][seg][lx] = first;
+        last_s[k][seg][lx] = last;
     }
-    first_s[seg][lx] = first;
-    last_s[seg][lx] = last;
     __syncthreads();
-    if (!live) return;
-    int above = -1, below = -1;                       // nearest seed rows outside the segment
-    for (int sgm = seg - 1; sgm >= 0 && above < 0; --sgm) above = last_s[sgm][lx];
-    for (int sgm = seg + 1; sgm < EDT_SEG && below < 0; ++sgm) below = first_s[sgm][lx];
-    int* gk = g + (int64_t)k * H * W;
-    int d = above >= 0 ? y0 - 1 - above : EDT_INF;    // distance of row y0-1 to the seed above
-    for (int y = y0; y < y1; ++y) {
-        const bool seed = cls[(int64_t)y * W + x] == target;
-        d = seed ? 0 : (d + 1 > EDT_INF ? EDT_INF : d + 1);
-        gk[(int64_t)y * W + x] = d;
-    }
-    d = below >= 0 ? below - y1 : EDT_INF;            // distance of row y1 to the seed below
-    for (int y = y1 - 1; y >= y0; --y) {
-        const int gv = gk[(int64_t)y * W + x];
-        d = gv == 0 ? 0 : (d + 1 > EDT_INF ? EDT_INF : d + 1);
-        gk[(int64_t)y * W + x] = gv < d ? gv : d;
+    if (!live || y1 <= y0) return;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const uint8_t target = k == 0 ? 0 : 2;
+        int above = -1, below = -1;                       // nearest seed rows outside the segment
+        for (int sgm = seg - 1; sgm >= 0 && above < 0; --sgm) above = last_s[k][sgm][lx];
+        for (int sgm = seg + 1; sgm < EDT_SEGS && below < 0; ++sgm) below = first_s[k][sgm][lx];
+        int dn[LEN_MAX];
+        int d = above >= 0 ? y0 - 1 - above : EDT_INF;    // distance of row y0-1 to the seed above
+#pragma unroll
+        for (int j = 0; j < LEN_MAX; ++j) {
+            d = c[j] == target ? 0 : (d + 1 > EDT_INF ? EDT_INF : d + 1);
+            dn[j] = d;
+        }
+        uint16_t* gk = g + (int64_t)k * H * W + x;
+        d = below >= 0 ? below - y1 : EDT_INF;            // distance of row y1 to the seed below
+#pragma unroll
+        for (int j = LEN_MAX - 1; j >= 0; --j) {
+            if (y0 + j < y1) {
+                d = c[j] == target ? 0 : (d + 1 > EDT_INF ? EDT_INF : d + 1);
+                gk[(int64_t)(y0 + j) * W] = (uint16_t)(dn[j] < d ? dn[j] : d);
+            }
+        }
     }
 }
 
-// phase 2 + encoding: one workgroup per (class, image row).  The row of squared column distances is staged in
-// LDS; every pixel scans outwards, d2(x) = min_dx dx^2 + min(g2[x-dx], g2[x+dx]), and stops as soon as dx^2 >= best
-// -- the trip count equals the pixel's own distance, so the work is sum_x d(x) instead of a serial W-step scan per
-// row (the first version: one thread per row, Meijster's stack in global memory, 1.6 ms at 1080p).  Integer
-// arithmetic throughout: exact.  The three Gaussians of the class are written straight into the x11 slice.
-__global__ __launch_bounds__(256) void edt_rows_encode_kernel(const int* __restrict__ g, int H, int W, const int* __restrict__ flags,
-                                                              float* __restrict__ x11, int x11_ld) {
-    extern __shared__ int g2[];
-    const int k = blockIdx.x / H, y = blockIdx.x - k * H;
+// images taller than EDT_SEGS * 40 rows: one thread per (class, column), two dependent passes (slow, rarely used)
+__global__ void edt_columns_tall_kernel(const uint8_t* __restrict__ cls, int H, int W, uint16_t* __restrict__ g) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, k = blockIdx.y;
+    if (x >= W) return;
+    const uint8_t target = k == 0 ? 0 : 2;
+    uint16_t* gk = g + (int64_t)k * H * W + x;
+    int d = EDT_INF;
+    for (int y = 0; y < H; ++y) {
+        d = cls[(int64_t)y * W + x] == target ? 0 : (d + 1 > EDT_INF ? EDT_INF : d + 1);
+        gk[(int64_t)y * W] = (uint16_t)d;
+    }
+    d = EDT_INF;
+    for (int y = H - 1; y >= 0; --y) {
+        const int gv = gk[(int64_t)y * W];
+        d = gv == 0 ? 0 : (d + 1 > EDT_INF ? EDT_INF : d + 1);
+        gk[(int64_t)y * W] = (uint16_t)(gv < d ? gv : d);
+    }
+}
+
+// phase 2 + encoding: one workgroup per image row, BOTH classes.  The row's squared column distances are staged in LDS;
+// every pixel scans outwards, d2(x) = min_dx dx^2 + min(g2[x-dx], g2[x+dx]), and stops as soon as dx^2 >= best -- the trip
+// count equals the pixel's own distance, so the work is sum_x d(x) instead of a serial W-step scan per row (the first
+// version: one thread per row, Meijster's stack in global memory, 1.6 ms at 1080p).  Integer arithmetic throughout:
+// exact.  A thread then writes the pixel's channels 3..11 of x11 (six Gaussians, the two soft channels
+// trimap2_soft = [tri[:,0], tri[:,2]] (alpha/model.py:51), the zero pad) and two_chan_trimap into d80[70..71]
+// (FBA/models.py:378, :418) in one go.
+__device__ __forceinline__ int edt_row_best(const int* __restrict__ g2, const int* __restrict__ bmin, int W, int nb, int x) {
+    int best = g2[x];
+    // near field: outward scan, stops at dx^2 >= best (the trip count is the pixel's own distance)
+    int dx = 1;
+    for (; dx < 32 && dx * dx < best; ++dx) {
+        const int xl = x - dx, xr = x + dx;
+        int c = EDT_INF * EDT_INF;
+        if (xl >= 0) c = g2[xl];
+        if (xr < W) c = min(c, g2[xr]);
+        best = min(best, dx * dx + c);
+    }
+    if (dx == 32 && dx * dx < best) {
+        // far field: whole 32-column blocks, outwards; a block is skipped when even its best case
+        // (nearest column, smallest g2 of the block) cannot improve -- pixels far from every seed cross the
+        // empty columns in W/32 steps instead of W
+        const int bx = x >> 5;
+        for (int r = 1;; ++r) {
+            bool any = false;
+            const int bl = bx - r, br = bx + r;
+            if (bl >= 0) {
+                const int dm = x - (bl * 32 + 31);
+                if (dm * dm < best) {
+                    any = true;
+                    if (dm * dm + bmin[bl] < best)
+                        for (int i = bl * 32 + 31; i >= bl * 32 && (x - i) * (x - i) < best; --i) best = min(best, (x - i) * (x - i) + g2[i]);
+                }
+            }
+            if (br < nb) {
+                const int dm = br * 32 - x;
+                if (dm * dm < best) {
+                    any = true;
+                    if (dm * dm + bmin[br] < best) {
+                        const int e = br * 32 + 32 < W ? br * 32 + 32 : W;
+                        for (int i = br * 32; i < e && (i - x) * (i - x) < best; ++i) best = min(best, (i - x) * (i - x) + g2[i]);
+                    }
+                }
+            }
+            if (!any) break;
+        }
+    }
+    return best;
+}
+
+__global__ __launch_bounds__(256) void edt_rows_encode_kernel(const uint16_t* __restrict__ g, const float* __restrict__ probs,
+                                                              int H, int W, const int* __restrict__ flags,
+                                                              float* __restrict__ x11, int x11_ld, float* __restrict__ d80, int d80_ld) {
+    extern __shared__ int lds[];
+    const int y = blockIdx.x;
+    const int nb = (W + 31) >> 5;
+    int* g2[2] = {lds, lds + W};
+    int* bmin[2] = {lds + 2 * W, lds + 2 * W + nb};        // min of g2 over each 32-column block
     const float den0 = (float)(2.0 * ((0.02 * 320) * (0.02 * 320)));   // 2*((sigma*L)^2), utils/utils.py:33-37
     const float den1 = (float)(2.0 * ((0.08 * 320) * (0.08 * 320)));
     const float den2 = (float)(2.0 * ((0.16 * 320) * (0.16 * 320)));
-    float* dst = x11 + (int64_t)y * W * x11_ld + 3 + 3 * k;
-    if (!flags[k]) {                                   // empty class -> zeros (utils/utils.py:32)
+    const int64_t P = (int64_t)H * W, row = (int64_t)y * W;
+    const bool on[2] = {flags[0] != 0, flags[1] != 0};     // empty class -> zeros (utils/utils.py:32)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!on[k]) continue;
+        const uint16_t* gr = g + (int64_t)k * P + row;
         for (int x = threadIdx.x; x < W; x += blockDim.x) {
-            dst[(int64_t)x * x11_ld] = 0.f; dst[(int64_t)x * x11_ld + 1] = 0.f; dst[(int64_t)x * x11_ld + 2] = 0.f;
+            const int v = gr[x];
+            g2[k][x] = v * v;
         }
-        return;
-    }
-    const int* gr = g + ((int64_t)k * H + y) * W;
-    const int nb = (W + 31) >> 5;
-    int* bmin = g2 + W;                                // min of g2 over each 32-column block
-    for (int x = threadIdx.x; x < W; x += blockDim.x) {
-        const int v = gr[x];
-        g2[x] = v * v;
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
-        int m = EDT_INF * EDT_INF;
-        const int e = b * 32 + 32 < W ? b * 32 + 32 : W;
-        for (int i = b * 32; i < e; ++i) m = min(m, g2[i]);
-        bmin[b] = m;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!on[k]) continue;
+        for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+            int m = EDT_INF * EDT_INF;
+            const int e = b * 32 + 32 < W ? b * 32 + 32 : W;
+            for (int i = b * 32; i < e; ++i) m = min(m, g2[k][i]);
+            bmin[k][b] = m;
+        }
     }
     __syncthreads();
     for (int x = threadIdx.x; x < W; x += blockDim.x) {
-        int best = g2[x];
-        // near field: outward scan, stops at dx^2 >= best (the trip count is the pixel's own distance)
-        int dx = 1;
-        for (; dx < 32 && dx * dx < best; ++dx) {
-            const int xl = x - dx, xr = x + dx;
-            int c = EDT_INF * EDT_INF;
-            if (xl >= 0) c = g2[xl];
-            if (xr < W) c = min(c, g2[xr]);
-            best = min(best, dx * dx + c);
-        }
-        if (dx == 32 && dx * dx < best) {
-            // far field: whole 32-column blocks, outwards; a block is skipped when even its best case
-            // (nearest column, smallest g2 of the block) cannot improve -- pixels far from every seed cross the
-            // empty columns in W/32 steps instead of W
-            const int bx = x >> 5;
-            for (int r = 1;; ++r) {
-                bool any = false;
-                const int bl = bx - r, br = bx + r;
-                if (bl >= 0) {
-                    const int dm = x - (bl * 32 + 31);
-                    if (dm * dm < best) {
-                        any = true;
-                        if (dm * dm + bmin[bl] < best)
-                            for (int i = bl * 32; i < bl * 32 + 32; ++i) best = min(best, (x - i) * (x - i) + g2[i]);
-                    }
-                }
-                if (br < nb) {
-                    const int dm = br * 32 - x;
-                    if (dm * dm < best) {
-                        any = true;
-                        if (dm * dm + bmin[br] < best) {
-                            const int e = br * 32 + 32 < W ? br * 32 + 32 : W;
-                            for (int i = br * 32; i < e; ++i) best = min(best, (i - x) * (i - x) + g2[i]);
-                        }
-                    }
-                }
-                if (!any) break;
+        float e[6];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (on[k]) {
+                const float d = sqrtf((float)edt_row_best(g2[k], bmin[k], W, nb, x));
+                const float v = -(d * d);                  // -dt(1 - tk)**2
+                e[3 * k] = expf(v / den0); e[3 * k + 1] = expf(v / den1); e[3 * k + 2] = expf(v / den2);
+            } else {
+                e[3 * k] = 0.f; e[3 * k + 1] = 0.f; e[3 * k + 2] = 0.f;
             }
         }
-        const float d = sqrtf((float)best);
-        const float v = -(d * d);                      // -dt(1 - tk)**2
-        dst[(int64_t)x * x11_ld] = expf(v / den0);
-        dst[(int64_t)x * x11_ld + 1] = expf(v / den1);
-        dst[(int64_t)x * x11_ld + 2] = expf(v / den2);
+        const float p0 = probs[row + x], p2 = probs[2 * P + row + x];
+        float* dst = x11 + (row + x) * x11_ld;
+        dst[3] = e[0];
+        *reinterpret_cast<edt_f32x4*>(dst + 4) = edt_f32x4{e[1], e[2], e[3], e[4]};
+        *reinterpret_cast<edt_f32x4*>(dst + 8) = edt_f32x4{e[5], p0, p2, 0.f};
+        *reinterpret_cast<edt_f32x2*>(d80 + (row + x) * d80_ld + 70) = edt_f32x2{p0, p2};
     }
 }
 
@@ -183,7 +265,7 @@ __global__ __launch_bounds__(256) void edt_rows_encode_kernel(const int* __restr
 
 extern "C" int64_t otvm_trimap_encode_ws_bytes(int Hp, int Wp) {
     const int64_t P = (int64_t)Hp * Wp;
-    return 256 + (2 * P) * 4;         // flags | g   (int32, 2 classes)
+    return 256 + (2 * P) * 4;         // flags | g (the kernels use 2 x P x uint16; the size is kept from ABI <= 16)
 }
 
 extern "C" int otvm_trimap_encode(const float* probs, int Hp, int Wp, const uint8_t* cls_override, uint8_t* cls_out,
@@ -195,15 +277,19 @@ extern "C" int otvm_trimap_encode(const float* probs, int Hp, int Wp, const uint
     hipStream_t s = (hipStream_t)stream;
     const int64_t P = (int64_t)Hp * Wp;
     int* flags = (int*)ws;
-    int* g = (int*)((char*)ws + 256);
+    uint16_t* g = (uint16_t*)((char*)ws + 256);
     if (hipMemsetAsync(flags, 0, 256, s) != hipSuccess) { otvm_set_error("otvm_trimap_encode: memset failed"); return 2; }
-    int64_t nb = (P + 255) / 256;
-    const int grid = (int)(nb > 4096 ? 4096 : nb);
-    hipLaunchKernelGGL(classify_kernel, dim3(grid), dim3(256), 0, s, probs, P, cls_override, cls_out, flags, x11, x11_ld, d80,
-                       d80_ld);
-    hipLaunchKernelGGL(edt_columns_kernel, dim3(2 * otvm_ceil_div(Wp, 64)), dim3(64 * EDT_SEG), 0, s, cls_out, Hp, Wp, g);
-    hipLaunchKernelGGL(edt_rows_encode_kernel, dim3(2 * Hp), dim3(256), (Wp + (Wp + 31) / 32) * sizeof(int), s, g, Hp, Wp, flags,
-                       x11, x11_ld);
+    int64_t nb = (P / 4 + 255) / 256;
+    const int grid = (int)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb));
+    hipLaunchKernelGGL(classify_kernel, dim3(grid), dim3(256), 0, s, probs, P, cls_override, cls_out, flags);
+    const int len = otvm_ceil_div(Hp, EDT_SEGS);
+    const dim3 cgrid(otvm_ceil_div(Wp, EDT_XB)), cblock(EDT_XB * EDT_SEGS);
+    if (len <= 8) hipLaunchKernelGGL(edt_columns_kernel<8>, cgrid, cblock, 0, s, cls_out, Hp, Wp, len, g);
+    else if (len <= 20) hipLaunchKernelGGL(edt_columns_kernel<20>, cgrid, cblock, 0, s, cls_out, Hp, Wp, len, g);
+    else if (len <= 40) hipLaunchKernelGGL(edt_columns_kernel<40>, cgrid, cblock, 0, s, cls_out, Hp, Wp, len, g);
+    else hipLaunchKernelGGL(edt_columns_tall_kernel, dim3(otvm_ceil_div(Wp, 64), 2), dim3(64), 0, s, cls_out, Hp, Wp, g);
+    hipLaunchKernelGGL(edt_rows_encode_kernel, dim3(Hp), dim3(256), 2 * (Wp + (Wp + 31) / 32) * sizeof(int), s, g, probs, Hp, Wp,
+                       flags, x11, x11_ld, d80, d80_ld);
     OTVM_CHECK_LAUNCH("otvm_trimap_encode");
     return 0;
 }

@@ -168,6 +168,7 @@ __global__ __launch_bounds__(256) void upsample2x_bilinear_kernel(const float* _
 // sums over the 12 column bins (1 + 2 + 3 + 6); a second, tiny kernel adds the rows of every bin in a fixed order.
 // (The first version read the 2048-channel map once per scale: 4 x 267 MB, 0.33 ms at 1080p.)
 constexpr int PPM_XBINS = 12;
+constexpr int PPM_MAXSEG = 24;
 
 __device__ __forceinline__ void ppm_scale(int bin, int& s, int& base, int& xbase) {
     if (bin < 1) { s = 1; base = 0; xbase = 0; }
@@ -176,31 +177,38 @@ __device__ __forceinline__ void ppm_scale(int bin, int& s, int& base, int& xbase
     else { s = 6; base = 14; xbase = 6; }
 }
 
+// Round 4: the 12 column bins of a row overlap and nest, so the row is cut at every bin boundary into elementary segments
+// (<= 23; at W = 240: six of 40 columns) -- a thread adds the pixels of a segment into ONE accumulator, without a
+// predicate per bin (the first version tested every pixel against all 12 bins: ~130 VALU operations per 16-byte load, 99 us
+// for a 267 MB read), and the segment's sum then goes to the bins that contain it (mask, wave-uniform).
+struct PpmSegs { int nseg; int b[PPM_MAXSEG + 1]; unsigned short mask[PPM_MAXSEG]; };
+
 __global__ __launch_bounds__(256) void ppm_pool_rows_kernel(const float* __restrict__ in, int H, int W, int C, int ld,
-                                                            float* __restrict__ rowsum) {
+                                                            float* __restrict__ rowsum, const PpmSegs sg) {
     const int y = blockIdx.x;
     const int q = threadIdx.x & 63, lanep = threadIdx.x >> 6;
     const int c = blockIdx.y * 256 + q * 4;
-    int x0[PPM_XBINS], x1[PPM_XBINS];
-    {
-        const int sc[4] = {1, 2, 3, 6};
-        int j = 0;
-        for (int k = 0; k < 4; ++k)
-            for (int bx = 0; bx < sc[k]; ++bx, ++j) {
-                x0[j] = (bx * W) / sc[k];
-                x1[j] = ((bx + 1) * W + sc[k] - 1) / sc[k];
-            }
-    }
     f32x4 acc[PPM_XBINS];
 #pragma unroll
     for (int j = 0; j < PPM_XBINS; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     if (c < C) {
         const float* row = in + (int64_t)y * W * ld + c;
-        for (int x = lanep; x < W; x += 4) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(row + (int64_t)x * ld);
+        for (int i = 0; i < sg.nseg; ++i) {
+            const int x1 = sg.b[i + 1];
+            f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
+            int x = sg.b[i] + lanep;
+            for (; x + 12 < x1; x += 16) {                  // four independent loads in flight per thread
+                a0 += *reinterpret_cast<const f32x4*>(row + (int64_t)x * ld);
+                a1 += *reinterpret_cast<const f32x4*>(row + (int64_t)(x + 4) * ld);
+                a2 += *reinterpret_cast<const f32x4*>(row + (int64_t)(x + 8) * ld);
+                a3 += *reinterpret_cast<const f32x4*>(row + (int64_t)(x + 12) * ld);
+            }
+            for (; x < x1; x += 4) a0 += *reinterpret_cast<const f32x4*>(row + (int64_t)x * ld);
+            const f32x4 t = (a0 + a1) + (a2 + a3);
+            const unsigned m = sg.mask[i];
 #pragma unroll
-            for (int j = 0; j < PPM_XBINS; ++j) acc[j] += (x >= x0[j] && x < x1[j]) ? v : zero;
+            for (int j = 0; j < PPM_XBINS; ++j)
+                if ((m >> j) & 1u) acc[j] += t;
         }
     }
     __shared__ f32x4 red[PPM_XBINS][256];
@@ -215,7 +223,8 @@ __global__ __launch_bounds__(256) void ppm_pool_rows_kernel(const float* __restr
     }
 }
 
-__global__ void ppm_pool_final_kernel(const float* __restrict__ rowsum, int H, int W, int C, float* __restrict__ out) {
+// rows of every bin added in a fixed order: four row phases per workgroup (independent loads in flight), then (r0 + r1) + (r2 + r3)
+__global__ __launch_bounds__(256) void ppm_pool_final_kernel(const float* __restrict__ rowsum, int H, int W, int C, float* __restrict__ out) {
     const int bin = blockIdx.x;
     int s, base, xbase;
     ppm_scale(bin, s, base, xbase);
@@ -223,11 +232,16 @@ __global__ void ppm_pool_final_kernel(const float* __restrict__ rowsum, int H, i
     const int y0 = (by * H) / s, y1 = ((by + 1) * H + s - 1) / s;
     const int x0 = (bx * W) / s, x1 = ((bx + 1) * W + s - 1) / s;
     const float inv = 1.f / (float)((y1 - y0) * (x1 - x0));
-    for (int c = (blockIdx.y * blockDim.x + threadIdx.x) * 4; c < C; c += gridDim.y * blockDim.x * 4) {
-        f32x4 t = {0.f, 0.f, 0.f, 0.f};
-        for (int y = y0; y < y1; ++y) t += *reinterpret_cast<const f32x4*>(rowsum + ((int64_t)y * PPM_XBINS + xbase + bx) * C + c);
-        *reinterpret_cast<f32x4*>(out + (int64_t)bin * C + c) = t * inv;
-    }
+    const int q = threadIdx.x & 63, rp = threadIdx.x >> 6;
+    const int c = blockIdx.y * 256 + q * 4;
+    __shared__ f32x4 red[256];
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (c < C)
+        for (int y = y0 + rp; y < y1; y += 4) t += *reinterpret_cast<const f32x4*>(rowsum + ((int64_t)y * PPM_XBINS + xbase + bx) * C + c);
+    red[threadIdx.x] = t;
+    __syncthreads();
+    if (rp == 0 && c < C)
+        *reinterpret_cast<f32x4*>(out + (int64_t)bin * C + c) = ((red[q] + red[q + 64]) + (red[q + 128] + red[q + 192])) * inv;
 }
 
 }  // namespace
@@ -291,22 +305,52 @@ extern "C" int64_t otvm_ppm_pool_ws_bytes(int H, int C) { return (int64_t)H * PP
 
 extern "C" int otvm_ppm_pool(const float* in, int H, int W, int C, int ld, float* out, void* ws, void* stream) {
     OTVM_REQUIRE(C % 4 == 0 && ld % 4 == 0 && ws, "otvm_ppm_pool: channels must be multiples of 4, ws required");
+    // elementary segments of a row: cut at every boundary of the 12 column bins
+    PpmSegs sg;
+    int x0[PPM_XBINS], x1[PPM_XBINS], cuts[2 * PPM_XBINS], ncut = 0;
+    {
+        const int sc[4] = {1, 2, 3, 6};
+        int j = 0;
+        for (int k = 0; k < 4; ++k)
+            for (int bx = 0; bx < sc[k]; ++bx, ++j) {
+                x0[j] = (bx * W) / sc[k];
+                x1[j] = ((bx + 1) * W + sc[k] - 1) / sc[k];
+                cuts[ncut++] = x0[j];
+                cuts[ncut++] = x1[j];
+            }
+    }
+    for (int i = 1; i < ncut; ++i)                                  // insertion sort, then unique
+        for (int k = i; k > 0 && cuts[k] < cuts[k - 1]; --k) { const int t = cuts[k]; cuts[k] = cuts[k - 1]; cuts[k - 1] = t; }
+    int nu = 0;
+    for (int i = 0; i < ncut; ++i)
+        if (nu == 0 || cuts[i] != cuts[nu - 1]) cuts[nu++] = cuts[i];
+    sg.nseg = nu - 1;
+    OTVM_REQUIRE(sg.nseg >= 1 && sg.nseg <= PPM_MAXSEG, "otvm_ppm_pool: %d row segments", sg.nseg);
+    for (int i = 0; i <= sg.nseg; ++i) sg.b[i] = cuts[i];
+    for (int i = 0; i < sg.nseg; ++i) {
+        unsigned m = 0;
+        for (int j = 0; j < PPM_XBINS; ++j)
+            if (x0[j] <= cuts[i] && cuts[i + 1] <= x1[j]) m |= 1u << j;
+        sg.mask[i] = (unsigned short)m;
+    }
     hipLaunchKernelGGL(ppm_pool_rows_kernel, dim3(H, otvm_ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, in, H, W, C,
-                       ld, (float*)ws);
-    hipLaunchKernelGGL(ppm_pool_final_kernel, dim3(50, otvm_ceil_div(C, 1024)), dim3(256), 0, (hipStream_t)stream,
+                       ld, (float*)ws, sg);
+    hipLaunchKernelGGL(ppm_pool_final_kernel, dim3(50, otvm_ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float*)ws, H, W, C, out);
     OTVM_CHECK_LAUNCH("otvm_ppm_pool");
     return 0;
 }
 
-// ---- the four PPM heads in ONE launch (FBA/models.py:298-307, 357-361): for each pooled map (1x1, 2x2, 3x3, 6x6 = 50
+// ---- the four PPM heads in ONE library call (FBA/models.py:298-307, 357-361): for each pooled map (1x1, 2x2, 3x3, 6x6 = 50
 // pixels of 2048 channels) a 1x1 convolution to 256 channels (+bias), GroupNorm(32) over the map, LeakyReLU.  As separate
-// library calls that is 4 x (split-K conv + reduction + statistics + table) = 16 launches of a few microseconds of work
-// each on a serial chain; here a workgroup owns one GroupNorm group (8 channels) of one map: the 256 threads split the
-// 2048 input channels, keep their slice of the 8 filters in registers, and reduce per (pixel, channel) through lane
-// shuffles and LDS; the group's mean / variance are taken in fp64 over its <= 288 values.  fp32 FMA arithmetic (exact
-// products, fp32 accumulate): the same class as the matrix-core paths.  (First version: 32 lanes per channel, one pixel
-// at a time -- 2304 dependent-latency loads per lane on the 6x6 map, slower than the 16 launches it replaced.)
+// conv / statistics / table launches that was 16 launches of a few microseconds of work each on a serial chain.
+// Round 2 made it one launch of 128 workgroups (a workgroup = one GroupNorm group of one map: 70 us, the 6x6 map's 32
+// workgroups walking 36 pixels with six lane shuffles per (pixel, channel)).  Round 4: the convolution is spread over the
+// chip -- a workgroup = up to four pooled pixels of one branch x 16 output channels, a wave = four of those channels: every
+// weight row is read once per workgroup with coalesced 16-byte loads (lane = four consecutive k) and used for the
+// workgroup's pixels, whose 2048 values sit in registers; one wave reduction per (pixel, channel) -- and the normalisation
+// (288 values per group at most) follows as a second, tiny kernel.  fp32 FMA arithmetic (exact products, fp32 accumulate):
+// the same class as the matrix-core paths.
 namespace {
 
 struct PpmHeadArgs {
@@ -315,66 +359,88 @@ struct PpmHeadArgs {
     int out_ld, act;
 };
 
-__global__ __launch_bounds__(256) void ppm_head_kernel(const PpmHeadArgs p) {
-    constexpr int C = 2048, KT = C / 256, PB = 4;               // k values per thread; pixels per batch
+constexpr int PPMH_GROUPS = 14;       // pixel groups: 1x1 -> {1}; 2x2 -> {4}; 3x3 -> {3,3,3}; 6x6 -> 9 x {4}
+constexpr int PPMH_CB = 16;           // output channels per workgroup
+
+__global__ __launch_bounds__(256) void ppm_head_conv_kernel(const PpmHeadArgs p) {
+    constexpr int C = 2048, KJ = C / 256;                       // float4 per lane and row
+    const int pg = blockIdx.x, cb = blockIdx.y;
+    int br, px0, npx;
+    if (pg < 1) { br = 0; px0 = 0; npx = 1; }
+    else if (pg < 2) { br = 1; px0 = 0; npx = 4; }
+    else if (pg < 5) { br = 2; px0 = (pg - 2) * 3; npx = 3; }
+    else { br = 3; px0 = (pg - 5) * 4; npx = 4; }
+    const int base = br == 0 ? 0 : (br == 1 ? 1 : (br == 2 ? 5 : 14));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 xv[4][KJ];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int px = q < npx ? px0 + q : px0;                  // tail: re-read the first pixel, results dropped
+        const float* x = p.pooled + (int64_t)(base + px) * C + lane * 4;
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) xv[q][j] = *reinterpret_cast<const f32x4*>(x + 256 * j);
+    }
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+        const int c = cb * PPMH_CB + wave * 4 + ch;
+        const float* wr = p.w[br] + (int64_t)c * p.K_pad + lane * 4;
+        f32x4 wv[KJ];
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) wv[j] = *reinterpret_cast<const f32x4*>(wr + 256 * j);
+        float a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < KJ; ++j) {
+                t.x = fmaf(wv[j].x, xv[q][j].x, t.x); t.y = fmaf(wv[j].y, xv[q][j].y, t.y);
+                t.z = fmaf(wv[j].z, xv[q][j].z, t.z); t.w = fmaf(wv[j].w, xv[q][j].w, t.w);
+            }
+            a[q] = (t.x + t.y) + (t.z + t.w);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] += __shfl_xor(a[q], off);
+        if (lane < npx) {
+            const float v = (lane == 0 ? a[0] : (lane == 1 ? a[1] : (lane == 2 ? a[2] : a[3]))) + (p.bias[br] ? p.bias[br][c] : 0.f);
+            p.out[br][(int64_t)(px0 + lane) * p.out_ld + c] = v;
+        }
+    }
+}
+
+// GroupNorm(32) + activation of the four maps in place: a workgroup (one wave) = one group (8 channels) of one map
+__global__ __launch_bounds__(64) void ppm_head_norm_kernel(const PpmHeadArgs p) {
     const int g = blockIdx.x, br = blockIdx.y;
     const int s = br == 0 ? 1 : (br == 1 ? 2 : (br == 2 ? 3 : 6));
-    const int base = br == 0 ? 0 : (br == 1 ? 1 : (br == 2 ? 5 : 14));
-    const int P = s * s;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ float part[4][36 * 8];                           // per wave: partial dot products [pixel][channel]
-    __shared__ float val[36 * 8];
-    __shared__ float mean_s, rstd_s;
-    // thread t owns k = t, t + 256, ...: the 8 filters' weights at those k stay in registers (64 values); a pooled pixel
-    // costs 8 coalesced loads per thread, used for all 8 channels; 4 pixels (32 loads) are in flight at a time
-    float wr[8][KT];
+    const int n = s * s * 8, lane = threadIdx.x;
+    float v[5];                                                  // 288 values at most
+    double sm = 0.0, sq = 0.0;
 #pragma unroll
-    for (int ch = 0; ch < 8; ++ch)
+    for (int k = 0; k < 5; ++k) {
+        const int i = lane + 64 * k;
+        v[k] = i < n ? p.out[br][(int64_t)(i >> 3) * p.out_ld + g * 8 + (i & 7)] : 0.f;
+        sm += (double)v[k];
+        sq += (double)v[k] * (double)v[k];
+    }
 #pragma unroll
-        for (int j = 0; j < KT; ++j) wr[ch][j] = p.w[br][(int64_t)(g * 8 + ch) * p.K_pad + tid + 256 * j];
-    for (int p0 = 0; p0 < P; p0 += PB) {
-        float xv[PB][KT];
+    for (int off = 32; off > 0; off >>= 1) {
+        sm += __shfl_xor(sm, off);
+        sq += __shfl_xor(sq, off);
+    }
+    const double cnt = (double)n, mean = sm / cnt;
+    double var = sq / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float mean_s = (float)mean, rstd_s = (float)(1.0 / sqrt(var + 1e-5));
 #pragma unroll
-        for (int q = 0; q < PB; ++q) {
-            const int px = p0 + q < P ? p0 + q : P - 1;         // tail: re-read the last pixel, results dropped
-            const float* x = p.pooled + (int64_t)(base + px) * C + tid;
-#pragma unroll
-            for (int j = 0; j < KT; ++j) xv[q][j] = x[256 * j];
+    for (int k = 0; k < 5; ++k) {
+        const int i = lane + 64 * k;
+        if (i < n) {
+            const int cc = g * 8 + (i & 7);
+            const float a = rstd_s * p.gamma[br][cc];
+            const float b = p.beta[br][cc] - mean_s * a;
+            p.out[br][(int64_t)(i >> 3) * p.out_ld + cc] = otvm_act(v[k] * a + b, p.act);
         }
-#pragma unroll
-        for (int q = 0; q < PB; ++q) {
-#pragma unroll
-            for (int ch = 0; ch < 8; ++ch) {
-                float a = 0.f;
-#pragma unroll
-                for (int j = 0; j < KT; ++j) a = fmaf(wr[ch][j], xv[q][j], a);
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
-                if (lane == 0 && p0 + q < P) part[wave][(p0 + q) * 8 + ch] = a;
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = tid; i < P * 8; i += 256) {
-        const int c = g * 8 + (i & 7);
-        val[i] = ((part[0][i] + part[1][i]) + (part[2][i] + part[3][i])) + (p.bias[br] ? p.bias[br][c] : 0.f);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        double sm = 0.0, sq = 0.0;
-        for (int i = 0; i < P * 8; ++i) { const double v = val[i]; sm += v; sq += v * v; }
-        const double cnt = (double)(P * 8), mean = sm / cnt;
-        double var = sq / cnt - mean * mean;
-        if (var < 0.0) var = 0.0;
-        mean_s = (float)mean;
-        rstd_s = (float)(1.0 / sqrt(var + 1e-5));
-    }
-    __syncthreads();
-    for (int i = tid; i < P * 8; i += 256) {
-        const int px = i >> 3, cc = g * 8 + (i & 7);
-        const float a = rstd_s * p.gamma[br][cc];
-        const float b = p.beta[br][cc] - mean_s * a;
-        p.out[br][(int64_t)px * p.out_ld + cc] = otvm_act(val[i] * a + b, p.act);
     }
 }
 
@@ -383,13 +449,16 @@ __global__ __launch_bounds__(256) void ppm_head_kernel(const PpmHeadArgs p) {
 extern "C" int otvm_ppm_head(const otvm_ppm_head_params* q, void* stream) {
     OTVM_REQUIRE(q && q->pooled && q->C == 2048 && q->K_pad >= 2048 && q->Cout == 256,
                  "otvm_ppm_head: built for 2048 -> 256 channels (got %d -> %d)", q ? q->C : 0, q ? q->Cout : 0);
+    OTVM_REQUIRE(q->K_pad % 4 == 0 && ((uintptr_t)q->pooled & 15) == 0, "otvm_ppm_head: pooled / weights must be 16-byte aligned");
     PpmHeadArgs a;
     a.pooled = q->pooled; a.K_pad = q->K_pad; a.out_ld = q->out_ld; a.act = q->act;
     for (int i = 0; i < 4; ++i) {
         OTVM_REQUIRE(q->w[i] && q->gamma[i] && q->beta[i] && q->out[i], "otvm_ppm_head: null pointer (branch %d)", i);
+        OTVM_REQUIRE(((uintptr_t)q->w[i] & 15) == 0, "otvm_ppm_head: weights must be 16-byte aligned");
         a.w[i] = q->w[i]; a.bias[i] = q->bias[i]; a.gamma[i] = q->gamma[i]; a.beta[i] = q->beta[i]; a.out[i] = q->out[i];
     }
-    hipLaunchKernelGGL(ppm_head_kernel, dim3(32, 4), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ppm_head_conv_kernel, dim3(PPMH_GROUPS, 256 / PPMH_CB), dim3(256), 0, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(ppm_head_norm_kernel, dim3(32, 4), dim3(64), 0, (hipStream_t)stream, a);
     OTVM_CHECK_LAUNCH("otvm_ppm_head");
     return 0;
 }
@@ -433,88 +502,94 @@ __global__ __launch_bounds__(256) void ppm_z_kernel(const float* __restrict__ y0
     Z[((int64_t)tap * PPMZ_BINS + j) * 256 + o] = (a0 + a1) + (a2 + a3);
 }
 
-// out[p][o] += contribution(p)[o].  grid (pixel blocks, 4 channel groups of 64); a workgroup keeps its 9 x 50 x 64 slice of Z
-// in LDS (112.5 KB) and walks pixels: one wave per pixel (the bilinear index arithmetic is wave-uniform), lane = channel.
-// 16 waves share the slice (one workgroup per CU fits; with 4 waves -- one per SIMD -- every LDS round trip of the 36 tap x
-// scale steps of a pixel was exposed: 467 us at 136x240, rocprof).
-constexpr int PPMA_WAVES = 16;
-__global__ __launch_bounds__(PPMA_WAVES * 64) void ppm_add_kernel(const float* __restrict__ Z, int H, int W, float* __restrict__ out, int out_ld,
-                                                                  double* __restrict__ gn_stats) {
-    extern __shared__ float zs[];                               // [9][50][64]
-    const int g = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < PPMZ_TAPS * PPMZ_BINS * 64; i += PPMA_WAVES * 64) {
-        const int tj = i >> 6, o = i & 63;
-        zs[i] = Z[(int64_t)tj * 256 + g * 64 + o];
-    }
-    __syncthreads();
-    const int P = H * W;
-    float gs = 0.f, gss = 0.f;                                    // GroupNorm(32) sums of this lane's channel over the wave's pixels
-    // the pixel is the same for all lanes of a wave: tell the compiler (scalar index arithmetic), and compute the row terms of
-    // the three filter rows and the column terms of the three filter columns ONCE per scale instead of once per tap
-    for (int pv = blockIdx.x * PPMA_WAVES + wave; pv < P; pv += gridDim.x * PPMA_WAVES) {
-        const int p = __builtin_amdgcn_readfirstlane(pv);
-        const int y = p / W, x = p - y * W;
+// out[p][o] += contribution(p)[o].
+// Round 3's gather kept a 9 x 50 x 64 slice of Z in LDS and evaluated 9 taps x 4 scales x 4 bilinear neighbours per output value
+// (144 LDS reads; 191 us at 136x240, 0.05 of HBM speed).  Bilinear interpolation is separable: for a fixed output ROW y the sum
+// over the three filter rows and the two interpolation rows collapses the table to
+//     R[kx][scale][j][o] = sum_ky [y + ky - 1 inside] sum_{i in {y0, y1}} wy_i * Z[(ky, kx)][scale][i][j][o]      (3 x 12 x channels)
+// and a pixel of that row needs 3 filter columns x 4 scales x 2 interpolation columns = 24 reads.  A workgroup owns an image
+// row and 128 channels: it builds its R (18 KB of LDS; Z comes from L2) and streams the row -- read, add, write, GroupNorm sums.
+constexpr int PPMA_CH = 128;
+__global__ __launch_bounds__(256) void ppm_add_kernel(const float* __restrict__ Z, int H, int W, float* __restrict__ out, int out_ld,
+                                                      double* __restrict__ gn_stats) {
+    __shared__ float R[3 * 12 * PPMA_CH];                       // [kx][column j of the 12 (scale, j) pairs][channel]
+    __shared__ double gred[2 * (PPMA_CH / 8)];
+    const int y = blockIdx.x, c0 = blockIdx.y * PPMA_CH, tid = threadIdx.x;
+    // ---- the row table
+    for (int i = tid; i < 3 * 12 * PPMA_CH; i += 256) {
+        const int ch = i % PPMA_CH, kj = i / PPMA_CH, kx = kj / 12, jc = kj - kx * 12;
+        const int sc = jc < 1 ? 0 : (jc < 3 ? 1 : (jc < 6 ? 2 : 3));
+        const int s = sc == 0 ? 1 : (sc == 1 ? 2 : (sc == 2 ? 3 : 6));
+        const int base = sc == 0 ? 0 : (sc == 1 ? 1 : (sc == 2 ? 5 : 14));
+        const int j = jc - (sc == 0 ? 0 : (sc == 1 ? 1 : (sc == 2 ? 3 : 6)));
+        const float sy = (float)s / (float)H;
         float acc = 0.f;
 #pragma unroll
-        for (int sc = 0; sc < 4; ++sc) {
-            const int s = sc == 0 ? 1 : (sc == 1 ? 2 : (sc == 2 ? 3 : 6));
-            const int base = sc == 0 ? 0 : (sc == 1 ? 1 : (sc == 2 ? 5 : 14));
-            // F.interpolate(bilinear, align_corners=False), as upsample_bilinear_kernel
-            const float sy = (float)s / (float)H, sx = (float)s / (float)W;
-            int ro0[3], ro1[3], co0[3], co1[3];
-            float rl[3], cl[3];
-            bool rok[3], cok[3];
+        for (int ky = 0; ky < 3; ++ky) {
+            const int qy = y + ky - 1;
+            if ((unsigned)qy >= (unsigned)H) continue;            // zero padding of the convolution
+            float fy = ((float)qy + 0.5f) * sy - 0.5f;           // F.interpolate(bilinear, align_corners=False)
+            fy = fy < 0.f ? 0.f : fy;
+            const int y0 = (int)fy, y1 = y0 + (y0 < s - 1 ? 1 : 0);
+            const float ly = fy - (float)y0, hy = 1.f - ly;
+            const float* zt = Z + ((int64_t)(ky * 3 + kx) * PPMZ_BINS + base + j) * 256 + c0 + ch;
+            acc += hy * zt[(int64_t)y0 * s * 256] + ly * zt[(int64_t)y1 * s * 256];
+        }
+        R[i] = acc;
+    }
+    if (tid < 2 * (PPMA_CH / 8)) gred[tid] = 0.0;
+    // ---- the column terms of every source column qx = -1 .. W of the four scales, once per workgroup: (x0 | x1 << 16, lx);
+    // a column outside the image (the convolution's zero padding) gets weight 0 on both neighbours through lx = hx = 0
+    extern __shared__ int2 xt[];                                 // [4][W + 2]
+    for (int i = tid; i < 4 * (W + 2); i += 256) {
+        const int sc = i / (W + 2), qx = i - sc * (W + 2) - 1;
+        const int s = sc == 0 ? 1 : (sc == 1 ? 2 : (sc == 2 ? 3 : 6));
+        float fx = ((float)qx + 0.5f) * ((float)s / (float)W) - 0.5f;   // F.interpolate(bilinear, align_corners=False)
+        fx = fx < 0.f ? 0.f : fx;
+        const int x0 = (int)fx, x1 = x0 + (x0 < s - 1 ? 1 : 0);
+        const bool in = (unsigned)qx < (unsigned)W;
+        xt[i] = int2{in ? (x0 | (x1 << 16)) : 0, in ? __float_as_int(fx - (float)x0) : (int)0x7fc00000};
+    }
+    __syncthreads();
+    // ---- the row: thread = (channel, x phase)
+    const int ch = tid % PPMA_CH, xp = tid / PPMA_CH;
+    float gs = 0.f, gss = 0.f;
+    float* orow = out + (int64_t)y * W * out_ld + c0 + ch;
+    for (int xv = xp; xv < W; xv += 256 / PPMA_CH) {
+        const int x = __builtin_amdgcn_readfirstlane(xv);        // (the same for all lanes of a wave: scalar index arithmetic)
+        const float prev = orow[(int64_t)x * out_ld];
+        float acc = 0.f;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int qy = y + k - 1, qx = x + k - 1;
-                rok[k] = (unsigned)qy < (unsigned)H;               // zero padding of the convolution
-                cok[k] = (unsigned)qx < (unsigned)W;
-                float fy = ((float)qy + 0.5f) * sy - 0.5f, fx = ((float)qx + 0.5f) * sx - 0.5f;
-                fy = fy < 0.f ? 0.f : fy;
-                fx = fx < 0.f ? 0.f : fx;
-                const int y0 = (int)fy, x0 = (int)fx;
-                const int y1 = y0 + (y0 < s - 1 ? 1 : 0), x1 = x0 + (x0 < s - 1 ? 1 : 0);
-                rl[k] = fy - (float)y0;
-                cl[k] = fx - (float)x0;
-                ro0[k] = (base + y0 * s) * 64; ro1[k] = (base + y1 * s) * 64;
-                co0[k] = x0 * 64; co1[k] = x1 * 64;
-            }
+        for (int kx = 0; kx < 3; ++kx) {
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                if (!rok[ky]) continue;
-                const float ly = rl[ky], hy = 1.f - ly;
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    if (!cok[kx]) continue;
-                    const float lx = cl[kx], hx = 1.f - lx;
-                    const float* zt = zs + (ky * 3 + kx) * PPMZ_BINS * 64 + lane;
-                    const float v00 = zt[ro0[ky] + co0[kx]], v01 = zt[ro0[ky] + co1[kx]];
-                    const float v10 = zt[ro1[ky] + co0[kx]], v11 = zt[ro1[ky] + co1[kx]];
-                    acc += hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
-                }
+            for (int sc = 0; sc < 4; ++sc) {
+                const int jb = sc == 0 ? 0 : (sc == 1 ? 1 : (sc == 2 ? 3 : 6));
+                const int2 e = xt[sc * (W + 2) + x + kx];        // source column qx = x + kx - 1
+                const int x0 = e.x & 0xffff, x1 = e.x >> 16;
+                const bool in = e.y != (int)0x7fc00000;
+                const float lx = in ? __int_as_float(e.y) : 0.f, hx = in ? 1.f - lx : 0.f;
+                const float* r = R + (kx * 12 + jb) * PPMA_CH + ch;
+                acc += hx * r[x0 * PPMA_CH] + lx * r[x1 * PPMA_CH];
             }
         }
-        const float v = out[(int64_t)p * out_ld + g * 64 + lane] + acc;
-        out[(int64_t)p * out_ld + g * 64 + lane] = v;
+        const float v = prev + acc;
+        orow[(int64_t)x * out_ld] = v;
         gs += v;
         gss += v * v;
     }
     if (gn_stats) {
-        // 256 channels in 32 groups of 8: lanes 8k .. 8k+7 of this 64-channel slice share group g*8 + k; per-wave partial
-        // sums in fp32 over <= a few dozen pixels, promoted to fp64 for the workgroup (LDS) and device (atomic) reductions
-        __shared__ double gred[16];
-        if (tid < 16) gred[tid] = 0.0;
-        __syncthreads();
+        // 256 channels in 32 groups of 8: lanes 8k .. 8k+7 share a group; per-thread partial sums in fp32 over <= W / 2 pixels,
+        // promoted to fp64 for the workgroup (LDS) and device (atomic) reductions
         for (int off = 1; off < 8; off <<= 1) {
             gs += __shfl_xor(gs, off);
             gss += __shfl_xor(gss, off);
         }
-        if ((lane & 7) == 0) {
-            atomicAdd(&gred[2 * (lane >> 3)], (double)gs);
-            atomicAdd(&gred[2 * (lane >> 3) + 1], (double)gss);
+        if ((tid & 7) == 0) {
+            atomicAdd(&gred[2 * (ch >> 3)], (double)gs);
+            atomicAdd(&gred[2 * (ch >> 3) + 1], (double)gss);
         }
         __syncthreads();
-        if (tid < 16) atomicAdd(&gn_stats[2 * (g * 8 + (tid >> 1)) + (tid & 1)], gred[tid]);
+        if (tid < 2 * (PPMA_CH / 8)) atomicAdd(&gn_stats[2 * (c0 / 8 + (tid >> 1)) + (tid & 1)], gred[tid]);
     }
 }
 
@@ -528,20 +603,9 @@ extern "C" int otvm_ppm_conv_z(const float* const* y, int y_ld, const float* w_p
 
 extern "C" int otvm_ppm_conv_add(const float* Z, int H, int W, float* out, int out_ld, double* gn_stats, void* stream) {
     OTVM_REQUIRE(Z && out && H > 0 && W > 0, "otvm_ppm_conv_add: bad arguments");
-    constexpr int LDS = PPMZ_TAPS * PPMZ_BINS * 64 * (int)sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        const hipError_t e = hipFuncSetAttribute((const void*)ppm_add_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) {
-            otvm_set_error("otvm_ppm_conv_add: cannot reserve %d bytes of LDS: %s", LDS, hipGetErrorString(e));
-            return 2;
-        }
-        attr_set = true;
-    }
-    int bx = otvm_ceil_div((int64_t)H * W, PPMA_WAVES * 8);        // >= 8 pixels per wave
-    if (bx > 64) bx = 64;                                         // 64 x 4 channel groups = one workgroup per CU
-    if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(ppm_add_kernel, dim3(bx, 4), dim3(PPMA_WAVES * 64), LDS, (hipStream_t)stream, Z, H, W, out, out_ld, gn_stats);
+    OTVM_REQUIRE(W + 2 <= 4096, "otvm_ppm_conv_add: map too wide (%d)", W);
+    hipLaunchKernelGGL(ppm_add_kernel, dim3(H, 256 / PPMA_CH), dim3(256), 4 * (W + 2) * sizeof(int2), (hipStream_t)stream, Z, H, W,
+                       out, out_ld, gn_stats);
     OTVM_CHECK_LAUNCH("otvm_ppm_conv_add");
     return 0;
 }

@@ -62,6 +62,19 @@ FUSE_GN_TABLE = os.environ.get("OTVM_FUSE_GN_TABLE", "1") != "0"
 # (csrc/bottleneck_f16x3.hip); f16x3 only.  0 = the three (four) convolution launches of round 2
 FUSE_STM_BLOCK = os.environ.get("OTVM_FUSE_STM_BLOCK", "1") != "0"
 FUSE_PPM_HEAD = os.environ.get("OTVM_PPM_HEAD", "1") != "0"
+# round 4 (ABI 17): the GroupNorm statistics of conv3's OUTPUT in the FBA bottlenecks predicted from its input (channel sums +
+# Gram matrix, csrc/gram.hip), so conv3's epilogue normalises, adds the identity, applies the ReLU and writes the block output:
+# the bn3 apply pass (read raw output + identity, write the block output: 16 passes, 1.25 ms per 1080p frame) is gone.
+# OTVM_GN_PREDICT=0 = round 3's apply passes; OTVM_GN_PREDICT_PASSES=3 = Gram matrix on f16x3 operands instead of fp16;
+# OTVM_GN_PREDICT_DS=0 keeps the apply pass of the four blocks with a projection (their identity is a raw GroupNorm input:
+# conv3's epilogue scales it per channel, otvm_conv_params.res_scale)
+FUSE_GN_PREDICT = os.environ.get("OTVM_GN_PREDICT", "1") != "0"
+GN_PREDICT_PASSES = int(os.environ.get("OTVM_GN_PREDICT_PASSES", "1"))
+GN_PREDICT_DS = os.environ.get("OTVM_GN_PREDICT_DS", "1") != "0"
+# round 4 (ABI 17): the refinement's last BasicBlock ends in bn2 -> (+ identity) -> ReLU with ONE reader, pred.0 (a 3x3 patch
+# conv): its staging normalises, adds the identity and applies the ReLU (otvm_conv_params.in_res) -- the 535 MB block output
+# is never written (one 1.6 GB apply pass less per frame, 535 MB more read by pred.0).  0 = round 3's apply pass
+FUSE_REFINE_TAIL = os.environ.get("OTVM_FUSE_REFINE_TAIL", "1") != "0"
 # round 3: the PPM branches' third of conv_up1.0 computed from the 50 pooled pixels (otvm_ppm_conv_z / _add) instead of
 # convolving their upsampled copies; conv_up1.0 then reads layer 4 only.  OTVM_PPM_ALGEBRA=0 keeps the materialised form.
 PPM_ALGEBRA = os.environ.get("OTVM_PPM_ALGEBRA", "1") != "0"       # the four PPM heads in one launch (otvm_ppm_head)
@@ -253,6 +266,29 @@ def pack_conv_weight(lib, dev, w, ws=False, scale=None, i_pad=None, split=True, 
     return cw
 
 
+def gram_tables(lib, cw):
+    """(Mp fp32 [entries][32], v fp64 [32][Cin]) of a bias-free 1x1 conv for otvm_gn_predict (csrc/gram.hip): per GroupNorm
+    group g of its OUTPUT channels v_g = sum of the group's filters and M_g = sum of their outer products, from the packed
+    (standardised) fp32 weights in float64; M in the block-upper-triangular order of the Gram kernel's partials, off-diagonal
+    blocks doubled (the symmetric half they stand for)."""
+    O_pad = cw.w.numel() // cw.K_pad
+    w = cw.w.view(O_pad, cw.K_pad)[:cw.O, :cw.I].double()               # 1x1: K index = input channel
+    cg, Cin = cw.O // 32, cw.I
+    wg = w.view(32, cg, Cin)
+    v = wg.sum(1).contiguous()                                           # [32][Cin]
+    bs = int(lib.otvm_gram_block(Cin))
+    nb = Cin // bs
+    blocks = []
+    for bi in range(nb):
+        rows = wg[:, :, bi * bs:(bi + 1) * bs]
+        for bj in range(bi, nb):
+            m = torch.einsum("gci,gcj->gij", rows, wg[:, :, bj * bs:(bj + 1) * bs])
+            blocks.append((m if bi == bj else 2.0 * m).reshape(32, bs * bs))
+    mp = torch.cat(blocks, 1).t().float().contiguous()                   # [nblk * bs * bs][32]: entry-major
+    assert mp.shape[0] == int(lib.otvm_gram_entries(Cin))
+    return mp, v
+
+
 def conv_params(x, cw, out, bias=None, stride=1, pad=0, dil=1, act=NONE, in_relu=0, residual=None, precision=L.PREC_F32,
                 in_norm=None, splitk_ws=None):
     """in_norm = (scale_ptr, shift_ptr, act[, floats between the images' tables]): fused normalisation of the input
@@ -349,6 +385,9 @@ class HipEngine:
                                                          cw.w_wfrag.data_ptr(), self._stream()), "pack_wave_weight")
         return cw.w_wfrag
 
+    def _gram_tables(self, cw):
+        return gram_tables(self.lib, cw)
+
     def _fold_bn(self, bn):
         sd = self.sd
         n = sd[bn + ".weight"].numel()
@@ -399,6 +438,15 @@ class HipEngine:
                 for b in range(3):
                     for cname in ("conv1", "conv2", "conv3cat" if b == 0 else "conv3"):
                         self._wave_frag(self.W[enc + "res2.%d.%s" % (b, cname)])
+        # round 4: per bias-free 1x1 conv3 of the FBA bottlenecks the constants that turn its INPUT's channel sums and Gram
+        # matrix into the GroupNorm sums of its output (csrc/gram.hip): v_g = sum of the group's filters, M_g = sum of their
+        # outer products, the latter in the block-upper-triangular order of the Gram kernel's partials (off-diagonal x 2)
+        self.GP = {}
+        if FUSE_GN_PREDICT and self.precision == L.PREC_F16X3:
+            for name, cw in list(self.W.items()):
+                if (name.startswith("NET.encoder.layer") and name.endswith(".conv3") and cw.kh == 1 and cw.kw == 1 and cw.bias is None
+                        and cw.I % 64 == 0 and cw.O % 32 == 0 and cw.I_pad == cw.I):
+                    self.GP[name] = self._gram_tables(cw)
         # Encoder_M stem: conv1_h(hid16) + conv1(rgb) + conv1_m(p_un) + conv1_o(p_fg) + conv1_a(alpha) (STM.py:63-66)
         e = "trimap.model.Encoder_M."
         wcat = torch.cat([sd[e + "conv1_h.weight"], sd[e + "conv1.weight"], sd[e + "conv1_m.weight"],
@@ -858,7 +906,7 @@ class FramePlan:
     def _signature(p):
         return (p.H, p.W, p.Cin, p.in_ld, p.Cout, p.out_ld, p.kh, p.kw, p.stride, p.pad, p.dil, p.in_relu, p.act, int(bool(p.bias)),
                 int(bool(p.residual)), p.res_ld, int(bool(p.gn_stats)), int(bool(p.in_scale)), int(bool(p.splitk_ws)), p.precision,
-                max(1, p.batch))
+                max(1, p.batch), int(bool(p.res_scale)), int(bool(p.in_res)))
 
     def _time_conv(self, p, code, stream, reps=3):
         p.tune = code
@@ -958,18 +1006,24 @@ class FramePlan:
         return [t[b * n:(b + 1) * n] for b in range(self.B)]
 
     # ---- step builders (S = list being filled)
-    def conv(self, S, x, wname, out, stride=1, pad=0, dil=1, act=NONE, in_relu=0, residual=None, in_norm=None):
+    def conv(self, S, x, wname, out, stride=1, pad=0, dil=1, act=NONE, in_relu=0, residual=None, in_norm=None, in_res=None):
+        """in_res (with in_norm): x' = in_act(x * scale + shift + in_res) -- the identity of a residual block whose last apply
+        pass is skipped (otvm_conv_params.in_res; 3x3 patch-kernel layers only)."""
         w = self.e.W[wname]
         assert x.C == w.I_pad, (wname, x.C, w.I_pad)
         Ho = (x.H + 2 * pad - dil * (w.kh - 1) - 1) // stride + 1
         Wo = (x.W + 2 * pad - dil * (w.kw - 1) - 1) // stride + 1
         assert (out.H, out.W) == (Ho, Wo) and out.C >= w.O, (wname, out.H, out.W, Ho, Wo, out.C, w.O)
         p = conv_params(x, w, out, w.bias, stride, pad, dil, act, in_relu, residual, self.e.precision, in_norm, self._ws)
+        if in_res is not None:
+            assert in_norm is not None and (in_res.H, in_res.W) == (x.H, x.W) and in_res.C >= w.I
+            p.in_res, p.in_res_ld, p.in_res_bs = in_res.ptr, in_res.ld, in_res.bs
         self._keep.append(p)
         self._convs.append((p, wname))
         flops = 2 * Ho * Wo * w.O * w.kh * w.kw * w.I * x.B     # algorithmic (un-padded) 2*MAC, all images of the launch
         # algorithmic bytes: read the input once, the weights once, write the output once (+ residual read), fp32
-        abytes = 4 * (x.B * x.H * x.W * w.I + w.O * w.I * w.kh * w.kw + x.B * Ho * Wo * w.O * (2 if residual is not None else 1))
+        abytes = 4 * (x.B * x.H * x.W * w.I * (2 if in_res is not None else 1) + w.O * w.I * w.kh * w.kw
+                      + x.B * Ho * Wo * w.O * (2 if residual is not None else 1))
         S.append((self.lib.otvm_conv2d, (C.byref(p),), "conv " + wname, flops, abytes, (x, out.ch(0, _rup(w.O, 4)) if out.C >= _rup(w.O, 4) else out)))
         return p
 
@@ -1052,6 +1106,10 @@ class FramePlan:
                 elif st[0] == "ppm_add":
                     _, a, b, label = st
                     S[i] = (self.lib.otvm_ppm_conv_add, a + (self._ppm_stats.gn_stats + 8 * b * sbs,), label)
+                elif st[0] == "gn_predict":
+                    _, r, idx, label = st
+                    r.sums, r.sums_bs = base + idx * 512, sbs
+                    S[i] = (self.lib.otvm_gn_predict, (C.byref(r),), label)
                 elif st[0] == "gn_apply":
                     _, q, idx, label = st
                     q.stats, q.stats_bs = base + idx * 512, sbs
@@ -1086,6 +1144,8 @@ class FramePlan:
         cp = self.conv(S, x, p + ".conv1", t1)
         t2 = self.buf("bt2", Ho, Wo, planes)
         cp = self.gn_then_conv(S, t1, p + ".bn1", RELU, cp, p + ".conv2", t2, stride=stride, pad=dil, dil=dil)
+        if self._predicted_tail(S, x, p, planes, stride, has_ds, out, t2, cp):
+            return
         t3 = self.buf("bt3", Ho, Wo, planes * 4)
         if FUSE_GN_APPLY_IGEMM:
             # round 3: bn2's apply pass is folded into conv3's staging (the implicit-GEMM kernels take in_scale / in_shift too)
@@ -1108,6 +1168,63 @@ class FramePlan:
         else:
             idt = x
         self.gn(S, t3, p + ".bn3", RELU, out=out, residual=idt, conv_p=cp3, res_norm=res_norm)
+
+    def _predicted_tail(self, S, x, p, planes, stride, has_ds, out, t2, cp2):
+        """Round 4: bn2 -> conv3 -> bn3 -> (+ identity) -> ReLU of an FBA bottleneck with bn3's statistics PREDICTED from conv3's
+        input (csrc/gram.hip), so conv3's epilogue writes the block output and the apply pass is gone.  Returns False when the
+        block keeps round 3's route (switched off, exact-fp32 path, a conv3 the tables were not built for)."""
+        e, lib, sd = self.e, self.lib, self.e.sd
+        wname = p + ".conv3"
+        gp = e.GP.get(wname) if hasattr(e, "GP") else None
+        if not (FUSE_GN_PREDICT and gp is not None and FUSE_GN_APPLY and FUSE_GN_STATS and FUSE_GN_TABLE and FUSE_GN_APPLY_IGEMM
+                and cp2 is not None and (GN_PREDICT_DS or not has_ds)):
+            return False
+        w = e.W[wname]
+        probe = conv_params(t2, w, out, None, 1, 0, 1, RELU, 0, x, e.precision, (1, 1, RELU))
+        if lib.otvm_conv2d_input_norm_kind(C.byref(probe)) != 2:
+            return False
+        B, C4 = self.B, planes * 4
+        Ho, Wo = t2.H, t2.W
+        sc, sh, nbs = self.gn_table_step(S, t2, p + ".bn2", cp2)         # bn2's table, written by conv2's last workgroup
+        rsc = rsh = None
+        if has_ds:
+            # the identity path first: its GroupNorm (no activation) stays unapplied -- conv3's epilogue multiplies the raw
+            # tensor by its scale (otvm_conv_params.res_scale), the shift joins conv3's bias (otvm_gn_predict.res_shift)
+            idt = self.buf("btd", Ho, Wo, C4)
+            cpd = self.conv(S, x, p + ".downsample.0", idt, stride=stride)
+            rsc, rsh, rnbs = self.gn_table_step(S, idt, p + ".downsample.1", cpd)
+        else:
+            idt = x
+        nk = int(lib.otvm_gram_chunks(t2.P, planes, None))
+        ent = int(lib.otvm_gram_entries(planes))
+        gpart = self.raw("gram_g", B * nk * ent)                         # shared by all blocks of a size (a chain)
+        spart = self.raw("gram_s", B * nk * planes)
+        q = L.GramParams()
+        q.x, q.P, q.C, q.ld = t2.ptr, t2.P, planes, t2.ld
+        q.in_scale, q.in_shift, q.in_act = sc, sh, RELU
+        q.gpart, q.spart, q.passes = gpart.data_ptr(), spart.data_ptr(), GN_PREDICT_PASSES
+        q.batch, q.x_bs, q.norm_bs = B, t2.bs, nbs
+        self._keep.append(q)
+        S.append((lib.otvm_gram_f16, (C.byref(q),), "gram " + p))
+        tab = self.raw("gnpred_" + p, 2 * C4 * B)                        # [B][scale_eff C4 | bias_eff C4]
+        cnt = self.raw("gnpredcnt_" + p, B, torch.int32)
+        r = L.GnPredictParams()
+        r.gpart, r.spart, r.P, r.C, r.Cout = gpart.data_ptr(), spart.data_ptr(), t2.P, planes, C4
+        r.Mp, r.v = gp[0].data_ptr(), gp[1].data_ptr()
+        r.counter = cnt.data_ptr()
+        r.wscale, r.gamma, r.beta = w.w_scale.data_ptr(), sd[p + ".bn3.weight"].data_ptr(), sd[p + ".bn3.bias"].data_ptr()
+        r.res_shift = 0 if rsh is None else rsh
+        r.scale_eff, r.bias_eff = tab.data_ptr(), tab.data_ptr() + 4 * C4
+        r.batch, r.tab_bs, r.rs_bs = B, 2 * C4, 0 if rsh is None else rnbs
+        self._keep.append(r)
+        idx = self.n_gn
+        self.n_gn += 1
+        S.append(("gn_predict", r, idx, "gn_predict " + p))
+        cp3 = self.conv(S, t2, wname, out, in_norm=(sc, sh, RELU, nbs), residual=idt, act=RELU)
+        cp3.w_scale, cp3.bias, cp3.ws_bs = tab.data_ptr(), tab.data_ptr() + 4 * C4, 2 * C4
+        if rsc is not None:
+            cp3.res_scale, cp3.res_scale_bs = rsc, rnbs
+        return True
 
     def bn_bottleneck(self, S, x, p, planes, stride, has_ds, out, tag):
         Ho, Wo = x.H // stride, x.W // stride
@@ -1351,14 +1468,27 @@ class FramePlan:
             x_norm = (sc, sh, LEAKY, nbs)
         else:
             self.gn(S, r0, rf + "conv1.1", LEAKY, conv_p=cp)
+        tail = None
         for l in ("layer1", "layer2"):
             cp = self.conv(S, x, rf + l + ".conv1", t1, pad=1, in_norm=x_norm)
             t2 = self.buf("rt2", Hp, Wp, 64)
             cp = self.gn_then_conv(S, t1, rf + l + ".bn1", RELU, cp, rf + l + ".conv2", t2, pad=1)
+            if l == "layer2" and FUSE_REFINE_TAIL and FUSE_GN_APPLY and FUSE_GN_STATS and x_norm is None:
+                # round 4: layer2's bn2 -> (+ identity) -> ReLU has ONE reader, pred.0: folded into its staging when the
+                # library takes it (otvm_conv_params.in_res) -- the block output is never written
+                w0 = e.W[rf + "pred.0"]
+                probe = conv_params(t2, w0, h32, w0.bias, 1, 1, 1, LEAKY, 0, None, e.precision, (1, 1, RELU))
+                if lib.otvm_conv2d_accepts_input_residual(C.byref(probe)):
+                    sc, sh, nbs = self.gn_table_step(S, t2, rf + l + ".bn2", cp)
+                    tail = (t2, (sc, sh, RELU, nbs), x)
+                    break
             o = self.buf("r_" + l, Hp, Wp, 64)
             self.gn(S, t2, rf + l + ".bn2", RELU, out=o, residual=x, conv_p=cp, res_norm=x_norm)
             x, x_norm = o, None
-        self.conv(S, x, rf + "pred.0", h32, pad=1, act=LEAKY)
+        if tail is not None:
+            self.conv(S, tail[0], rf + "pred.0", h32, pad=1, act=LEAKY, in_norm=tail[1], in_res=tail[2])
+        else:
+            self.conv(S, x, rf + "pred.0", h32, pad=1, act=LEAKY)
         self.steps["fba"] = S
         for par in (0, 1):
             S = []

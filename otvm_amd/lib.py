@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3 = 0, 1
-ABI_VERSION = 16         # include/otvm_hip.h OTVM_ABI_VERSION
+ABI_VERSION = 17         # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -29,7 +29,9 @@ class ConvParams(C.Structure):
                 ("splitk_ws", vp), ("splitk_ws_bytes", i64),
                 ("batch", i32), ("in_bs", i64), ("out_bs", i64), ("res_bs", i64), ("gn_bs", i32), ("norm_bs", i32),
                 ("w_wfrag", vp),
-                ("gn_gamma", vp), ("gn_beta", vp), ("gn_scale_out", vp), ("gn_shift_out", vp), ("gn_counter", vp), ("gn_tab_bs", i32)]
+                ("gn_gamma", vp), ("gn_beta", vp), ("gn_scale_out", vp), ("gn_shift_out", vp), ("gn_counter", vp), ("gn_tab_bs", i32),
+                ("ws_bs", i32), ("res_scale", vp), ("res_scale_bs", i32),
+                ("in_res", vp), ("in_res_ld", i32), ("in_res_bs", i64)]
 
 
 class StmBottleneckParams(C.Structure):
@@ -43,6 +45,18 @@ class GnApplyParams(C.Structure):
                 ("residual", vp), ("res_ld", i32), ("res_scale", vp), ("res_shift", vp), ("res_act", i32), ("act", i32),
                 ("out", vp), ("out_ld", i32),
                 ("batch", i32), ("x_bs", i64), ("res_bs", i64), ("out_bs", i64), ("stats_bs", i32), ("norm_bs", i32)]
+
+
+class GramParams(C.Structure):
+    _fields_ = [("x", vp), ("P", i64), ("C", i32), ("ld", i32), ("in_scale", vp), ("in_shift", vp), ("in_act", i32),
+                ("gpart", vp), ("spart", vp), ("passes", i32), ("batch", i32), ("x_bs", i64), ("norm_bs", i32)]
+
+
+class GnPredictParams(C.Structure):
+    _fields_ = [("gpart", vp), ("spart", vp), ("P", i64), ("C", i32), ("Cout", i32), ("Mp", vp), ("v", vp), ("sums", vp),
+                ("counter", vp), ("wscale", vp), ("gamma", vp), ("beta", vp), ("res_shift", vp),
+                ("scale_eff", vp), ("bias_eff", vp), ("stat_out", vp),
+                ("batch", i32), ("sums_bs", i32), ("tab_bs", i32), ("rs_bs", i32)]
 
 
 class PreprocessParams(C.Structure):
@@ -78,6 +92,7 @@ _PROTOS = {
     "otvm_gn_table": (i32, [vp, i64, i32, vp, vp, vp, vp, vp]),
     "otvm_conv2d_accepts_input_norm": (i32, [C.POINTER(ConvParams)]),
     "otvm_conv2d_input_norm_kind": (i32, [C.POINTER(ConvParams)]),
+    "otvm_conv2d_accepts_input_residual": (i32, [C.POINTER(ConvParams)]),
     "otvm_conv2d_candidates": (i32, [C.POINTER(ConvParams), C.POINTER(i32), i32]),
     "otvm_gn_apply": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, i32, vp]),
     "otvm_maxpool3x3s2": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
@@ -125,6 +140,11 @@ _PROTOS = {
     "otvm_loss_ce3": (i32, [vp, vp, i64, i64, vp, vp]),
     "otvm_finite_guard": (i32, [vp, i64, i32, i32, f32, i32, vp, vp]),
     "otvm_clear": (i32, [vp, i64, vp]),
+    "otvm_gram_block": (i32, [i32]),
+    "otvm_gram_entries": (i64, [i32]),
+    "otvm_gram_chunks": (i32, [i64, i32, C.POINTER(i32)]),
+    "otvm_gram_f16": (i32, [C.POINTER(GramParams), vp]),
+    "otvm_gn_predict": (i32, [C.POINTER(GnPredictParams), vp]),
 }
 
 EXPORTED = sorted(list(_PROTOS) + ["otvm_last_error"])

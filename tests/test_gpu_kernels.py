@@ -1034,6 +1034,161 @@ def test_ppm_conv_algebra_matches_conv_over_upsampled_maps(G):
     assert float((stats.cpu() - ws).abs().max()) <= 1e-5 * float(ws.abs().max())
 
 
+# ---------------------------------------------------------------------------------------------- identity inside the fused input normalisation (ABI 17)
+@pytest.mark.parametrize("Cout,H,W", [(32, 40, 64), (32, 37, 45), (64, 24, 96)])
+def test_conv_input_norm_with_identity(G, Cout, H, W):
+    """otvm_conv_params.in_res: conv3x3(relu(x * scale + shift + identity)) in ONE launch (the refinement's last BasicBlock:
+    bn2 -> += identity -> ReLU -> pred.0, FBA/models.py:425-432 / resnet_GN_WS.py:36-48) == otvm_gn_apply(residual) followed by
+    the plain convolution, bit for bit (same arithmetic per element, same tiles), interior and edge tiles."""
+    from otvm_amd import lib as L
+    from otvm_amd.engine import conv_params
+    lib, st = L.load(), G.stream()
+    Cin = 64
+    x, idt = rnd(1, Cin, H, W, seed=70), rnd(1, Cin, H, W, seed=71).clamp_min(0)
+    w, b = rnd(Cout, Cin, 3, 3, seed=72, scale=1.0 / math.sqrt(Cin * 9)), rnd(Cout, seed=73, scale=0.2)
+    gam, bet = rnd(Cin, seed=74) * 0.2 + 1, rnd(Cin, seed=75) * 0.3
+    xa, ia = G.to_act(x), G.to_act(idt)
+    cw = G.pack_weight(w)
+    bd, gd, btd = b.to(G.DEV), gam.to(G.DEV), bet.to(G.DEV)
+    stats = torch.zeros(64, dtype=torch.float64, device=G.DEV)
+    tab = torch.zeros(2 * Cin, device=G.DEV)
+    L.check(lib.otvm_gn_stats(xa.ptr, H * W, Cin, xa.ld, stats.data_ptr(), st))
+    L.check(lib.otvm_gn_table(stats.data_ptr(), H * W, Cin, gd.data_ptr(), btd.data_ptr(), tab.data_ptr(), tab.data_ptr() + 4 * Cin, st))
+    # reference route: apply pass (+ identity, ReLU), then the convolution
+    xn = G.empty_act(H, W, Cin, fill=0.0)
+    L.check(lib.otvm_gn_apply(xa.ptr, H * W, Cin, xa.ld, stats.data_ptr(), gd.data_ptr(), btd.data_ptr(), ia.ptr, ia.ld, 0, 0, 0, 1,
+                              xn.ptr, xn.ld, st))
+    want = G.empty_act(H, W, Cout)
+    G.conv2d(xn, cw, want, bd, pad=1, act=2, precision=1)
+    got = G.empty_act(H, W, Cout)
+    p = conv_params(xa, cw, got, bd, 1, 1, 1, 2, 0, None, 1, (tab.data_ptr(), tab.data_ptr() + 4 * Cin, 1))
+    p.in_res, p.in_res_ld = ia.ptr, ia.ld
+    assert lib.otvm_conv2d_accepts_input_residual(C.byref(p)) == 1
+    L.check(lib.otvm_conv2d(C.byref(p), st), "conv (in_res)")
+    torch.cuda.synchronize()
+    assert torch.equal(G.from_act(got), G.from_act(want))
+    ref = F.leaky_relu(F.conv2d(F.relu(F.group_norm(x, 32, gam, bet, 1e-5) + idt), w, b, padding=1), 0.01)
+    assert G.maxdiff(G.from_act(got), ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+    # a layer the patch kernel does not take must refuse the field
+    p.dil, p.pad = 2, 2
+    assert lib.otvm_conv2d_accepts_input_residual(C.byref(p)) == 0
+
+
+# ---------------------------------------------------------------------------------------------- predicted GroupNorm statistics (ABI 17)
+PREDICT_CASES = [(64, 256, 272, 480), (128, 512, 136, 240), (256, 1024, 136, 240), (512, 2048, 136, 240), (192, 512, 37, 53)]
+
+
+@pytest.mark.parametrize("passes", [1, 3])
+@pytest.mark.parametrize("planes,C4,H,W", PREDICT_CASES, ids=["%d_%d_%dx%d" % c for c in PREDICT_CASES])
+def test_gn_predict_matches_accumulated_statistics(G, planes, C4, H, W, passes):
+    """otvm_gram_f16 + otvm_gn_predict (csrc/gram.hip): mean / rstd of GroupNorm(conv3(x')) predicted from the channel sums and
+    the Gram matrix of conv3's INPUT x' = relu(GroupNorm(raw)) on the real 1080p bottleneck shapes of the FBA encoder
+    (resnet_GN_WS.py:66-86) -- against the float64 statistics of the float64 convolution AND against the sums conv3's own
+    epilogue accumulates (round 3's route); then the block tail itself: conv3 with the predicted scale / shift in its epilogue
+    + identity + ReLU == conv3 -> otvm_gn_apply(+ identity, ReLU)."""
+    from otvm_amd import lib as L
+    from otvm_amd.engine import Act, conv_params, gram_tables
+    lib, st = L.load(), G.stream()
+    P = H * W
+    g = torch.Generator(device=G.DEV).manual_seed(planes + passes)
+    rawbuf = torch.zeros(P * planes + 16, device=G.DEV)
+    raw = rawbuf[:P * planes].view(P, planes)
+    raw.copy_(torch.randn(P, planes, generator=g, device=G.DEV) * 1.7 + 0.3)
+    sc = (torch.rand(planes, generator=g, device=G.DEV) + 0.5).contiguous()
+    sh = (torch.randn(planes, generator=g, device=G.DEV) * 0.4).contiguous()
+    tab = torch.cat([sc, sh]).contiguous()
+    w = torch.randn(C4, planes, 1, 1, generator=torch.Generator().manual_seed(5)) * 0.2 + 0.05
+    cw = G.pack_weight(w, ws=True)
+    mp, v = gram_tables(lib, cw)
+    gamma = (torch.rand(C4, generator=g, device=G.DEV) + 0.5).contiguous()
+    beta = (torch.randn(C4, generator=g, device=G.DEV) * 0.2).contiguous()
+    # ---- float64 reference of the statistics
+    xp = torch.relu(raw.double() * sc.double() + sh.double())
+    O_pad = cw.w.numel() // cw.K_pad
+    wstd = cw.w.view(O_pad, cw.K_pad)[:C4, :planes].double()
+    y = xp @ wstd.t()
+    cg = C4 // 32
+    yg = y.view(P, 32, cg)
+    mean64 = yg.mean((0, 2))
+    var64 = (yg * yg).mean((0, 2)) - mean64 * mean64
+    rstd64 = 1.0 / torch.sqrt(var64 + 1e-5)
+    # ---- prediction
+    nk = int(lib.otvm_gram_chunks(P, planes, None))
+    ent = int(lib.otvm_gram_entries(planes))
+    gpart = torch.empty(nk * ent, device=G.DEV)
+    spart = torch.empty(nk * planes, device=G.DEV)
+    q = L.GramParams()
+    q.x, q.P, q.C, q.ld = raw.data_ptr(), P, planes, planes
+    q.in_scale, q.in_shift, q.in_act = tab.data_ptr(), tab.data_ptr() + 4 * planes, 1
+    q.gpart, q.spart, q.passes, q.batch = gpart.data_ptr(), spart.data_ptr(), passes, 1
+    L.check(lib.otvm_gram_f16(C.byref(q), st), "gram")
+    sums = torch.zeros(64, dtype=torch.float64, device=G.DEV)
+    cnt = torch.zeros(1, dtype=torch.int32, device=G.DEV)
+    eff = torch.full((2 * C4,), float("nan"), device=G.DEV)
+    stat = torch.zeros(64, device=G.DEV)
+    r = L.GnPredictParams()
+    r.gpart, r.spart, r.P, r.C, r.Cout = gpart.data_ptr(), spart.data_ptr(), P, planes, C4
+    r.Mp, r.v, r.sums, r.counter = mp.data_ptr(), v.data_ptr(), sums.data_ptr(), cnt.data_ptr()
+    r.wscale, r.gamma, r.beta = cw.w_scale.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    r.scale_eff, r.bias_eff, r.stat_out, r.batch = eff.data_ptr(), eff.data_ptr() + 4 * C4, stat.data_ptr(), 1
+    L.check(lib.otvm_gn_predict(C.byref(r), st), "gn_predict")
+    torch.cuda.synchronize()
+    assert int(cnt.item()) == 0 and float(sums.abs().max()) == 0.0          # re-armed
+    mean_p, rstd_p = stat.view(32, 2)[:, 0].double(), stat.view(32, 2)[:, 1].double()
+    std64 = 1.0 / rstd64
+    e_mean = float(((mean_p - mean64).abs() / torch.maximum(mean64.abs(), std64)).max())
+    e_rstd = float(((rstd_p - rstd64).abs() / rstd64).max())
+    # ---- round 3's route: the sums conv3's epilogue accumulates
+    xa = Act(rawbuf, H, W, planes)
+    t3 = G.empty_act(H, W, C4, fill=0.0)
+    stats = torch.zeros(64, dtype=torch.float64, device=G.DEV)
+    G.conv2d(xa, cw, t3, None, precision=1, gn_stats=stats, in_norm=(tab.data_ptr(), tab.data_ptr() + 4 * planes, 1))
+    cntf = float(P * cg)
+    sv = stats.view(32, 2)
+    mean_a = sv[:, 0] / cntf
+    rstd_a = 1.0 / torch.sqrt((sv[:, 1] / cntf - mean_a * mean_a).clamp_min(0) + 1e-5)
+    a_mean = float(((mean_a - mean64).abs() / torch.maximum(mean64.abs(), std64)).max())
+    a_rstd = float(((rstd_a - rstd64).abs() / rstd64).max())
+    d_mean = float(((mean_p - mean_a).abs() / torch.maximum(mean_a.abs(), 1.0 / rstd_a)).max())
+    d_rstd = float(((rstd_p - rstd_a).abs() / rstd_a).max())
+    print("gn_predict %d->%d %dx%d passes %d: predicted vs float64 mean %.2e rstd %.2e | accumulated vs float64 mean %.2e rstd %.2e | "
+          "predicted vs accumulated mean %.2e rstd %.2e" % (planes, C4, H, W, passes, e_mean, e_rstd, a_mean, a_rstd, d_mean, d_rstd))
+    # (mean / rstd leave the kernel as fp32: 6e-8 of rounding each.  One fp16 pass: the operands' rounding noise averages out
+    # over the P * cg values of a group -- 5e-7 .. 9e-7 measured on the 1080p shapes, 4e-6 on the 37 x 53 map)
+    tol = 2.5e-7 if passes == 3 else (1e-6 if P >= 30000 else 1e-5)
+    assert e_mean <= tol and e_rstd <= tol, (e_mean, e_rstd)
+    assert d_mean <= tol and d_rstd <= tol, (d_mean, d_rstd)
+    # ---- the block tail: predicted normalisation in conv3's epilogue == conv3 -> gn_apply(+ identity, ReLU)
+    idt = G.empty_act(H, W, C4, fill=0.0)
+    idt.t[:P * C4].copy_(torch.randn(P * C4, generator=g, device=G.DEV).clamp_min(0))
+    want = G.empty_act(H, W, C4, fill=0.0)
+    L.check(lib.otvm_gn_apply(t3.ptr, P, C4, t3.ld, stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), idt.ptr, idt.ld, 0, 0, 0, 1,
+                              want.ptr, want.ld, st))
+    got = G.empty_act(H, W, C4)
+    p3 = conv_params(xa, cw, got, None, 1, 0, 1, 1, 0, idt, 1, (tab.data_ptr(), tab.data_ptr() + 4 * planes, 1))
+    p3.w_scale, p3.bias = eff.data_ptr(), eff.data_ptr() + 4 * C4
+    L.check(lib.otvm_conv2d(C.byref(p3), st), "conv3 (predicted normalisation)")
+    torch.cuda.synchronize()
+    gv, wv = got.t[:P * C4], want.t[:P * C4]
+    d = float((gv - wv).abs().max())
+    print("   block tail max-abs %.2e (range %.1f)" % (d, float(wv.abs().max())))
+    assert d <= 2e-5 * max(1.0, float(wv.abs().max())), d
+    # ---- a projection block: the identity is a raw GroupNorm input, scaled per channel in the epilogue, its shift in the bias
+    rs_tab = torch.cat([torch.rand(C4, generator=g, device=G.DEV) + 0.5, torch.randn(C4, generator=g, device=G.DEV) * 0.3]).contiguous()
+    want2 = G.empty_act(H, W, C4, fill=0.0)
+    L.check(lib.otvm_gn_apply(t3.ptr, P, C4, t3.ld, stats.data_ptr(), gamma.data_ptr(), beta.data_ptr(), idt.ptr, idt.ld,
+                              rs_tab.data_ptr(), rs_tab.data_ptr() + 4 * C4, 0, 1, want2.ptr, want2.ld, st))
+    L.check(lib.otvm_gram_f16(C.byref(q), st), "gram")
+    r.res_shift = rs_tab.data_ptr() + 4 * C4
+    L.check(lib.otvm_gn_predict(C.byref(r), st), "gn_predict")
+    got2 = G.empty_act(H, W, C4)
+    p3.out, p3.res_scale = got2.ptr, rs_tab.data_ptr()
+    L.check(lib.otvm_conv2d(C.byref(p3), st), "conv3 (predicted normalisation, scaled identity)")
+    torch.cuda.synchronize()
+    d2 = float((got2.t[:P * C4] - want2.t[:P * C4]).abs().max())
+    assert d2 <= 2e-5 * max(1.0, float(want2.t[:P * C4].abs().max())), d2
+
+
 # ---------------------------------------------------------------------------------------------- fused bottleneck (ABI 15)
 @pytest.mark.parametrize("Cin,H,W", [(256, 8, 32), (256, 19, 45), (64, 16, 64), (64, 27, 70), (256, 68, 120)])
 def test_stm_bottleneck_fused_kernel(G, Cin, H, W):
