@@ -239,11 +239,12 @@ int otvm_gn_apply_b(const otvm_gn_apply_params* p, void* stream);
  *                 gpart[k][blk][bs*bs] (bs = otvm_gram_block(C); blocks (bi <= bj) row-major; otvm_gram_entries(C) floats per
  *                 chunk) and the partial channel sums spart[k][C].  passes = 1: operands rounded to fp16 (round to nearest;
  *                 the statistics average the rounding noise out), 3: the f16x3 split of the convolutions.
- * otvm_gn_predict: adds the partials in fp64, contracts them with Mp[entries][32] (fp32, entry-major; off-diagonal blocks
+ * otvm_gn_predict: adds the partials in fp64, contracts them with Mp[32][entries] (fp32, group-major; off-diagonal blocks
  *                 carrying the factor 2 of the symmetric half) and v[32][C] (fp64), and writes  scale_eff[c] = wscale[c] * rstd_g * gamma[c],
  *                 bias_eff[c] = beta[c] - mean_g * rstd_g * gamma[c] (+ res_shift[c])  -- the values the consuming conv takes
- *                 as otvm_conv_params.w_scale / bias.  sums = zeroed [32][2] fp64, counter = zeroed uint32 per image (both
- *                 are left zeroed); stat_out (optional) receives (mean, rstd) per group.  Batched like otvm_gn_*_b.           */
+ *                 as otvm_conv_params.w_scale / bias.  ws = batch * otvm_gn_predict_ws_bytes() of workspace (per-workgroup partial
+ *                 sums, added in a fixed order by the last workgroup: deterministic), counter = zeroed uint32 per image (left
+ *                 zeroed); stat_out (optional) receives (mean, rstd) per group.  Batched like otvm_gn_*_b.                     */
 typedef struct otvm_gram_params {
     const float* x; int64_t P; int C, ld;
     const float* in_scale; const float* in_shift; int in_act;
@@ -256,11 +257,12 @@ int otvm_gram_chunks(int64_t P, int C, int* pch_out);
 int otvm_gram_f16(const otvm_gram_params* p, void* stream);
 typedef struct otvm_gn_predict_params {
     const float* gpart; const float* spart; int64_t P; int C, Cout;
-    const float* Mp; const double* v; double* sums; unsigned* counter;
+    const float* Mp; const double* v; void* ws; unsigned* counter;
     const float* wscale; const float* gamma; const float* beta; const float* res_shift;
     float* scale_eff; float* bias_eff; float* stat_out;
-    int batch, sums_bs, tab_bs, rs_bs;               /* image b: sums + b * sums_bs doubles, tables + b * tab_bs floats */
+    int batch, tab_bs, rs_bs;                        /* image b: tables + b * tab_bs floats, res_shift + b * rs_bs floats */
 } otvm_gn_predict_params;
+int64_t otvm_gn_predict_ws_bytes(void);
 int otvm_gn_predict(const otvm_gn_predict_params* p, void* stream);
 
 /* ---------------------------------------------------------------- pooling / resampling ---------*/

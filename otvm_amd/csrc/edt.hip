@@ -11,6 +11,7 @@
 //                      produces zeros (utils/utils.py:32).
 // Classes: k=0 background (argmax == 0), k=1 foreground (argmax == 2).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -65,12 +66,12 @@ __global__ __launch_bounds__(256) void classify_kernel(const float* __restrict__
             has_fg |= (cls == 2);
         }
     }
-    // one flag write per class is enough: a wave looks first (L2 read) and only the first arrivals issue the atomic
-    // (16 k waves doing an atomicOr on the same two words serialised at L2: 0.16 of the kernel's 0.20 ms)
-    if (__any(has_bg) && (threadIdx.x & 63) == 0 && __hip_atomic_load(&flags[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-        atomicOr(&flags[0], 1);
-    if (__any(has_fg) && (threadIdx.x & 63) == 0 && __hip_atomic_load(&flags[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0)
-        atomicOr(&flags[1], 1);
+    // "class present" flags: plain stores of the same value (idempotent; visible to the next kernel of the stream).  Round 1 used
+    // atomicOr from every wave that found the class, round 2 looked at the flag first -- but in a kernel this short every wave
+    // looks before the first atomic lands, and 8 k atomics on two words serialised at L2: 80-100 us of a kernel that moves
+    // 27 MB (measured with the kernel alone on the device, profiles/r04_glue_probes.txt)
+    if (__any(has_bg) && (threadIdx.x & 63) == 0) flags[0] = 1;
+    if (__any(has_fg) && (threadIdx.x & 63) == 0) flags[1] = 1;
 }
 
 // phase 1: distance to the nearest class pixel within the column, both classes from one read of the class map.  A column
@@ -208,7 +209,8 @@ __device__ __forceinline__ int edt_row_best(const int* __restrict__ g2, const in
 
 __global__ __launch_bounds__(256) void edt_rows_encode_kernel(const uint16_t* __restrict__ g, const float* __restrict__ probs,
                                                               int H, int W, const int* __restrict__ flags,
-                                                              float* __restrict__ x11, int x11_ld, float* __restrict__ d80, int d80_ld) {
+                                                              float* __restrict__ x11, int x11_ld, float* __restrict__ d80, int d80_ld,
+                                                              int dbg) {
     extern __shared__ int lds[];
     const int y = blockIdx.x;
     const int nb = (W + 31) >> 5;
@@ -245,19 +247,22 @@ __global__ __launch_bounds__(256) void edt_rows_encode_kernel(const uint16_t* __
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (on[k]) {
-                const float d = sqrtf((float)edt_row_best(g2[k], bmin[k], W, nb, x));
+                const float d = sqrtf((float)((dbg & 4) ? g2[k][x] : edt_row_best(g2[k], bmin[k], W, nb, x)));
                 const float v = -(d * d);                  // -dt(1 - tk)**2
-                e[3 * k] = expf(v / den0); e[3 * k + 1] = expf(v / den1); e[3 * k + 2] = expf(v / den2);
+                if (dbg & 8) { e[3 * k] = v; e[3 * k + 1] = v + 1.f; e[3 * k + 2] = v + 2.f; }
+                else { e[3 * k] = expf(v / den0); e[3 * k + 1] = expf(v / den1); e[3 * k + 2] = expf(v / den2); }
             } else {
                 e[3 * k] = 0.f; e[3 * k + 1] = 0.f; e[3 * k + 2] = 0.f;
             }
         }
         const float p0 = probs[row + x], p2 = probs[2 * P + row + x];
         float* dst = x11 + (row + x) * x11_ld;
-        dst[3] = e[0];
-        *reinterpret_cast<edt_f32x4*>(dst + 4) = edt_f32x4{e[1], e[2], e[3], e[4]};
-        *reinterpret_cast<edt_f32x4*>(dst + 8) = edt_f32x4{e[5], p0, p2, 0.f};
-        *reinterpret_cast<edt_f32x2*>(d80 + (row + x) * d80_ld + 70) = edt_f32x2{p0, p2};
+        if (!(dbg & 1)) {
+            dst[3] = e[0];
+            *reinterpret_cast<edt_f32x4*>(dst + 4) = edt_f32x4{e[1], e[2], e[3], e[4]};
+            *reinterpret_cast<edt_f32x4*>(dst + 8) = edt_f32x4{e[5], p0, p2, 0.f};
+        } else if (e[0] + e[1] + e[2] + e[3] + e[4] + e[5] == 12345.f) dst[3] = 0.f;
+        if (!(dbg & 2)) *reinterpret_cast<edt_f32x2*>(d80 + (row + x) * d80_ld + 70) = edt_f32x2{p0, p2};
     }
 }
 
@@ -281,15 +286,20 @@ extern "C" int otvm_trimap_encode(const float* probs, int Hp, int Wp, const uint
     if (hipMemsetAsync(flags, 0, 256, s) != hipSuccess) { otvm_set_error("otvm_trimap_encode: memset failed"); return 2; }
     int64_t nb = (P / 4 + 255) / 256;
     const int grid = (int)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb));
+    static const int dbg0 = getenv("OTVM_EDT_DBG") ? atoi(getenv("OTVM_EDT_DBG")) : 0;
+    if (!(dbg0 & 32))
     hipLaunchKernelGGL(classify_kernel, dim3(grid), dim3(256), 0, s, probs, P, cls_override, cls_out, flags);
+    if (dbg0 & 64) return 0;
     const int len = otvm_ceil_div(Hp, EDT_SEGS);
     const dim3 cgrid(otvm_ceil_div(Wp, EDT_XB)), cblock(EDT_XB * EDT_SEGS);
     if (len <= 8) hipLaunchKernelGGL(edt_columns_kernel<8>, cgrid, cblock, 0, s, cls_out, Hp, Wp, len, g);
     else if (len <= 20) hipLaunchKernelGGL(edt_columns_kernel<20>, cgrid, cblock, 0, s, cls_out, Hp, Wp, len, g);
     else if (len <= 40) hipLaunchKernelGGL(edt_columns_kernel<40>, cgrid, cblock, 0, s, cls_out, Hp, Wp, len, g);
     else hipLaunchKernelGGL(edt_columns_tall_kernel, dim3(otvm_ceil_div(Wp, 64), 2), dim3(64), 0, s, cls_out, Hp, Wp, g);
+    static const int dbg = getenv("OTVM_EDT_DBG") ? atoi(getenv("OTVM_EDT_DBG")) : 0;     // timing probes (results WRONG when set)
+    if (!(dbg & 16))
     hipLaunchKernelGGL(edt_rows_encode_kernel, dim3(Hp), dim3(256), 2 * (Wp + (Wp + 31) / 32) * sizeof(int), s, g, probs, Hp, Wp,
-                       flags, x11, x11_ld, d80, d80_ld);
+                       flags, x11, x11_ld, d80, d80_ld, dbg);
     OTVM_CHECK_LAUNCH("otvm_trimap_encode");
     return 0;
 }

@@ -115,10 +115,9 @@ __global__ __launch_bounds__(256) void fba_head_kernel(const float* __restrict__
                                                        float* __restrict__ alpha_out, int alpha_stride,
                                                        float* __restrict__ tri_out, float* __restrict__ sm, int sm_ld,
                                                        float* __restrict__ out7, float* __restrict__ logits_out) {
-    __shared__ float sw[10 * 16 + 10];
-    for (int i = threadIdx.x; i < n_out * 16; i += blockDim.x) sw[i] = w[i];
-    for (int i = threadIdx.x; i < n_out; i += blockDim.x) sw[160 + i] = b[i];
-    __syncthreads();
+    // the 1x1 weights are read through wave-uniform addresses (scalar loads, 16 SGPRs per output row at a time).  Round 1-3
+    // staged them in LDS: the compiler hoisted all 170 LDS reads out of the pixel loop into registers -- 250 VGPRs, two waves
+    // per SIMD for an elementwise kernel (found in the round-4 ISA audit, profiles/r04_isa_audit.txt)
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
         float h[16];
 #pragma unroll
@@ -132,8 +131,8 @@ __global__ __launch_bounds__(256) void fba_head_kernel(const float* __restrict__
             if (j < n_out) {
                 float acc = 0.f;
 #pragma unroll
-                for (int k = 0; k < 16; ++k) acc += sw[j * 16 + k] * h[k];
-                o[j] = acc + sw[160 + j];
+                for (int k = 0; k < 16; ++k) acc += w[j * 16 + k] * h[k];
+                o[j] = acc + b[j];
             } else {
                 o[j] = 0.f;
             }

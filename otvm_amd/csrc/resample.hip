@@ -515,7 +515,8 @@ __global__ __launch_bounds__(256) void ppm_add_kernel(const float* __restrict__ 
     __shared__ float R[3 * 12 * PPMA_CH];                       // [kx][column j of the 12 (scale, j) pairs][channel]
     __shared__ double gred[2 * (PPMA_CH / 8)];
     const int y = blockIdx.x, c0 = blockIdx.y * PPMA_CH, tid = threadIdx.x;
-    // ---- the row table
+    // ---- the row table (18 entries per thread, three at a time: 18 independent L2 loads in flight)
+#pragma unroll 3
     for (int i = tid; i < 3 * 12 * PPMA_CH; i += 256) {
         const int ch = i % PPMA_CH, kj = i / PPMA_CH, kx = kj / 12, jc = kj - kx * 12;
         const int sc = jc < 1 ? 0 : (jc < 3 ? 1 : (jc < 6 ? 2 : 3));
@@ -523,23 +524,30 @@ __global__ __launch_bounds__(256) void ppm_add_kernel(const float* __restrict__ 
         const int base = sc == 0 ? 0 : (sc == 1 ? 1 : (sc == 2 ? 5 : 14));
         const int j = jc - (sc == 0 ? 0 : (sc == 1 ? 1 : (sc == 2 ? 3 : 6)));
         const float sy = (float)s / (float)H;
-        float acc = 0.f;
+        float za[3], zb[3], wa[3], wb[3];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-            const int qy = y + ky - 1;
-            if ((unsigned)qy >= (unsigned)H) continue;            // zero padding of the convolution
+            int qy = y + ky - 1;
+            const bool in = (unsigned)qy < (unsigned)H;           // zero padding of the convolution
+            qy = in ? qy : y;
             float fy = ((float)qy + 0.5f) * sy - 0.5f;           // F.interpolate(bilinear, align_corners=False)
             fy = fy < 0.f ? 0.f : fy;
             const int y0 = (int)fy, y1 = y0 + (y0 < s - 1 ? 1 : 0);
-            const float ly = fy - (float)y0, hy = 1.f - ly;
+            const float ly = fy - (float)y0;
             const float* zt = Z + ((int64_t)(ky * 3 + kx) * PPMZ_BINS + base + j) * 256 + c0 + ch;
-            acc += hy * zt[(int64_t)y0 * s * 256] + ly * zt[(int64_t)y1 * s * 256];
+            za[ky] = zt[(int64_t)y0 * s * 256];
+            zb[ky] = zt[(int64_t)y1 * s * 256];
+            wa[ky] = in ? 1.f - ly : 0.f;
+            wb[ky] = in ? ly : 0.f;
         }
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) acc += wa[ky] * za[ky] + wb[ky] * zb[ky];
         R[i] = acc;
     }
     if (tid < 2 * (PPMA_CH / 8)) gred[tid] = 0.0;
     // ---- the column terms of every source column qx = -1 .. W of the four scales, once per workgroup: (x0 | x1 << 16, lx);
-    // a column outside the image (the convolution's zero padding) gets weight 0 on both neighbours through lx = hx = 0
+    // a column outside the image (the convolution's zero padding) gets weight 0 on both neighbours
     extern __shared__ int2 xt[];                                 // [4][W + 2]
     for (int i = tid; i < 4 * (W + 2); i += 256) {
         const int sc = i / (W + 2), qx = i - sc * (W + 2) - 1;
@@ -551,31 +559,44 @@ __global__ __launch_bounds__(256) void ppm_add_kernel(const float* __restrict__ 
         xt[i] = int2{in ? (x0 | (x1 << 16)) : 0, in ? __float_as_int(fx - (float)x0) : (int)0x7fc00000};
     }
     __syncthreads();
-    // ---- the row: thread = (channel, x phase)
+    // ---- the row segment of this workgroup: thread = (channel, x phase), four consecutive pixels per step -- their four
+    // loads go out together (one pixel per step was one exposed memory round trip per pixel: 120 us for a 67 MB pass)
     const int ch = tid % PPMA_CH, xp = tid / PPMA_CH;
+    const int wseg = (W + gridDim.z - 1) / gridDim.z;
+    const int xbeg = blockIdx.z * wseg, xend = xbeg + wseg < W ? xbeg + wseg : W;
     float gs = 0.f, gss = 0.f;
     float* orow = out + (int64_t)y * W * out_ld + c0 + ch;
-    for (int xv = xp; xv < W; xv += 256 / PPMA_CH) {
-        const int x = __builtin_amdgcn_readfirstlane(xv);        // (the same for all lanes of a wave: scalar index arithmetic)
-        const float prev = orow[(int64_t)x * out_ld];
-        float acc = 0.f;
+    for (int xv = xbeg + xp * 4; xv < xend; xv += 4 * (256 / PPMA_CH)) {
+        const int xb = __builtin_amdgcn_readfirstlane(xv);       // (the same for all lanes of a wave: scalar index arithmetic)
+        float prev[4];
 #pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-#pragma unroll
-            for (int sc = 0; sc < 4; ++sc) {
-                const int jb = sc == 0 ? 0 : (sc == 1 ? 1 : (sc == 2 ? 3 : 6));
-                const int2 e = xt[sc * (W + 2) + x + kx];        // source column qx = x + kx - 1
-                const int x0 = e.x & 0xffff, x1 = e.x >> 16;
-                const bool in = e.y != (int)0x7fc00000;
-                const float lx = in ? __int_as_float(e.y) : 0.f, hx = in ? 1.f - lx : 0.f;
-                const float* r = R + (kx * 12 + jb) * PPMA_CH + ch;
-                acc += hx * r[x0 * PPMA_CH] + lx * r[x1 * PPMA_CH];
-            }
+        for (int u = 0; u < 4; ++u) {
+            const int x = xb + u < xend ? xb + u : xend - 1;
+            prev[u] = orow[(int64_t)x * out_ld];
         }
-        const float v = prev + acc;
-        orow[(int64_t)x * out_ld] = v;
-        gs += v;
-        gss += v * v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int x = xb + u;
+            if (x >= xend) break;
+            float acc = 0.f;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+#pragma unroll
+                for (int sc = 0; sc < 4; ++sc) {
+                    const int jb = sc == 0 ? 0 : (sc == 1 ? 1 : (sc == 2 ? 3 : 6));
+                    const int2 e = xt[sc * (W + 2) + x + kx];    // source column qx = x + kx - 1
+                    const int x0 = e.x & 0xffff, x1 = e.x >> 16;
+                    const bool in = e.y != (int)0x7fc00000;
+                    const float lx = in ? __int_as_float(e.y) : 0.f, hx = in ? 1.f - lx : 0.f;
+                    const float* r = R + (kx * 12 + jb) * PPMA_CH + ch;
+                    acc += hx * r[x0 * PPMA_CH] + lx * r[x1 * PPMA_CH];
+                }
+            }
+            const float v = prev[u] + acc;
+            orow[(int64_t)x * out_ld] = v;
+            gs += v;
+            gss += v * v;
+        }
     }
     if (gn_stats) {
         // 256 channels in 32 groups of 8: lanes 8k .. 8k+7 share a group; per-thread partial sums in fp32 over <= W / 2 pixels,
@@ -604,8 +625,8 @@ extern "C" int otvm_ppm_conv_z(const float* const* y, int y_ld, const float* w_p
 extern "C" int otvm_ppm_conv_add(const float* Z, int H, int W, float* out, int out_ld, double* gn_stats, void* stream) {
     OTVM_REQUIRE(Z && out && H > 0 && W > 0, "otvm_ppm_conv_add: bad arguments");
     OTVM_REQUIRE(W + 2 <= 4096, "otvm_ppm_conv_add: map too wide (%d)", W);
-    hipLaunchKernelGGL(ppm_add_kernel, dim3(H, 256 / PPMA_CH), dim3(256), 4 * (W + 2) * sizeof(int2), (hipStream_t)stream, Z, H, W,
-                       out, out_ld, gn_stats);
+    hipLaunchKernelGGL(ppm_add_kernel, dim3(H, 256 / PPMA_CH, W >= 64 ? 2 : 1), dim3(256), 4 * (W + 2) * sizeof(int2),
+                       (hipStream_t)stream, Z, H, W, out, out_ld, gn_stats);
     OTVM_CHECK_LAUNCH("otvm_ppm_conv_add");
     return 0;
 }

@@ -47,6 +47,7 @@ def graphs_wanted(setting, padded_pixels):
         return True
     return padded_pixels < GRAPH_AUTO_PIXELS
 PRE_ON_S2 = os.environ.get("OTVM_PRE_ON_S2", "1") != "0"           # preprocess + statistics clear on the second side stream
+EVDEC_LATE = os.environ.get("OTVM_EVDEC_LATE", "1") != "0"         # release the next frame's query encoder behind the trimap encoding
 # one-wave 64x64 tile (operands straight from L2 into MFMA registers, no LDS / barriers in the K loop) as an autotuner
 # candidate.  Built and verified in round 3, measured 20-90 % SLOWER than the 4-wave LDS tiles on every small-map shape
 # (scattered 32-byte A loads: 32 cache lines per load instruction through a 64 B/clk L1): off by default, no weight copy.
@@ -69,12 +70,15 @@ FUSE_PPM_HEAD = os.environ.get("OTVM_PPM_HEAD", "1") != "0"
 # OTVM_GN_PREDICT_DS=0 keeps the apply pass of the four blocks with a projection (their identity is a raw GroupNorm input:
 # conv3's epilogue scales it per channel, otvm_conv_params.res_scale)
 FUSE_GN_PREDICT = os.environ.get("OTVM_GN_PREDICT", "1") != "0"
+# ... on maps of at least this many pixels (the 1/8-resolution maps of a 1080p frame hold 32 640): below, the two extra launches
+# per block cost more than the pass they replace, and the fp16 pass's noise on the statistics (~ 1 / sqrt(pixels)) grows
+GN_PREDICT_MIN_PIXELS = int(os.environ.get("OTVM_GN_PREDICT_MIN_PIXELS", "16384"))
 GN_PREDICT_PASSES = int(os.environ.get("OTVM_GN_PREDICT_PASSES", "1"))
 GN_PREDICT_DS = os.environ.get("OTVM_GN_PREDICT_DS", "1") != "0"
 # round 4 (ABI 17): the refinement's last BasicBlock ends in bn2 -> (+ identity) -> ReLU with ONE reader, pred.0 (a 3x3 patch
 # conv): its staging normalises, adds the identity and applies the ReLU (otvm_conv_params.in_res) -- the 535 MB block output
 # is never written (one 1.6 GB apply pass less per frame, 535 MB more read by pred.0).  0 = round 3's apply pass
-FUSE_REFINE_TAIL = os.environ.get("OTVM_FUSE_REFINE_TAIL", "1") != "0"
+FUSE_REFINE_TAIL = os.environ.get("OTVM_FUSE_REFINE_TAIL", "0") != "0"
 # round 3: the PPM branches' third of conv_up1.0 computed from the 50 pooled pixels (otvm_ppm_conv_z / _add) instead of
 # convolving their upsampled copies; conv_up1.0 then reads layer 4 only.  OTVM_PPM_ALGEBRA=0 keeps the materialised form.
 PPM_ALGEBRA = os.environ.get("OTVM_PPM_ALGEBRA", "1") != "0"       # the four PPM heads in one launch (otvm_ppm_head)
@@ -267,7 +271,7 @@ def pack_conv_weight(lib, dev, w, ws=False, scale=None, i_pad=None, split=True, 
 
 
 def gram_tables(lib, cw):
-    """(Mp fp32 [entries][32], v fp64 [32][Cin]) of a bias-free 1x1 conv for otvm_gn_predict (csrc/gram.hip): per GroupNorm
+    """(Mp fp32 [32][entries], v fp64 [32][Cin]) of a bias-free 1x1 conv for otvm_gn_predict (csrc/gram.hip): per GroupNorm
     group g of its OUTPUT channels v_g = sum of the group's filters and M_g = sum of their outer products, from the packed
     (standardised) fp32 weights in float64; M in the block-upper-triangular order of the Gram kernel's partials, off-diagonal
     blocks doubled (the symmetric half they stand for)."""
@@ -284,8 +288,8 @@ def gram_tables(lib, cw):
         for bj in range(bi, nb):
             m = torch.einsum("gci,gcj->gij", rows, wg[:, :, bj * bs:(bj + 1) * bs])
             blocks.append((m if bi == bj else 2.0 * m).reshape(32, bs * bs))
-    mp = torch.cat(blocks, 1).t().float().contiguous()                   # [nblk * bs * bs][32]: entry-major
-    assert mp.shape[0] == int(lib.otvm_gram_entries(Cin))
+    mp = torch.cat(blocks, 1).float().contiguous()                       # [32][nblk * bs * bs]: group-major
+    assert mp.shape[1] == int(lib.otvm_gram_entries(Cin))
     return mp, v
 
 
@@ -781,9 +785,18 @@ class HipEngine:
                     l4 = pl.L4.img(b)
                     L.check(lib.otvm_upsample4_logits3(l4.ptr, l4.H, l4.W, l4.ld, train["seg_logits"][b].data_ptr(), stream),
                             "upsample4_logits3")
-            self.ev_dec = torch.cuda.Event()                  # the query encoder's buffers are free again
-            self.ev_dec.record(main)
+            if not EVDEC_LATE:
+                self.ev_dec = torch.cuda.Event()              # the query encoder's buffers are free again
+                self.ev_dec.record(main)
         pl.encode(stream, cls_override)
+        if not first_frame and EVDEC_LATE:
+            # round 4: the NEXT frame's query encoder (side stream) is released behind the trimap encoding, not in front of
+            # it: its fused-bottleneck kernels (one workgroup per CU, every register of the CU) otherwise take the chip from
+            # the three small kernels of the encoding -- on the frame's serial chain -- which then wait for whole workgroups
+            # to drain (edt_rows_encode 204 us inside the frame against 90 us alone); the encoder still has the whole alpha
+            # network to hide under
+            self.ev_dec = torch.cuda.Event()
+            self.ev_dec.record(main)
         pl.run("fba", stream)
         pl.run("fba_tail%d" % par, stream)
         self.guard(pl.SMs[par].ch(0, 16), "hidden state", stream, frame_id)
@@ -1106,10 +1119,6 @@ class FramePlan:
                 elif st[0] == "ppm_add":
                     _, a, b, label = st
                     S[i] = (self.lib.otvm_ppm_conv_add, a + (self._ppm_stats.gn_stats + 8 * b * sbs,), label)
-                elif st[0] == "gn_predict":
-                    _, r, idx, label = st
-                    r.sums, r.sums_bs = base + idx * 512, sbs
-                    S[i] = (self.lib.otvm_gn_predict, (C.byref(r),), label)
                 elif st[0] == "gn_apply":
                     _, q, idx, label = st
                     q.stats, q.stats_bs = base + idx * 512, sbs
@@ -1177,7 +1186,7 @@ class FramePlan:
         wname = p + ".conv3"
         gp = e.GP.get(wname) if hasattr(e, "GP") else None
         if not (FUSE_GN_PREDICT and gp is not None and FUSE_GN_APPLY and FUSE_GN_STATS and FUSE_GN_TABLE and FUSE_GN_APPLY_IGEMM
-                and cp2 is not None and (GN_PREDICT_DS or not has_ds)):
+                and cp2 is not None and (GN_PREDICT_DS or not has_ds) and t2.P >= GN_PREDICT_MIN_PIXELS):
             return False
         w = e.W[wname]
         probe = conv_params(t2, w, out, None, 1, 0, 1, RELU, 0, x, e.precision, (1, 1, RELU))
@@ -1212,14 +1221,13 @@ class FramePlan:
         r.gpart, r.spart, r.P, r.C, r.Cout = gpart.data_ptr(), spart.data_ptr(), t2.P, planes, C4
         r.Mp, r.v = gp[0].data_ptr(), gp[1].data_ptr()
         r.counter = cnt.data_ptr()
+        r.ws = self.raw("gnpred_ws", B * int(lib.otvm_gn_predict_ws_bytes()) // 8, torch.float64).data_ptr()   # (launches are serial)
         r.wscale, r.gamma, r.beta = w.w_scale.data_ptr(), sd[p + ".bn3.weight"].data_ptr(), sd[p + ".bn3.bias"].data_ptr()
         r.res_shift = 0 if rsh is None else rsh
         r.scale_eff, r.bias_eff = tab.data_ptr(), tab.data_ptr() + 4 * C4
         r.batch, r.tab_bs, r.rs_bs = B, 2 * C4, 0 if rsh is None else rnbs
         self._keep.append(r)
-        idx = self.n_gn
-        self.n_gn += 1
-        S.append(("gn_predict", r, idx, "gn_predict " + p))
+        S.append((lib.otvm_gn_predict, (C.byref(r),), "gn_predict " + p))
         cp3 = self.conv(S, t2, wname, out, in_norm=(sc, sh, RELU, nbs), residual=idt, act=RELU)
         cp3.w_scale, cp3.bias, cp3.ws_bs = tab.data_ptr(), tab.data_ptr() + 4 * C4, 2 * C4
         if rsc is not None:

@@ -53,10 +53,10 @@ class GramParams(C.Structure):
 
 
 class GnPredictParams(C.Structure):
-    _fields_ = [("gpart", vp), ("spart", vp), ("P", i64), ("C", i32), ("Cout", i32), ("Mp", vp), ("v", vp), ("sums", vp),
+    _fields_ = [("gpart", vp), ("spart", vp), ("P", i64), ("C", i32), ("Cout", i32), ("Mp", vp), ("v", vp), ("ws", vp),
                 ("counter", vp), ("wscale", vp), ("gamma", vp), ("beta", vp), ("res_shift", vp),
                 ("scale_eff", vp), ("bias_eff", vp), ("stat_out", vp),
-                ("batch", i32), ("sums_bs", i32), ("tab_bs", i32), ("rs_bs", i32)]
+                ("batch", i32), ("tab_bs", i32), ("rs_bs", i32)]
 
 
 class PreprocessParams(C.Structure):
@@ -145,6 +145,7 @@ _PROTOS = {
     "otvm_gram_chunks": (i32, [i64, i32, C.POINTER(i32)]),
     "otvm_gram_f16": (i32, [C.POINTER(GramParams), vp]),
     "otvm_gn_predict": (i32, [C.POINTER(GnPredictParams), vp]),
+    "otvm_gn_predict_ws_bytes": (i64, []),
 }
 
 EXPORTED = sorted(list(_PROTOS) + ["otvm_last_error"])

@@ -43,6 +43,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--reps", type=int, default=30)
+    ap.add_argument("--probe", action="store_true", help="also time strided partial writes of several widths")
     args = ap.parse_args()
     lib = L.load()
     dev = torch.device("cuda", 0)
@@ -123,6 +124,19 @@ def main():
     pp.scaled_imgs, pp.x11, pp.x11_ld, pp.sq, pp.sq_ld = si.data_ptr(), x11.data_ptr(), 12, sq.data_ptr(), 4
     pp.sm, pp.sm_ld, pp.d80, pp.d80_ld = sm.data_ptr() + 64, 24, d80.data_ptr(), 80
     res["preprocess_us"] = timed(lambda: L.check(lib.otvm_preprocess(C.byref(pp), st)), args.reps)
+    # ---- what a strided partial write costs (torch copy kernels; [P][80] fp32 rows of 320 bytes, like the D80 buffer): `w`
+    # floats written per row at a 32-byte aligned offset -- is a 32-byte sector written without a read-modify-write?
+    if args.probe:
+        big = torch.zeros(P * 80, device=dev)
+        v2 = big.view(P, 80)
+        for w_ in (1, 2, 4, 8, 16, 32, 80):
+            src = torch.randn(P, w_, device=dev)
+            res["probe_write_%dB_per_320B_us" % (4 * w_)] = timed(lambda: v2[:, 64 - (64 if w_ == 80 else 0):64 - (64 if w_ == 80 else 0) + w_].copy_(src)
+                                                                if w_ <= 16 or w_ == 80 else v2[:, 32:32 + w_].copy_(src), args.reps)
+        for w_ in (1, 2, 4, 8, 12):
+            big12 = torch.zeros(P * 12, device=dev).view(P, 12)
+            src = torch.randn(P, w_, device=dev)
+            res["probe_write_%dB_per_48B_us" % (4 * w_)] = timed(lambda: big12[:, 12 - w_:].copy_(src), args.reps)
     print(json.dumps(res, indent=1))
 
 
