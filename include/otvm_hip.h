@@ -154,6 +154,22 @@ typedef struct {
                                                        otvm_gn_apply with a residual; in_res = the block's identity, same shape   */
 } otvm_conv_params;
 int otvm_conv2d_accepts_input_residual(const otvm_conv_params* p);
+
+/* ABI 17: the last 3x3 convolution of the FBA decoder / refinement (32 -> 16, LeakyReLU; FBA/models.py:383-388, 425-432) with
+ * the head that follows it -- 1x1 conv 16 -> n_out, clamp / sigmoid, fba_fusion, softmax of the trimap-refinement logits; the
+ * per-pixel arithmetic of otvm_fba_head below -- in the epilogue: the 16 hidden values never leave the registers.  p = the conv
+ * (3x3, stride 1, dilation 1, Cin % 16 == 0, Cout == 16, f16x3, w_frag; p->out = the hidden state or NULL: not written);
+ * image b of the head's tensors lives *_bs floats behind image 0 (p->batch > 1).                                            */
+typedef struct otvm_head_params {
+    const float* w; const float* b; int n_out;      /* 1x1 head: [n_out][16], [n_out]; n_out = 7 or 10                         */
+    const float* img; int img_ld;                   /* composited RGB in [0,1]: 3 channels at pixel stride img_ld               */
+    int64_t P;                                      /* pixels per plane of the planar outputs (= H * W of the conv)            */
+    float* alpha_out; int alpha_stride;             /* fused alpha, element i at alpha_out[i * alpha_stride]                   */
+    float* tri_out;                                 /* n_out == 10: [3][P] softmax of logits 7..9                              */
+    float* sm; int sm_ld;                           /* optional (n_out == 10): p_unknown, p_fg, alpha -> sm[i * sm_ld + 3..5]   */
+    int64_t img_bs, alpha_bs, tri_bs, sm_bs;
+} otvm_head_params;
+int otvm_conv2d_head(const otvm_conv_params* p, const otvm_head_params* h, void* stream);
 int otvm_conv2d(const otvm_conv_params* p, void* stream);
 /* The legal kernel configurations of a layer (f16x3): the patch kernel where the shape allows it, and the implicit-GEMM
  * tiles 256x256 ... 64x64, each alone or with the K range of every output tile shared by S = 2..8 workgroups

@@ -15,6 +15,7 @@
 // One wave owns TM = TH/NW output rows (M tiles of 32 pixels) x TN = BN/32 channel tiles.  fp32 accumulate; epilogue
 // as conv_f16x3.hip (filter scale, bias, residual, activation, optional fused GroupNorm statistics).
 #include "common.h"
+#include "head_math.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -57,6 +58,9 @@ struct PatchArgs {
     // ABI 17 (INRES kernels): the input is the raw GroupNorm input of a residual block's LAST normalisation, whose apply pass
     // was skipped: x' = in_act(x * in_scale[c] + in_shift[c] + in_res), in_res = the block's (materialised) identity
     const float* in_res; int in_res_ld; int64_t in_res_bs;
+    // ABI 17 (HEAD kernels, 16 output channels): the 1x1 head + fba_fusion of the FBA decoder / refinement run in the epilogue
+    // on the pixel's 16 hidden values (head_math.h); out (the hidden state) is optional then
+    OtvmHeadArgs head; int64_t head_img_bs, head_alpha_bs, head_tri_bs, head_sm_bs;
 };
 
 constexpr int CB = 16;           // channels per stage = one MFMA k-step
@@ -77,7 +81,7 @@ __device__ __forceinline__ void split4p(const f32x4 v, f16x4& hi, f16x4& lo) {
 // fragments of its BN output channels, copied verbatim from the fragment-major weight array (1-KiB blocks).
 // TAPG = 9: one weight stage per channel stage (narrow layers); TAPG = 3: wide layers (BN = 256), where nine taps of
 // weights (144 KiB) would not fit beside the patch.
-template <int TH, int BN, int NW, int DIL, int TAPG, bool INRES = false>
+template <int TH, int BN, int NW, int DIL, int TAPG, bool INRES = false, bool HEAD = false>
 __global__ __launch_bounds__(NW * 64)
 __attribute__((amdgpu_waves_per_eu((TAPG == 3 && BN <= 32 && !INRES) ? 3 : 1, (TAPG == 3 && BN <= 32 && !INRES) ? 3 : 10)))
 void conv_patch_f16x3_kernel(const PatchArgs pa) {
@@ -86,6 +90,12 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
         const int zb = blockIdx.y;
         p.in += zb * p.in_bs;
         if (INRES) p.in_res += zb * p.in_res_bs;
+        if (HEAD) {
+            p.head.img += zb * p.head_img_bs;
+            if (p.head.alpha_out) p.head.alpha_out += zb * p.head_alpha_bs;
+            if (p.head.tri_out) p.head.tri_out += zb * p.head_tri_bs;
+            if (p.head.sm) p.head.sm += zb * p.head_sm_bs;
+        }
         p.out += zb * p.out_bs;
         if (p.residual) p.residual += zb * p.res_bs;
         if (p.gn_stats) p.gn_stats += zb * p.gn_bs;
@@ -99,7 +109,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     constexpr int PATCH_HALFS = 2 * NPIX * LDP;                        // hi + lo
     constexpr int B_PIECES = TAPG * TN * 2 * 64;                       // 16-byte pieces of one weight stage
     constexpr int B_HALFS = B_PIECES * 8;
-    constexpr int EPI_HALFS = NW * 32 * 36 * 2;                        // epilogue patches (fp32) expressed in halfs
+    constexpr int EPI_HALFS = NW * 32 * 36 * 2 * (HEAD ? 2 : 1);       // epilogue patches (fp32) expressed in halfs
     constexpr int SM_HALFS = PATCH_HALFS + B_HALFS > EPI_HALFS ? PATCH_HALFS + B_HALFS : EPI_HALFS;
     __shared__ __attribute__((aligned(16))) _Float16 smem[SM_HALFS];
     _Float16* Ph = smem;
@@ -289,6 +299,46 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     if (acc[0][0][0] == 12345.678f) p.out[0] = acc[0][0][1];
     if (acc[0][0][0] != 12345.678f) return;
 #endif
+    if constexpr (HEAD) {
+        // ---- round 4: 16 output channels (a half-empty 32-wide tile) followed by a per-pixel head (FBA/models.py:383-388,
+        // 425-432: conv_up4.2 -> conv_up4.4 -> fba_fusion, pred.2 -> pred.4 -> fba_fusion / softmax).  As two launches the hidden
+        // state made a round trip through HBM (134 MB written, 134 MB + the image read back by a pass of its own: 117-170 us);
+        // here a wave turns its TM = 2 accumulator tiles into [pixel][channel] rows in LDS and every lane takes ONE pixel --
+        // lanes 0-31 the wave's first image row, lanes 32-63 the second: filter scale, bias, activation (the arithmetic of the
+        // plain epilogue), the hidden state's 64 bytes (optional), then the head on the 16 values in registers.
+        static_assert(TM == 2 && TN == 1, "the head epilogue is written for two pixel rows and one channel tile per wave");
+        float* patch = reinterpret_cast<float*>(smem) + wave * (2 * 32 * 36);
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) patch[a * (32 * 36) + ((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][0][e];
+        const int a = lane >> 5, px = lane & 31;
+        const int y = ty0 + wave * TM + a, x = tx0 + px;
+        float h[16];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(&patch[a * (32 * 36) + px * 36 + 4 * k]);
+            f32x4 sc4, bi4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sc4[j] = p.wscale[4 * k + j];
+                if (p.bias) bi4[j] = p.bias[4 * k + j];
+            }
+            v = v * sc4 + bi4;
+            h[4 * k] = otvm_act(v.x, p.act); h[4 * k + 1] = otvm_act(v.y, p.act);
+            h[4 * k + 2] = otvm_act(v.z, p.act); h[4 * k + 3] = otvm_act(v.w, p.act);
+        }
+        if (y < p.H && x < p.W) {
+            const int64_t m = (int64_t)y * p.W + x;
+            if (p.out) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    *reinterpret_cast<f32x4*>(p.out + m * p.out_ld + 4 * k) = f32x4{h[4 * k], h[4 * k + 1], h[4 * k + 2], h[4 * k + 3]};
+            }
+            otvm_head_pixel(h, p.head, m);
+        }
+        return;
+    }
     const bool vec_ok = ((p.out_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.out) & 15) == 0) &&
                         (!p.residual || (((p.res_ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(p.residual) & 15) == 0)));
     // interior blocks (every row, column and channel of the block inside the output) take a copy of the epilogue without
@@ -501,12 +551,12 @@ __global__ __launch_bounds__(256) void pack_patch_weight_kernel(const float* __r
     }
 }
 
-template <int TH, int BN, int NW, int DIL, int TAPG = 9, bool INRES = false>
+template <int TH, int BN, int NW, int DIL, int TAPG = 9, bool INRES = false, bool HEAD = false>
 int launch_patch(PatchArgs& a, hipStream_t s) {
     a.tiles_x = otvm_ceil_div(a.W, 32);
     a.tiles_y = otvm_ceil_div(a.H, TH);
     a.tiles_n = otvm_ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL, TAPG, INRES>), dim3(a.tiles_x * a.tiles_y * a.tiles_n, a.batch), dim3(NW * 64), 0, s, a);
+    hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL, TAPG, INRES, HEAD>), dim3(a.tiles_x * a.tiles_y * a.tiles_n, a.batch), dim3(NW * 64), 0, s, a);
     OTVM_CHECK_LAUNCH("otvm_conv2d(patch f16x3)");
     return 0;
 }
@@ -569,14 +619,25 @@ int otvm_conv2d_patch_eligible(const otvm_conv_params* p) {
     return patch_choice(p, true) != 0 ? 1 : 0;
 }
 
-static int patch_run(const otvm_conv_params* p, void* stream, int choice);
+static int patch_run(const otvm_conv_params* p, void* stream, int choice, const otvm_head_params* hd = nullptr);
+
+// ABI 17: 3x3 conv to 16 channels with the FBA head in its epilogue (include/otvm_hip.h)
+extern "C" int otvm_conv2d_head(const otvm_conv_params* p, const otvm_head_params* hd, void* stream) {
+    OTVM_REQUIRE(p && hd && p->in && hd->w && hd->b && hd->img, "otvm_conv2d_head: null pointer");
+    OTVM_REQUIRE(p->precision == OTVM_PREC_F16X3 && p->Cout == 16 && patch_choice(p) == 1 && p->dil == 1 && !p->residual &&
+                     !p->gn_stats && !p->in_res && p->w_scale,
+                 "otvm_conv2d_head: a 3x3 stride-1 f16x3 layer with 16 output channels, no residual / statistics");
+    OTVM_REQUIRE(hd->n_out == 7 || (hd->n_out == 10 && hd->tri_out), "otvm_conv2d_head: n_out must be 7, or 10 with tri_out");
+    OTVM_REQUIRE(!p->out || ((p->out_ld & 3) == 0 && ((uintptr_t)p->out & 15) == 0), "otvm_conv2d_head: out must be 16-byte aligned");
+    return patch_run(p, stream, 1, hd);
+}
 
 int otvm_conv2d_patch_f16x3_forced(const otvm_conv_params* p, void* stream) { return patch_run(p, stream, patch_choice(p, true)); }
 
 // returns -1 when the layer is not eligible (caller falls back to the implicit-GEMM kernel)
 int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream) { return patch_run(p, stream, patch_choice(p)); }
 
-static int patch_run(const otvm_conv_params* p, void* stream, int choice) {
+static int patch_run(const otvm_conv_params* p, void* stream, int choice, const otvm_head_params* hd) {
     if (choice == 0) return -1;
     const bool is_wide = choice == 2;
     PatchArgs a;
@@ -591,6 +652,14 @@ static int patch_run(const otvm_conv_params* p, void* stream, int choice) {
     a.in_bs = a.batch > 1 ? p->in_bs : 0; a.out_bs = a.batch > 1 ? p->out_bs : 0; a.res_bs = a.batch > 1 ? p->res_bs : 0;
     a.gn_bs = a.batch > 1 ? p->gn_bs : 0; a.norm_bs = a.batch > 1 ? p->norm_bs : 0;
     a.in_res = p->in_res; a.in_res_ld = p->in_res_ld; a.in_res_bs = a.batch > 1 ? p->in_res_bs : 0;
+    if (hd) {
+        a.head.w = hd->w; a.head.b = hd->b; a.head.n_out = hd->n_out; a.head.img = hd->img; a.head.img_ld = hd->img_ld;
+        a.head.P = hd->P; a.head.alpha_out = hd->alpha_out; a.head.alpha_stride = hd->alpha_stride; a.head.tri_out = hd->tri_out;
+        a.head.sm = hd->sm; a.head.sm_ld = hd->sm_ld; a.head.out7 = nullptr; a.head.logits_out = nullptr;
+        a.head_img_bs = a.batch > 1 ? hd->img_bs : 0; a.head_alpha_bs = a.batch > 1 ? hd->alpha_bs : 0;
+        a.head_tri_bs = a.batch > 1 ? hd->tri_bs : 0; a.head_sm_bs = a.batch > 1 ? hd->sm_bs : 0;
+        return launch_patch<8, 32, 4, 1, 3, false, true>(a, s);
+    }
     if (p->in_res) {
         OTVM_REQUIRE(otvm_conv2d_accepts_input_residual(p) && !is_wide && (p->in_res_ld & 3) == 0 && ((uintptr_t)p->in_res & 15) == 0,
                      "otvm_conv2d: in_res needs in_scale on a 3x3 stride-1 dilation-1 layer with <= 64 output channels");

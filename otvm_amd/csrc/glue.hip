@@ -3,6 +3,7 @@
 // first-frame trimap from a GT alpha.  All elementwise / HBM-bound.  Compiled with
 // -ffp-contract=off so the elementwise arithmetic follows the reference's operation order exactly.
 #include "common.h"
+#include "head_math.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -104,84 +105,21 @@ __global__ void upsample4_softmax3_kernel(const float* __restrict__ lg, int h4, 
     }
 }
 
-__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
-__device__ __forceinline__ float clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
-
 // 1x1 conv 16 -> n_out, clamp / sigmoid, fba_fusion (FBA/models.py:279-288; the B update reads the
-// already-updated F), softmax of the 3 trimap-refinement logits.
-__global__ __launch_bounds__(256) void fba_head_kernel(const float* __restrict__ hid, int hid_ld,
-                                                       const float* __restrict__ w, const float* __restrict__ b, int n_out,
-                                                       const float* __restrict__ img, int img_ld, int64_t P,
-                                                       float* __restrict__ alpha_out, int alpha_stride,
-                                                       float* __restrict__ tri_out, float* __restrict__ sm, int sm_ld,
-                                                       float* __restrict__ out7, float* __restrict__ logits_out) {
+// already-updated F), softmax of the 3 trimap-refinement logits: head_math.h (shared with the conv kernel that carries
+// the head in its epilogue).
+__global__ __launch_bounds__(256) void fba_head_kernel(const float* __restrict__ hid, int hid_ld, const OtvmHeadArgs q) {
     // the 1x1 weights are read through wave-uniform addresses (scalar loads, 16 SGPRs per output row at a time).  Round 1-3
     // staged them in LDS: the compiler hoisted all 170 LDS reads out of the pixel loop into registers -- 250 VGPRs, two waves
     // per SIMD for an elementwise kernel (found in the round-4 ISA audit, profiles/r04_isa_audit.txt)
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < q.P; i += (int64_t)gridDim.x * blockDim.x) {
         float h[16];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(hid + i * hid_ld + 4 * k);
             h[4 * k] = v.x; h[4 * k + 1] = v.y; h[4 * k + 2] = v.z; h[4 * k + 3] = v.w;
         }
-        float o[10];
-#pragma unroll
-        for (int j = 0; j < 10; ++j) {
-            if (j < n_out) {
-                float acc = 0.f;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) acc += w[j * 16 + k] * h[k];
-                o[j] = acc + b[j];
-            } else {
-                o[j] = 0.f;
-            }
-        }
-        float al = clamp01(o[0]);
-        float im[3], F[3], B[3];
-        float num = 0.f, den = 0.f;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            im[c] = img[i * img_ld + c];
-            const float f0 = sigmoidf(o[1 + c]), b0 = sigmoidf(o[4 + c]);
-            float fn = al * im[c] + (1.f - al * al) * f0 - al * (1.f - al) * b0;
-            float bn = (1.f - al) * im[c] + (2.f * al - al * al) * b0 - al * (1.f - al) * fn;
-            F[c] = clamp01(fn);
-            B[c] = clamp01(bn);
-        }
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            num += (im[c] - B[c]) * (F[c] - B[c]);
-            den += (F[c] - B[c]) * (F[c] - B[c]);
-        }
-        al = clamp01((al * 0.1f + num) / (den + 0.1f));
-        if (alpha_out) alpha_out[i * alpha_stride] = al;
-        if (out7) {                                             // training forward: the fused (alpha, F, B) of FBA/models.py:388
-            out7[i] = al;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                out7[(1 + c) * P + i] = F[c];
-                out7[(4 + c) * P + i] = B[c];
-            }
-        }
-        if (logits_out && n_out == 10) {
-            logits_out[i] = o[7];
-            logits_out[P + i] = o[8];
-            logits_out[2 * P + i] = o[9];
-        }
-        if (n_out == 10 && tri_out) {
-            const float m = fmaxf(o[7], fmaxf(o[8], o[9]));
-            const float e0 = expf(o[7] - m), e1 = expf(o[8] - m), e2 = expf(o[9] - m);
-            const float inv = 1.f / (e0 + e1 + e2);
-            tri_out[i] = e0 * inv;
-            tri_out[P + i] = e1 * inv;
-            tri_out[2 * P + i] = e2 * inv;
-            if (sm) {                                           // Es = cat[tri, alpha, hid] (trimap/model.py:231)
-                sm[i * sm_ld + 3] = e1 * inv;                   // unknown prob  -> conv1_m (STM.py:58)
-                sm[i * sm_ld + 4] = e2 * inv;                   // fg prob       -> conv1_o
-                sm[i * sm_ld + 5] = al;                         // alpha         -> conv1_a
-            }
-        }
+        otvm_head_pixel(h, q, i);
     }
 }
 
@@ -307,8 +245,10 @@ extern "C" int otvm_fba_head(const float* hid, int hid_ld, const float* w, const
     OTVM_REQUIRE(n_out == 7 || n_out == 10, "otvm_fba_head: n_out must be 7 or 10 (got %d)", n_out);
     OTVM_REQUIRE(n_out == 7 || tri_out, "otvm_fba_head: tri_out required when n_out == 10");
     OTVM_REQUIRE(hid_ld % 4 == 0 && ((uintptr_t)hid & 15) == 0, "otvm_fba_head: hid view must be 16-byte aligned");
-    hipLaunchKernelGGL(fba_head_kernel, dim3(grid_for(P)), dim3(256), 0, (hipStream_t)stream, hid, hid_ld, w, b, n_out, img,
-                       img_ld, P, alpha_out, alpha_stride, tri_out, sm, sm_ld, (float*)nullptr, (float*)nullptr);
+    OtvmHeadArgs q;
+    q.w = w; q.b = b; q.n_out = n_out; q.img = img; q.img_ld = img_ld; q.P = P; q.alpha_out = alpha_out; q.alpha_stride = alpha_stride;
+    q.tri_out = tri_out; q.sm = sm; q.sm_ld = sm_ld; q.out7 = nullptr; q.logits_out = nullptr;
+    hipLaunchKernelGGL(fba_head_kernel, dim3(grid_for(P)), dim3(256), 0, (hipStream_t)stream, hid, hid_ld, q);
     OTVM_CHECK_LAUNCH("otvm_fba_head");
     return 0;
 }
@@ -318,8 +258,10 @@ extern "C" int otvm_fba_head_train(const float* hid, int hid_ld, const float* w,
     OTVM_REQUIRE(n_out == 7 || n_out == 10, "otvm_fba_head_train: n_out must be 7 or 10 (got %d)", n_out);
     OTVM_REQUIRE(out7 && (n_out == 7 || logits_out), "otvm_fba_head_train: out7 (and logits_out for n_out == 10) required");
     OTVM_REQUIRE(hid_ld % 4 == 0 && ((uintptr_t)hid & 15) == 0, "otvm_fba_head_train: hid view must be 16-byte aligned");
-    hipLaunchKernelGGL(fba_head_kernel, dim3(grid_for(P)), dim3(256), 0, (hipStream_t)stream, hid, hid_ld, w, b, n_out, img,
-                       img_ld, P, (float*)nullptr, 0, (float*)nullptr, (float*)nullptr, 0, out7, logits_out);
+    OtvmHeadArgs q;
+    q.w = w; q.b = b; q.n_out = n_out; q.img = img; q.img_ld = img_ld; q.P = P; q.alpha_out = nullptr; q.alpha_stride = 0;
+    q.tri_out = nullptr; q.sm = nullptr; q.sm_ld = 0; q.out7 = out7; q.logits_out = logits_out;
+    hipLaunchKernelGGL(fba_head_kernel, dim3(grid_for(P)), dim3(256), 0, (hipStream_t)stream, hid, hid_ld, q);
     OTVM_CHECK_LAUNCH("otvm_fba_head_train");
     return 0;
 }

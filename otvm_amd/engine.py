@@ -79,6 +79,10 @@ GN_PREDICT_DS = os.environ.get("OTVM_GN_PREDICT_DS", "1") != "0"
 # conv): its staging normalises, adds the identity and applies the ReLU (otvm_conv_params.in_res) -- the 535 MB block output
 # is never written (one 1.6 GB apply pass less per frame, 535 MB more read by pred.0).  0 = round 3's apply pass
 FUSE_REFINE_TAIL = os.environ.get("OTVM_FUSE_REFINE_TAIL", "0") != "0"
+# round 4 (ABI 17): conv_up4.2 / pred.2 (3x3, 32 -> 16) carry the 1x1 head + fba_fusion that follows them in their epilogue
+# (otvm_conv2d_head): the decoder's hidden state is not written at all (unless a training forward needs it), the
+# refinement's is written once and not read back; two launches per frame less.  0 = conv + otvm_fba_head
+FUSE_HEAD = os.environ.get("OTVM_FUSE_HEAD", "1") != "0"
 # round 3: the PPM branches' third of conv_up1.0 computed from the 50 pooled pixels (otvm_ppm_conv_z / _add) instead of
 # convolving their upsampled copies; conv_up1.0 then reads layer 4 only.  OTVM_PPM_ALGEBRA=0 keeps the materialised form.
 PPM_ALGEBRA = os.environ.get("OTVM_PPM_ALGEBRA", "1") != "0"       # the four PPM heads in one launch (otvm_ppm_head)
@@ -362,6 +366,7 @@ class HipEngine:
         self._guard_ev = None
         self._guard_what = {}
         self.use_graphs = USE_GRAPHS
+        self.keep_hid_d = False      # training forward (otvm_amd/train.py): the decoder's hidden state must exist in memory
         global _TUNE_FILE_LOADED
         if not _TUNE_FILE_LOADED:
             _TUNE_FILE_LOADED = True
@@ -524,6 +529,8 @@ class HipEngine:
     # ------------------------------------------------------------------ plans
     def plan(self, H, W, B=1):
         key = (H, W) if B == 1 else (H, W, B)
+        if self.keep_hid_d:
+            key = key + ("hid_d",)
         if key not in self.plans:
             self.plans[key] = FramePlan(self, H, W, B)
         return self.plans[key]
@@ -1040,6 +1047,31 @@ class FramePlan:
         S.append((self.lib.otvm_conv2d, (C.byref(p),), "conv " + wname, flops, abytes, (x, out.ch(0, _rup(w.O, 4)) if out.C >= _rup(w.O, 4) else out)))
         return p
 
+    def conv_head(self, S, x, wname, hid_out, head_w, head_b, n_out, img, alpha, alpha_stride, alpha_bs, tri=None, sm=None):
+        """3x3 conv 32 -> 16 + LeakyReLU with the FBA head in its epilogue (otvm_conv2d_head).  hid_out: Act or None (hidden
+        state not written); img: Act view of the 3 image channels; alpha: (tensor pointer of image 0); tri: pointer or None;
+        sm: Act view (channels 16..23 of the Encoder_M input) or None."""
+        w = self.e.W[wname]
+        assert x.C == w.I_pad and w.O == 16 and w.kh == 3
+        out = hid_out if hid_out is not None else x
+        p = conv_params(x, w, out, w.bias, 1, 1, 1, LEAKY, 0, None, self.e.precision, None, None)
+        if hid_out is None:
+            p.out, p.out_ld, p.out_bs = 0, 0, 0
+        h = L.HeadParams()
+        h.w, h.b, h.n_out = head_w.data_ptr(), head_b.data_ptr(), n_out
+        h.img, h.img_ld, h.img_bs = img.ptr, img.ld, img.bs
+        h.P = x.P
+        h.alpha_out, h.alpha_stride, h.alpha_bs = alpha, alpha_stride, alpha_bs
+        h.tri_out, h.tri_bs = (0 if tri is None else tri), 3 * x.P
+        if sm is not None:
+            h.sm, h.sm_ld, h.sm_bs = sm.ptr, sm.ld, sm.bs
+        self._keep += [p, h]
+        flops = 2 * x.P * w.O * 9 * w.I * x.B
+        abytes = 4 * (x.B * x.P * w.I + w.O * w.I * 9 + x.B * x.P * (16 if hid_out is not None else 0) + x.B * x.P * 4)
+        S.append((self.lib.otvm_conv2d_head, (C.byref(p), C.byref(h)), "conv " + wname + " (+ head)", flops, abytes,
+                  (x, hid_out if hid_out is not None else x)))
+        return p
+
     def gn(self, S, x, name, act, out=None, residual=None, conv_p=None, res_norm=None):
         """GroupNorm(32) of the raw conv output ``x``.  With ``conv_p`` (the params of the conv that produced x)
         the statistics are accumulated in that conv's epilogue and the separate stats pass is dropped.
@@ -1454,13 +1486,19 @@ class FramePlan:
         self.gn_then_upsample(S, u3, de + "conv_up3.1", LEAKY, cp, self.D80.ch(0, 64))
         h32 = self.buf("h32", Hp, Wp, 32)
         self.conv(S, self.D80, de + "conv_up4.0", h32, pad=1, act=LEAKY)      # ch 72.. carry zero weights
-        hid_d = self.HID_D = self.buf("hid_d", Hp, Wp, 16)
-        self.conv(S, h32, de + "conv_up4.2", hid_d, pad=1, act=LEAKY)
         img = self.D80.ch(67, 3)
-        for b in range(self.B):
-            S.append((lib.otvm_fba_head,
-                      (hid_d.img(b).ptr, hid_d.ld, sd[de + "conv_up4.4.weight"].data_ptr(), sd[de + "conv_up4.4.bias"].data_ptr(), 7,
-                       img.img(b).ptr, img.ld, P, self.D80.ch(72, 1).img(b).ptr, self.D80.ld, 0, 0, 0), "fba_head7"))
+        fuse_head = FUSE_HEAD and e.precision == L.PREC_F16X3 and e.W[de + "conv_up4.2"].w_frag is not None
+        if fuse_head:
+            hid_d = self.HID_D = self.buf("hid_d", Hp, Wp, 16) if e.keep_hid_d else None
+            self.conv_head(S, h32, de + "conv_up4.2", hid_d, sd[de + "conv_up4.4.weight"], sd[de + "conv_up4.4.bias"], 7, img,
+                           self.D80.ch(72, 1).ptr, self.D80.ld, self.D80.bs)
+        else:
+            hid_d = self.HID_D = self.buf("hid_d", Hp, Wp, 16)
+            self.conv(S, h32, de + "conv_up4.2", hid_d, pad=1, act=LEAKY)
+            for b in range(self.B):
+                S.append((lib.otvm_fba_head,
+                          (hid_d.img(b).ptr, hid_d.ld, sd[de + "conv_up4.4.weight"].data_ptr(), sd[de + "conv_up4.4.bias"].data_ptr(), 7,
+                           img.img(b).ptr, img.ld, P, self.D80.ch(72, 1).img(b).ptr, self.D80.ld, 0, 0, 0), "fba_head7"))
         # ---------------- refinement (FBA/models.py:417-435)
         rf = "NET.refine."
         r0 = self.buf("r0", Hp, Wp, 64)
@@ -1502,6 +1540,11 @@ class FramePlan:
             S = []
             SM = self.SMs[par]
             hid = SM.ch(0, 16)
+            if fuse_head:
+                self.conv_head(S, h32, rf + "pred.2", hid, sd[rf + "pred.4.weight"], sd[rf + "pred.4.bias"], 10, img,
+                               self.ALPHA_P_B[0].data_ptr(), 1, P, tri=self.TRI_P_B[0].data_ptr(), sm=SM.ch(16, 8))
+                self.steps["fba_tail%d" % par] = S
+                continue
             self.conv(S, h32, rf + "pred.2", hid, pad=1, act=LEAKY)
             for b in range(self.B):
                 S.append((lib.otvm_fba_head,

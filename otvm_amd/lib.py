@@ -47,6 +47,12 @@ class GnApplyParams(C.Structure):
                 ("batch", i32), ("x_bs", i64), ("res_bs", i64), ("out_bs", i64), ("stats_bs", i32), ("norm_bs", i32)]
 
 
+class HeadParams(C.Structure):
+    _fields_ = [("w", vp), ("b", vp), ("n_out", i32), ("img", vp), ("img_ld", i32), ("P", i64), ("alpha_out", vp),
+                ("alpha_stride", i32), ("tri_out", vp), ("sm", vp), ("sm_ld", i32),
+                ("img_bs", i64), ("alpha_bs", i64), ("tri_bs", i64), ("sm_bs", i64)]
+
+
 class GramParams(C.Structure):
     _fields_ = [("x", vp), ("P", i64), ("C", i32), ("ld", i32), ("in_scale", vp), ("in_shift", vp), ("in_act", i32),
                 ("gpart", vp), ("spart", vp), ("passes", i32), ("batch", i32), ("x_bs", i64), ("norm_bs", i32)]
@@ -93,6 +99,7 @@ _PROTOS = {
     "otvm_conv2d_accepts_input_norm": (i32, [C.POINTER(ConvParams)]),
     "otvm_conv2d_input_norm_kind": (i32, [C.POINTER(ConvParams)]),
     "otvm_conv2d_accepts_input_residual": (i32, [C.POINTER(ConvParams)]),
+    "otvm_conv2d_head": (i32, [C.POINTER(ConvParams), C.POINTER(HeadParams), vp]),
     "otvm_conv2d_candidates": (i32, [C.POINTER(ConvParams), C.POINTER(i32), i32]),
     "otvm_gn_apply": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, i32, vp]),
     "otvm_maxpool3x3s2": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),

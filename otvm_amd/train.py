@@ -85,6 +85,7 @@ def train_forward(model, a, fg, bg, tri):
     Returns the reference's list: [loss1, loss2, loss3, loss_trimap, scaled_imgs, tris_vis, alphas, comps, scaled_gts, Fs, Bs,
     preds_trimap] (losses as 0-dim device tensors)."""
     eng = model._get_engine()
+    eng.keep_hid_d = True            # (the fused decoder head otherwise never writes the hidden state the training head reads)
     lib, dev, f32 = eng.lib, eng.dev, torch.float32
     if tri is None:
         raise NotImplementedError("otvm_amd training forward: per-frame ground-truth trimaps (tri) are required, as train.py passes them")

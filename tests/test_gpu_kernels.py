@@ -575,6 +575,57 @@ def test_fba_head(G):
             assert G.maxdiff(s[:, 21], al.flatten()) <= 2e-6
 
 
+@pytest.mark.parametrize("n_out,H,W,write_hid", [(7, 40, 64, False), (7, 37, 45, True), (10, 24, 96, True), (10, 19, 33, True)])
+def test_conv_with_head_epilogue(G, n_out, H, W, write_hid):
+    """otvm_conv2d_head: conv3x3 32 -> 16 + LeakyReLU with the 1x1 head + fba_fusion (+ softmax of the trimap logits) in its
+    epilogue (FBA/models.py:383-388, 425-432) == otvm_conv2d followed by otvm_fba_head: the hidden state bit for bit (same
+    tiles, same epilogue arithmetic), the head's outputs to fp32 rounding; interior and edge tiles, with and without the
+    hidden state written."""
+    from otvm_amd import lib as L
+    from otvm_amd.engine import conv_params
+    lib, st = L.load(), G.stream()
+    P = H * W
+    x = rnd(1, 32, H, W, seed=80)
+    w, b = rnd(16, 32, 3, 3, seed=81, scale=1.0 / math.sqrt(32 * 9)), rnd(16, seed=82, scale=0.2)
+    hw, hb = rnd(n_out, 16, seed=83, scale=0.4).contiguous().to(G.DEV), rnd(n_out, seed=84, scale=0.3).to(G.DEV)
+    img = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(85))
+    xa, ia = G.to_act(x), G.to_act(img, c_pad=4, ld=8)
+    cw = G.pack_weight(w)
+    bd = b.to(G.DEV)
+    # reference route
+    hid0 = G.empty_act(H, W, 16, ld=24)
+    G.conv2d(xa, cw, hid0, bd, pad=1, act=2, precision=1)
+    a0 = torch.full((2 * P,), float("nan"), device=G.DEV)
+    t0 = torch.full((3 * P,), float("nan"), device=G.DEV)
+    sm0 = torch.zeros(P * 24, device=G.DEV)
+    L.check(lib.otvm_fba_head(hid0.ptr, hid0.ld, hw.data_ptr(), hb.data_ptr(), n_out, ia.ptr, ia.ld, P, a0.data_ptr(), 2,
+                              t0.data_ptr() if n_out == 10 else 0, sm0.data_ptr() + 64 if n_out == 10 else 0, 24, st))
+    # fused
+    hid1 = G.empty_act(H, W, 16, ld=24)
+    a1 = torch.full((2 * P,), float("nan"), device=G.DEV)
+    t1 = torch.full((3 * P,), float("nan"), device=G.DEV)
+    sm1 = torch.zeros(P * 24, device=G.DEV)
+    p = conv_params(xa, cw, hid1, bd, 1, 1, 1, 2, 0, None, 1)
+    if not write_hid:
+        p.out, p.out_ld = 0, 0
+    h = L.HeadParams()
+    h.w, h.b, h.n_out, h.img, h.img_ld, h.P = hw.data_ptr(), hb.data_ptr(), n_out, ia.ptr, ia.ld, P
+    h.alpha_out, h.alpha_stride = a1.data_ptr(), 2
+    if n_out == 10:
+        h.tri_out, h.sm, h.sm_ld = t1.data_ptr(), sm1.data_ptr() + 64, 24
+    L.check(lib.otvm_conv2d_head(C.byref(p), C.byref(h), st), "conv2d_head")
+    torch.cuda.synchronize()
+    if write_hid:
+        assert torch.equal(G.from_act(hid1), G.from_act(hid0))
+    assert G.maxdiff(a1[::2].cpu(), a0[::2].cpu()) <= 1e-6
+    if n_out == 10:
+        assert G.maxdiff(t1.cpu(), t0.cpu()) <= 1e-6
+        assert G.maxdiff(sm1.cpu(), sm0.cpu()) <= 1e-6
+    # a layer it cannot take is refused
+    p.Cout = 32
+    assert lib.otvm_conv2d_head(C.byref(p), C.byref(h), st) != 0
+
+
 def test_glue_kernels(G):
     from otvm_amd import lib as L
     from otvm_amd.synth_data import soft_alpha
