@@ -168,8 +168,14 @@ typedef struct otvm_head_params {
     float* tri_out;                                 /* n_out == 10: [3][P] softmax of logits 7..9                              */
     float* sm; int sm_ld;                           /* optional (n_out == 10): p_unknown, p_fg, alpha -> sm[i * sm_ld + 3..5]   */
     int64_t img_bs, alpha_bs, tri_bs, sm_bs;
+    const void* w16;                                /* optional: the conv's weights as B fragments of the 16-wide matrix-core tile
+                                                       (otvm_pack_head16_weight_f16x3; Cin == 32): v_mfma_f32_16x16x32_f16 with
+                                                       N = the 16 real output channels instead of a half-empty 32-wide tile   */
 } otvm_head_params;
 int otvm_conv2d_head(const otvm_conv_params* p, const otvm_head_params* h, void* stream);
+int64_t otvm_head16_weight_bytes_f16x3(void);
+/* w_packed = otvm_pack_conv_weight's output of a 3x3 layer with I_pad == 32 and 16 filters, w_scale = its split scale */
+int otvm_pack_head16_weight_f16x3(const float* w_packed, int O, int K_pad, int I_pad, const float* w_scale, void* w16, void* stream);
 int otvm_conv2d(const otvm_conv_params* p, void* stream);
 /* The legal kernel configurations of a layer (f16x3): the patch kernel where the shape allows it, and the implicit-GEMM
  * tiles 256x256 ... 64x64, each alone or with the K range of every output tile shared by S = 2..8 workgroups

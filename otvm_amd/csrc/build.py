@@ -16,6 +16,7 @@ SOURCES = [
     ("conv_f16x3.hip", []),
     ("conv_patch_f16x3.hip", []),
     ("conv_stem_f16x3.hip", []),
+    ("conv_head16_f16x3.hip", []),
     ("bottleneck_f16x3.hip", []),
     ("groupnorm.hip", []),
     ("gram.hip", []),

@@ -620,6 +620,7 @@ int otvm_conv2d_patch_eligible(const otvm_conv_params* p) {
 }
 
 static int patch_run(const otvm_conv_params* p, void* stream, int choice, const otvm_head_params* hd = nullptr);
+int otvm_conv2d_head16_impl(const otvm_conv_params* p, const otvm_head_params* hd, void* stream);   // conv_head16_f16x3.hip
 
 // ABI 17: 3x3 conv to 16 channels with the FBA head in its epilogue (include/otvm_hip.h)
 extern "C" int otvm_conv2d_head(const otvm_conv_params* p, const otvm_head_params* hd, void* stream) {
@@ -629,6 +630,7 @@ extern "C" int otvm_conv2d_head(const otvm_conv_params* p, const otvm_head_param
                  "otvm_conv2d_head: a 3x3 stride-1 f16x3 layer with 16 output channels, no residual / statistics");
     OTVM_REQUIRE(hd->n_out == 7 || (hd->n_out == 10 && hd->tri_out), "otvm_conv2d_head: n_out must be 7, or 10 with tri_out");
     OTVM_REQUIRE(!p->out || ((p->out_ld & 3) == 0 && ((uintptr_t)p->out & 15) == 0), "otvm_conv2d_head: out must be 16-byte aligned");
+    if (hd->w16) return otvm_conv2d_head16_impl(p, hd, stream);    // 32 -> 16 on the 16-wide matrix-core tile
     return patch_run(p, stream, 1, hd);
 }
 

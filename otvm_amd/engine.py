@@ -83,6 +83,7 @@ FUSE_REFINE_TAIL = os.environ.get("OTVM_FUSE_REFINE_TAIL", "0") != "0"
 # (otvm_conv2d_head): the decoder's hidden state is not written at all (unless a training forward needs it), the
 # refinement's is written once and not read back; two launches per frame less.  0 = conv + otvm_fba_head
 FUSE_HEAD = os.environ.get("OTVM_FUSE_HEAD", "1") != "0"
+HEAD16 = os.environ.get("OTVM_HEAD16", "1") != "0"                 # ... on the 16-wide matrix-core tile (csrc/conv_head16_f16x3.hip)
 # round 3: the PPM branches' third of conv_up1.0 computed from the 50 pooled pixels (otvm_ppm_conv_z / _add) instead of
 # convolving their upsampled copies; conv_up1.0 then reads layer 4 only.  OTVM_PPM_ALGEBRA=0 keeps the materialised form.
 PPM_ALGEBRA = os.environ.get("OTVM_PPM_ALGEBRA", "1") != "0"       # the four PPM heads in one launch (otvm_ppm_head)
@@ -198,7 +199,7 @@ class Act:
 
 
 class ConvW:
-    __slots__ = ("w", "K_pad", "O", "I", "I_pad", "kh", "kw", "bias", "w_hi", "w_lo", "w_scale", "w_frag", "w_wfrag")
+    __slots__ = ("w", "K_pad", "O", "I", "I_pad", "kh", "kw", "bias", "w_hi", "w_lo", "w_scale", "w_frag", "w_wfrag", "w16")
 
 
 def pad_amounts(h, w, d):
@@ -252,7 +253,7 @@ def pack_conv_weight(lib, dev, w, ws=False, scale=None, i_pad=None, split=True, 
     L.check(lib.otvm_pack_conv_weight(w.data_ptr(), O, I, kh, kw, 1 if ws else 0,
                                       0 if scale is None else scale.data_ptr(), cw.w.data_ptr(), O_pad,
                                       cw.I_pad, cw.K_pad, stream), "pack_conv_weight")
-    cw.w_hi = cw.w_lo = cw.w_scale = cw.w_frag = cw.w_wfrag = None
+    cw.w_hi = cw.w_lo = cw.w_scale = cw.w_frag = cw.w_wfrag = cw.w16 = None
     if split:
         cw.w_hi = torch.empty(O_pad * cw.K_pad, dtype=torch.float16, device=dev)
         cw.w_lo = torch.empty(O_pad * cw.K_pad, dtype=torch.float16, device=dev)
@@ -271,6 +272,10 @@ def pack_conv_weight(lib, dev, w, ws=False, scale=None, i_pad=None, split=True, 
             cw.w_frag = torch.zeros(int(lib.otvm_patch_weight_bytes_f16x3(O, cw.I_pad)), dtype=torch.uint8, device=dev)
             L.check(lib.otvm_pack_patch_weight_f16x3(cw.w.data_ptr(), O, cw.K_pad, cw.I_pad, cw.w_frag.data_ptr(),
                                                      cw.w_scale.data_ptr(), stream), "pack_patch_weight")
+            if O == 16 and cw.I_pad == 32:                        # ... and as B fragments of the 16-wide tile (otvm_conv2d_head)
+                cw.w16 = torch.zeros(int(lib.otvm_head16_weight_bytes_f16x3()), dtype=torch.uint8, device=dev)
+                L.check(lib.otvm_pack_head16_weight_f16x3(cw.w.data_ptr(), O, cw.K_pad, cw.I_pad, cw.w_scale.data_ptr(),
+                                                          cw.w16.data_ptr(), stream), "pack_head16_weight")
     return cw
 
 
@@ -1065,6 +1070,8 @@ class FramePlan:
         h.tri_out, h.tri_bs = (0 if tri is None else tri), 3 * x.P
         if sm is not None:
             h.sm, h.sm_ld, h.sm_bs = sm.ptr, sm.ld, sm.bs
+        if w.w16 is not None and HEAD16:
+            h.w16 = w.w16.data_ptr()
         self._keep += [p, h]
         flops = 2 * x.P * w.O * 9 * w.I * x.B
         abytes = 4 * (x.B * x.P * w.I + w.O * w.I * 9 + x.B * x.P * (16 if hid_out is not None else 0) + x.B * x.P * 4)

@@ -50,7 +50,7 @@ class GnApplyParams(C.Structure):
 class HeadParams(C.Structure):
     _fields_ = [("w", vp), ("b", vp), ("n_out", i32), ("img", vp), ("img_ld", i32), ("P", i64), ("alpha_out", vp),
                 ("alpha_stride", i32), ("tri_out", vp), ("sm", vp), ("sm_ld", i32),
-                ("img_bs", i64), ("alpha_bs", i64), ("tri_bs", i64), ("sm_bs", i64)]
+                ("img_bs", i64), ("alpha_bs", i64), ("tri_bs", i64), ("sm_bs", i64), ("w16", vp)]
 
 
 class GramParams(C.Structure):
@@ -100,6 +100,8 @@ _PROTOS = {
     "otvm_conv2d_input_norm_kind": (i32, [C.POINTER(ConvParams)]),
     "otvm_conv2d_accepts_input_residual": (i32, [C.POINTER(ConvParams)]),
     "otvm_conv2d_head": (i32, [C.POINTER(ConvParams), C.POINTER(HeadParams), vp]),
+    "otvm_head16_weight_bytes_f16x3": (i64, []),
+    "otvm_pack_head16_weight_f16x3": (i32, [vp, i32, i32, i32, vp, vp, vp]),
     "otvm_conv2d_candidates": (i32, [C.POINTER(ConvParams), C.POINTER(i32), i32]),
     "otvm_gn_apply": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, i32, vp, vp, i32, i32, vp, i32, vp]),
     "otvm_maxpool3x3s2": (i32, [vp, i32, i32, i32, i32, vp, i32, vp]),
