@@ -83,7 +83,12 @@ FUSE_REFINE_TAIL = os.environ.get("OTVM_FUSE_REFINE_TAIL", "0") != "0"
 # (otvm_conv2d_head): the decoder's hidden state is not written at all (unless a training forward needs it), the
 # refinement's is written once and not read back; two launches per frame less.  0 = conv + otvm_fba_head
 FUSE_HEAD = os.environ.get("OTVM_FUSE_HEAD", "1") != "0"
-HEAD16 = os.environ.get("OTVM_HEAD16", "1") != "0"                 # ... on the 16-wide matrix-core tile (csrc/conv_head16_f16x3.hip)
+HEAD16 = os.environ.get("OTVM_HEAD16", "1") != "0"
+# round 4, measured and rejected: the PPM chain (pooling, heads, Z table: ~110 us of small launches that need layer 4 only) on an
+# auxiliary stream BESIDE conv_up1.0's layer-4 part instead of in front of it (fork / join markers inside the launch list, captured
+# into the list's hipGraph as a second branch): 43.8 / 43.7 frames/s against 44.5 / 44.5 serial on one box -- the pooling is an
+# HBM-speed pass and takes from the convolution what it gives (work-conserving).  1 = fork (tests cover both)
+PPM_FORK = os.environ.get("OTVM_PPM_FORK", "0") != "0"                 # ... on the 16-wide matrix-core tile (csrc/conv_head16_f16x3.hip)
 # round 3: the PPM branches' third of conv_up1.0 computed from the 50 pooled pixels (otvm_ppm_conv_z / _add) instead of
 # convolving their upsampled copies; conv_up1.0 then reads layer 4 only.  OTVM_PPM_ALGEBRA=0 keeps the materialised form.
 PPM_ALGEBRA = os.environ.get("OTVM_PPM_ALGEBRA", "1") != "0"       # the four PPM heads in one launch (otvm_ppm_head)
@@ -916,6 +921,7 @@ class FramePlan:
         self._bufs = {}
         self._keep = []
         self.graphs, self._graph_warm = {}, {}
+        self._aux = None
         self._fused_stats = []
         self._convs = []
         self.n_gn = 0
@@ -1431,6 +1437,9 @@ class FramePlan:
         conv5 = self.PPMCAT.ch(0, 2048)
         self.POOL_B = self.raws("ppm_pool", 50 * 2048)
         self.POOL_WS_B = self.raws("ppm_ws", int(lib.otvm_ppm_pool_ws_bytes(H8, 2048)) // 4)
+        fork = PPM_FORK and ppm_alg and FUSE_PPM_HEAD
+        if fork:
+            S.append(("fork", (), "fork (PPM chain beside conv_up1.0)"))
         for b in range(self.B):                          # (three small launches per image: not batched)
             S.append((lib.otvm_ppm_pool, (conv5.img(b).ptr, H8, W8, 2048, conv5.ld, self.POOL_B[b].data_ptr(),
                                           self.POOL_WS_B[b].data_ptr()), "ppm_pool"))
@@ -1468,12 +1477,17 @@ class FramePlan:
         if self._ppm_algebra:
             # the PPM maps are never upsampled: conv_up1.0 over layer 4 alone, then the PPM channels' share of the same
             # convolution from the 50 pooled pixels (resample.hip: otvm_ppm_conv_z / _add), then the GroupNorm statistics
-            self.conv(S, self.PPMCAT.ch(0, 2048), de + "conv_up1.0.main", u1, pad=1)
             self.PPM_Z = self.raws("ppm_z", 9 * 50 * 256)
             for b in range(self.B):
                 yp = (C.c_void_p * 4)(*[y.img(b).ptr for y in ys])
                 self._keep.append(yp)
                 S.append((lib.otvm_ppm_conv_z, (yp, ys[0].ld, self.e.W_ppm.data_ptr(), self.PPM_Z[b].data_ptr()), "ppm_conv_z"))
+            if fork:
+                S.append(("endfork", (), "endfork"))
+            self.conv(S, self.PPMCAT.ch(0, 2048), de + "conv_up1.0.main", u1, pad=1)
+            if fork:
+                S.append(("join", (), "join"))
+            for b in range(self.B):
                 S.append(("ppm_add", (self.PPM_Z[b].data_ptr(), H8, W8, u1.img(b).ptr, u1.ld), b, "ppm_conv_add"))
             # the gather writes the layer's final values: it also accumulates their GroupNorm sums (bound in _bind_stats)
             import types
@@ -1584,6 +1598,8 @@ class FramePlan:
         if prof is None and self.e.check_level >= 3:
             # first run of a new checkpoint: scan the input and the output of every convolution
             for st in self.steps[key]:
+                if isinstance(st[0], str):
+                    continue                              # (fork / join markers: one serial stream here)
                 if st[2].startswith("conv "):
                     self.e.guard(st[5][0], "input of " + st[2], stream)
                 rc = st[0](*st[1], stream)
@@ -1598,11 +1614,7 @@ class FramePlan:
                 if g is None and self._graph_warm.get(key):
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):   # other threads (the IO pipeline) keep issuing copies
-                        cs = torch.cuda.current_stream(self.dev).cuda_stream
-                        for st in self.steps[key]:
-                            rc = st[0](*st[1], cs)
-                            if rc != 0:
-                                L.check(rc, st[2])
+                        self._launch(self.steps[key], torch.cuda.current_stream(self.dev))
                     self.graphs[key] = g
                 if g is not None:
                     if tstream is None:
@@ -1612,13 +1624,12 @@ class FramePlan:
                             g.replay()
                     return
                 self._graph_warm[key] = True              # first use: direct launches (module loading, warm-up)
-            for st in self.steps[key]:
-                rc = st[0](*st[1], stream)
-                if rc != 0:
-                    L.check(rc, st[2])
+            self._launch(self.steps[key], tstream if tstream is not None else torch.cuda.current_stream(self.dev), stream)
             return
         # instrumented pass (bench.py roofline leg): HIP events around every conv launch, on this stream
         for st in self.steps[key]:
+            if isinstance(st[0], str):
+                continue
             if st[2].startswith("conv "):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -1627,6 +1638,34 @@ class FramePlan:
                 prof.append((st[2], st[3], e0, e1, st[4]))
             else:
                 rc = st[0](*st[1], stream)
+            if rc != 0:
+                L.check(rc, st[2])
+
+    def _launch(self, steps, tmain, handle=None):
+        """Issue ``steps`` on the torch stream ``tmain`` (raw handle ``handle``).  ("fork",) ... ("endfork",) sends the steps in
+        between to the plan's auxiliary stream, ordered behind everything issued on ``tmain`` so far; ("join",) makes ``tmain``
+        wait for them.  Inside a graph capture the auxiliary stream joins the capture through the fork event."""
+        handle = tmain.cuda_stream if handle is None else handle
+        cur, aux = handle, None
+        for st in steps:
+            f = st[0]
+            if isinstance(f, str):
+                if f == "fork":
+                    if self._aux is None:
+                        self._aux = torch.cuda.Stream(device=self.dev)
+                    aux = self._aux
+                    ev = torch.cuda.Event()
+                    ev.record(tmain)
+                    aux.wait_event(ev)
+                    cur = aux.cuda_stream
+                elif f == "endfork":
+                    cur = handle
+                elif f == "join":
+                    ev = torch.cuda.Event()
+                    ev.record(aux)
+                    tmain.wait_event(ev)
+                continue
+            rc = f(*st[1], cur)
             if rc != 0:
                 L.check(rc, st[2])
 
