@@ -18,9 +18,9 @@
 // i.e. at the level of the fp32 rounding of mean / rstd themselves; one MFMA pass (PASSES = 1).  PASSES = 3 keeps the
 // f16x3 operand split of the convolutions (hi*hi + hi*lo + lo*hi) for comparison (tests/test_gpu_kernels.py measures both
 // against the statistics the convolution's own epilogue accumulates).  The channel sums s are taken from the fp32 values.
-// Accumulation: products of two fp16 values are exact in the fp32 MFMA accumulator; a workgroup adds 256 pixels in the
-// MFMA accumulator, then folds it into a second fp32 accumulator (<= 16 folds), and the per-workgroup partials -- one per
-// (block of the matrix, chunk of <= ~1000 pixels) -- are added in fp64 by gn_predict_kernel, which also contracts with M_g.
+// Accumulation: products of two fp16 values are exact in the fp32 MFMA accumulator; a workgroup adds its chunk of <= ~1000
+// pixels there (~1e-6 of unbiased noise per entry, far below the operands' own), and the per-workgroup partials -- one per
+// (block of the matrix, pixel chunk) -- are added in fp64 by gn_predict_kernel, which also contracts them with M_g.
 #include "common.h"
 #include <stdlib.h>
 
