@@ -164,7 +164,7 @@ __global__ void edt_columns_tall_kernel(const uint8_t* __restrict__ cls, int H, 
 // exact.  A thread then writes the pixel's channels 3..11 of x11 (six Gaussians, the two soft channels
 // trimap2_soft = [tri[:,0], tri[:,2]] (alpha/model.py:51), the zero pad) and two_chan_trimap into d80[70..71]
 // (FBA/models.py:378, :418) in one go.
-__device__ __forceinline__ int edt_row_best(const int* __restrict__ g2, const int* __restrict__ bmin, int W, int nb, int x) {
+__device__ __forceinline__ int edt_row_best(const int* __restrict__ g2, const int* __restrict__ cidx, int W, int x) {
     int best = g2[x];
     // near field: outward scan, stops at dx^2 >= best (the trip count is the pixel's own distance)
     int dx = 1;
@@ -176,35 +176,55 @@ __device__ __forceinline__ int edt_row_best(const int* __restrict__ g2, const in
         best = min(best, dx * dx + c);
     }
     if (dx == 32 && dx * dx < best) {
-        // far field: whole 32-column blocks, outwards; a block is skipped when even its best case
-        // (nearest column, smallest g2 of the block) cannot improve -- pixels far from every seed cross the
-        // empty columns in W/32 steps instead of W
-        const int bx = x >> 5;
-        for (int r = 1;; ++r) {
-            bool any = false;
-            const int bl = bx - r, br = bx + r;
-            if (bl >= 0) {
-                const int dm = x - (bl * 32 + 31);
-                if (dm * dm < best) {
-                    any = true;
-                    if (dm * dm + bmin[bl] < best)
-                        for (int i = bl * 32 + 31; i >= bl * 32 && (x - i) * (x - i) < best; --i) best = min(best, (x - i) * (x - i) + g2[i]);
-                }
-            }
-            if (br < nb) {
-                const int dm = br * 32 - x;
-                if (dm * dm < best) {
-                    any = true;
-                    if (dm * dm + bmin[br] < best) {
-                        const int e = br * 32 + 32 < W ? br * 32 + 32 : W;
-                        for (int i = br * 32; i < e && (i - x) * (i - x) < best; ++i) best = min(best, (i - x) * (i - x) + g2[i]);
-                    }
-                }
-            }
-            if (!any) break;
-        }
+        // far field (round 4): the minimiser i*(x) of (x - i)^2 + g2[i] is monotone in x (the cost is Monge), so it lies between
+        // the minimisers of the two coarse points around x (every 32nd column, found once per row: edt_coarse_argmin).  The work
+        // of a row is bounded by 32 (W + W / 32) candidates whatever the picture; the first far field walked 32-column blocks
+        // outwards from every pixel: 145 us of a 230 us kernel on a disc-shaped trimap.  |i - x| < 32 is covered above.
+        const int c = x >> 5;
+        const int ilo = cidx[c], ihi = cidx[c + 1];
+        const int e0 = ihi < x - 32 ? ihi : x - 32;
+        for (int i = ilo; i <= e0; ++i) best = min(best, (x - i) * (x - i) + g2[i]);
+        const int s1 = ilo > x + 32 ? ilo : x + 32;
+        for (int i = s1; i <= ihi; ++i) best = min(best, (i - x) * (i - x) + g2[i]);
     }
     return best;
+}
+
+// leftmost minimiser of (xc - i)^2 + g2[i] for the coarse points xc = min(32 c, W - 1), c = 0 .. nb: two threads per point, one
+// walking the 32-column blocks to the left of xc (xc included), one to the right, each stopping when the blocks' nearest column is
+// farther than its best; blocks whose best case (nearest column, smallest g2) cannot win are skipped.  Ties go to the smaller
+// index on both sides and in the merge, so the bounds of the fine pass bracket the leftmost minimiser.
+__device__ __forceinline__ void edt_coarse_argmin(const int* __restrict__ g2, const int* __restrict__ bmin, int W, int nb, int c,
+                                                  int dir, int* __restrict__ cidx) {
+    const int xc = c * 32 < W - 1 ? c * 32 : W - 1;
+    int best = 0x7fffffff, arg = xc;
+    if (dir == 0) {
+        for (int b = xc >> 5; b >= 0; --b) {
+            const int hi = b * 32 + 31 < xc ? b * 32 + 31 : xc;
+            const int dm = xc - hi;
+            if (dm * dm > best) break;
+            if (dm * dm + bmin[b] <= best)
+                for (int i = hi; i >= b * 32; --i) {
+                    const int v = (xc - i) * (xc - i) + g2[i];
+                    if (v <= best) { best = v; arg = i; }
+                }
+        }
+    } else {
+        for (int b = (xc + 1) >> 5; b < nb; ++b) {
+            const int lo = b * 32 > xc + 1 ? b * 32 : xc + 1;
+            const int dm = lo - xc;
+            if (dm * dm >= best) break;
+            if (dm * dm + bmin[b] < best) {
+                const int e = b * 32 + 32 < W ? b * 32 + 32 : W;
+                for (int i = lo; i < e; ++i) {
+                    const int v = (i - xc) * (i - xc) + g2[i];
+                    if (v < best) { best = v; arg = i; }
+                }
+            }
+        }
+    }
+    const int ob = __shfl_xor(best, 1), oa = __shfl_xor(arg, 1);   // the partner walks the other direction (adjacent lane)
+    if (dir == 0) cidx[c] = ob < best ? oa : arg;
 }
 
 __global__ __launch_bounds__(256) void edt_rows_encode_kernel(const uint16_t* __restrict__ g, const float* __restrict__ probs,
@@ -216,6 +236,7 @@ __global__ __launch_bounds__(256) void edt_rows_encode_kernel(const uint16_t* __
     const int nb = (W + 31) >> 5;
     int* g2[2] = {lds, lds + W};
     int* bmin[2] = {lds + 2 * W, lds + 2 * W + nb};        // min of g2 over each 32-column block
+    int* cidx[2] = {lds + 2 * W + 2 * nb, lds + 2 * W + 3 * nb + 1};   // minimisers of the nb + 1 coarse points
     const float den0 = (float)(2.0 * ((0.02 * 320) * (0.02 * 320)));   // 2*((sigma*L)^2), utils/utils.py:33-37
     const float den1 = (float)(2.0 * ((0.08 * 320) * (0.08 * 320)));
     const float den2 = (float)(2.0 * ((0.16 * 320) * (0.16 * 320)));
@@ -242,12 +263,17 @@ __global__ __launch_bounds__(256) void edt_rows_encode_kernel(const uint16_t* __
         }
     }
     __syncthreads();
+    for (int t = threadIdx.x; t < 4 * (nb + 1); t += blockDim.x) {     // (class, coarse point, direction); pairs on adjacent lanes
+        const int k = t / (2 * (nb + 1)), r = t - k * 2 * (nb + 1);
+        if (on[k]) edt_coarse_argmin(g2[k], bmin[k], W, nb, r >> 1, r & 1, cidx[k]);
+    }
+    __syncthreads();
     for (int x = threadIdx.x; x < W; x += blockDim.x) {
         float e[6];
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             if (on[k]) {
-                const float d = sqrtf((float)((dbg & 4) ? g2[k][x] : edt_row_best(g2[k], bmin[k], W, nb, x)));
+                const float d = sqrtf((float)((dbg & 4) ? g2[k][x] : edt_row_best(g2[k], cidx[k], W, x)));
                 const float v = -(d * d);                  // -dt(1 - tk)**2
                 if (dbg & 8) { e[3 * k] = v; e[3 * k + 1] = v + 1.f; e[3 * k + 2] = v + 2.f; }
                 else { e[3 * k] = expf(v / den0); e[3 * k + 1] = expf(v / den1); e[3 * k + 2] = expf(v / den2); }
@@ -298,7 +324,7 @@ extern "C" int otvm_trimap_encode(const float* probs, int Hp, int Wp, const uint
     else hipLaunchKernelGGL(edt_columns_tall_kernel, dim3(otvm_ceil_div(Wp, 64), 2), dim3(64), 0, s, cls_out, Hp, Wp, g);
     static const int dbg = getenv("OTVM_EDT_DBG") ? atoi(getenv("OTVM_EDT_DBG")) : 0;     // timing probes (results WRONG when set)
     if (!(dbg & 16))
-    hipLaunchKernelGGL(edt_rows_encode_kernel, dim3(Hp), dim3(256), 2 * (Wp + (Wp + 31) / 32) * sizeof(int), s, g, probs, Hp, Wp,
+    hipLaunchKernelGGL(edt_rows_encode_kernel, dim3(Hp), dim3(256), (2 * Wp + 4 * ((Wp + 31) / 32) + 2) * sizeof(int), s, g, probs, Hp, Wp,
                        flags, x11, x11_ld, d80, d80_ld, dbg);
     OTVM_CHECK_LAUNCH("otvm_trimap_encode");
     return 0;
