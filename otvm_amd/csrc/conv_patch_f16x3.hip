@@ -81,7 +81,7 @@ __device__ __forceinline__ void split4p(const f32x4 v, f16x4& hi, f16x4& lo) {
 // fragments of its BN output channels, copied verbatim from the fragment-major weight array (1-KiB blocks).
 // TAPG = 9: one weight stage per channel stage (narrow layers); TAPG = 3: wide layers (BN = 256), where nine taps of
 // weights (144 KiB) would not fit beside the patch.
-template <int TH, int BN, int NW, int DIL, int TAPG, bool INRES = false, bool HEAD = false>
+template <int TH, int BN, int NW, int DIL, int TAPG, bool INRES = false, bool HEAD = false, int NWN = 1>
 __global__ __launch_bounds__(NW * 64)
 __attribute__((amdgpu_waves_per_eu((TAPG == 3 && BN <= 32 && !INRES) ? 3 : 1, (TAPG == 3 && BN <= 32 && !INRES) ? 3 : 10)))
 void conv_patch_f16x3_kernel(const PatchArgs pa) {
@@ -102,12 +102,18 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
         if (p.in_scale) { p.in_scale += zb * p.norm_bs; p.in_shift += zb * p.norm_bs; }
     }
     constexpr int NT = NW * 64;
-    constexpr int TM = TH / NW, TN = BN / 32;
+    // NWN = 1: a wave owns TM = TH / NW output rows x all BN / 32 channel tiles.  NWN > 1 (the 256-channel tiles, round 4): the
+    // waves form an (NW / NWN) x NWN grid -- wave_m picks the rows, wave_n a share of the channel tiles: with 8 waves, TM = 1 and
+    // 8 channel tiles a wave read 2 A + 16 B fragments from LDS per 24 MFMAs, all eight waves the same 16 KiB of weights; as
+    // 4 x 2 waves (TM = 2, TN = 4) it reads 4 + 8 for the same 24 MFMAs on the same 128 accumulator registers
+    constexpr int NWM = NW / NWN, TNW = BN / 32;
+    constexpr int TM = TH / NWM, TN = TNW / NWN;
+    static_assert(NW % NWN == 0 && TH % NWM == 0 && TNW % NWN == 0, "bad wave grid");
     constexpr int PW = 32 + 2 * DIL, PH = TH + 2 * DIL, NPIX = PH * PW;
     constexpr int NG = 9 / TAPG;
-    static_assert(TH % NW == 0 && BN % 32 == 0 && 9 % TAPG == 0, "bad tile");
+    static_assert(BN % 32 == 0 && 9 % TAPG == 0, "bad tile");
     constexpr int PATCH_HALFS = 2 * NPIX * LDP;                        // hi + lo
-    constexpr int B_PIECES = TAPG * TN * 2 * 64;                       // 16-byte pieces of one weight stage
+    constexpr int B_PIECES = TAPG * TNW * 2 * 64;                      // 16-byte pieces of one weight stage
     constexpr int B_HALFS = B_PIECES * 8;
     constexpr int EPI_HALFS = NW * 32 * 36 * 2 * (HEAD ? 2 : 1);       // epilogue patches (fp32) expressed in halfs
     constexpr int SM_HALFS = PATCH_HALFS + B_HALFS > EPI_HALFS ? PATCH_HALFS + B_HALFS : EPI_HALFS;
@@ -117,6 +123,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     _Float16* Bs = smem + PATCH_HALFS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_m = NWN == 1 ? wave : wave % NWM, nt0 = NWN == 1 ? 0 : (wave / NWM) * TN;   // first row block / channel tile of the wave
 #ifdef OTVM_PATCH_STAGGER
     // timing experiment: the second workgroup of every CU starts half a tile late, so that one workgroup's epilogue / prologue
     // meets the other's MFMA phase (later workgroups inherit the offset of the slot they take over)
@@ -156,7 +163,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
             const int i = tid + k * NT;
             if (i < B_PIECES) {
                 const int l = i & 63, blk = i >> 6;                     // blk = (tapl*TN + b)*2 + hl
-                const int hl = blk & 1, tb = blk >> 1, b = tb % TN, tap = g * TAPG + tb / TN;
+                const int hl = blk & 1, tb = blk >> 1, b = tb % TNW, tap = g * TAPG + tb / TNW;
                 const int64_t src = (((((int64_t)cb32 * 9 + tap) * nbs + nb0 + b) * 2 + ks) * 2 + hl) * 512 + l * 8;
                 rb[k] = *reinterpret_cast<const f16x8*>(p.wf + src);
             }
@@ -246,7 +253,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                     const f16x8 one = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
                     ah[a] = one * (_Float16)(float)(lane + tap); al[a] = one;
 #else
-                    const int o = ((wave * TM + a + ky * DIL) * PW + kx * DIL + frow) * LDP + 8 * fh;
+                    const int o = ((wave_m * TM + a + ky * DIL) * PW + kx * DIL + frow) * LDP + 8 * fh;
                     ah[a] = *reinterpret_cast<const f16x8*>(&Ph[o]);
                     al[a] = *reinterpret_cast<const f16x8*>(&Pl[o]);
 #endif
@@ -264,8 +271,8 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                         const f16x8 one = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
                         bh[j] = one; bl[j] = one * (_Float16)(float)lane;
 #else
-                        bh[j] = *reinterpret_cast<const f16x8*>(&Bs[((tl * TN + b0 + j) * 2) * 512 + lane * 8]);
-                        bl[j] = *reinterpret_cast<const f16x8*>(&Bs[((tl * TN + b0 + j) * 2 + 1) * 512 + lane * 8]);
+                        bh[j] = *reinterpret_cast<const f16x8*>(&Bs[((tl * TNW + nt0 + b0 + j) * 2) * 512 + lane * 8]);
+                        bl[j] = *reinterpret_cast<const f16x8*>(&Bs[((tl * TNW + nt0 + b0 + j) * 2 + 1) * 512 + lane * 8]);
 #endif
                     }
 #if OTVM_PABL_NOMFMA
@@ -306,14 +313,14 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
         // here a wave turns its TM = 2 accumulator tiles into [pixel][channel] rows in LDS and every lane takes ONE pixel --
         // lanes 0-31 the wave's first image row, lanes 32-63 the second: filter scale, bias, activation (the arithmetic of the
         // plain epilogue), the hidden state's 64 bytes (optional), then the head on the 16 values in registers.
-        static_assert(TM == 2 && TN == 1, "the head epilogue is written for two pixel rows and one channel tile per wave");
+        static_assert(TM == 2 && TN == 1 && NWN == 1, "the head epilogue is written for two pixel rows and one channel tile per wave");
         float* patch = reinterpret_cast<float*>(smem) + wave * (2 * 32 * 36);
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
             for (int e = 0; e < 16; ++e) patch[a * (32 * 36) + ((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][0][e];
         const int a = lane >> 5, px = lane & 31;
-        const int y = ty0 + wave * TM + a, x = tx0 + px;
+        const int y = ty0 + wave_m * TM + a, x = tx0 + px;
         float h[16];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -357,28 +364,28 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sc4[b][j] = p.wscale[n0 + b * 32 + pc + j];
+            for (int j = 0; j < 4; ++j) sc4[b][j] = p.wscale[n0 + (nt0 + b) * 32 + pc + j];
             bi4[b] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (p.bias) {
 #pragma unroll
             for (int b = 0; b < TN; ++b)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) bi4[b][j] = p.bias[n0 + b * 32 + pc + j];
+                for (int j = 0; j < 4; ++j) bi4[b][j] = p.bias[n0 + (nt0 + b) * 32 + pc + j];
         }
         auto load_res = [&](int t, f32x4 (&r)[4]) __attribute__((always_inline)) {
             const int b = t / TM, a = t - b * TM;
-            const int64_t m0r = (int64_t)(ty0 + wave * TM + a) * p.W + tx0 + prow;
+            const int64_t m0r = (int64_t)(ty0 + wave_m * TM + a) * p.W + tx0 + prow;
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4)
-                r[r4] = *reinterpret_cast<const f32x4*>(p.residual + (m0r + r4 * 8) * p.res_ld + n0 + b * 32 + pc);
+                r[r4] = *reinterpret_cast<const f32x4*>(p.residual + (m0r + r4 * 8) * p.res_ld + n0 + (nt0 + b) * 32 + pc);
         };
         f32x4 rnext[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
         if (RES) load_res(0, rnext);
 #pragma unroll
         for (int t = 0; t < TM * TN; ++t) {
             const int b = t / TM, a = t - b * TM;
-            const int64_t m0r = (int64_t)(ty0 + wave * TM + a) * p.W + tx0 + prow;
+            const int64_t m0r = (int64_t)(ty0 + wave_m * TM + a) * p.W + tx0 + prow;
             f32x4 rres[4];
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) rres[r4] = rnext[r4];
@@ -391,7 +398,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                 v = v * sc4[b] + bi4[b];
                 if (RES) v += rres[r4];
                 v.x = otvm_act(v.x, ACT); v.y = otvm_act(v.y, ACT); v.z = otvm_act(v.z, ACT); v.w = otvm_act(v.w, ACT);
-                *reinterpret_cast<f32x4*>(p.out + (m0r + r4 * 8) * p.out_ld + n0 + b * 32 + pc) = v;
+                *reinterpret_cast<f32x4*>(p.out + (m0r + r4 * 8) * p.out_ld + n0 + (nt0 + b) * 32 + pc) = v;
             }
         }
     };
@@ -401,7 +408,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
         const int prow = lane >> 3, pc = (lane & 7) * 4;
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-            const int n4 = n0 + b * 32 + pc;
+            const int n4 = n0 + (nt0 + b) * 32 + pc;
             f32x4 sc4 = {0.f, 0.f, 0.f, 0.f}, bi4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -412,7 +419,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
             }
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
-                const int y = ty0 + wave * TM + a;
+                const int y = ty0 + wave_m * TM + a;
                 // residual: all four 16-byte loads of this tile are issued before anything waits on them
                 f32x4 rres[4];
                 const bool res_vec = p.residual && vec_ok && (FULL || n4 + 3 < p.Cout);
@@ -472,7 +479,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
         __syncthreads();
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
-            const int nl = b * 32 + col;
+            const int nl = (nt0 + b) * 32 + col;
             const int n = n0 + nl;
             float s = 0.f, ss = 0.f;
             if (n < p.Cout) {
@@ -480,7 +487,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                 const float bias = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
                 for (int a = 0; a < TM; ++a) {
-                    const int y = ty0 + wave * TM + a;
+                    const int y = ty0 + wave_m * TM + a;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) {
                         const int x = tx0 + (e & 3) + 8 * (e >> 2) + rbase;
@@ -551,12 +558,12 @@ __global__ __launch_bounds__(256) void pack_patch_weight_kernel(const float* __r
     }
 }
 
-template <int TH, int BN, int NW, int DIL, int TAPG = 9, bool INRES = false, bool HEAD = false>
+template <int TH, int BN, int NW, int DIL, int TAPG = 9, bool INRES = false, bool HEAD = false, int NWN = 1>
 int launch_patch(PatchArgs& a, hipStream_t s) {
     a.tiles_x = otvm_ceil_div(a.W, 32);
     a.tiles_y = otvm_ceil_div(a.H, TH);
     a.tiles_n = otvm_ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL, TAPG, INRES, HEAD>), dim3(a.tiles_x * a.tiles_y * a.tiles_n, a.batch), dim3(NW * 64), 0, s, a);
+    hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL, TAPG, INRES, HEAD, NWN>), dim3(a.tiles_x * a.tiles_y * a.tiles_n, a.batch), dim3(NW * 64), 0, s, a);
     OTVM_CHECK_LAUNCH("otvm_conv2d(patch f16x3)");
     return 0;
 }
@@ -668,6 +675,11 @@ static int patch_run(const otvm_conv_params* p, void* stream, int choice, const 
         return p->Cout <= 32 ? launch_patch<8, 32, 4, 1, 3, true>(a, s) : launch_patch<8, 64, 4, 1, 9, true>(a, s);
     }
     if (is_wide) {
+        // the eight waves as 4 x 2 (two rows x four channel tiles each) instead of 8 x 1 (one row x eight tiles): a third less
+        // LDS fragment traffic per MFMA; OTVM_PATCH_WIDE_NWN=1 keeps the round-2 arrangement (same-box A/B); 2 x 4 waves (four
+        // rows x two tiles) spills 108 B
+        static const int nwn = getenv("OTVM_PATCH_WIDE_NWN") ? atoi(getenv("OTVM_PATCH_WIDE_NWN")) : 2;
+        if (nwn == 2 && p->dil == 1) return launch_patch<8, 256, 8, 1, 3, false, false, 2>(a, s);   // (dilated: 52 / 92 B of scratch)
         if (p->dil == 1) return launch_patch<8, 256, 8, 1, 3>(a, s);
         if (p->dil == 2) return launch_patch<8, 256, 8, 2, 3>(a, s);
         return launch_patch<8, 256, 8, 4, 3>(a, s);
