@@ -696,6 +696,12 @@ static int patch_run(const otvm_conv_params* p, void* stream, int choice, const 
     // workgroups walking several tiles, the next tile's first stage requested under the last MFMAs of the current one --
     // is worth 4 % on its own code (0.710 -> 0.680 ms) but keeps 60 prefetch registers live across the epilogue: 47 spilled
     // dwords at two waves per SIMD, against 0.591 ms for this one-tile-per-workgroup kernel.)
+    // round 4, <= 32 output channels on maps of >= 2^20 pixels: 16 x 32 pixel blocks, four waves x four rows -- 18 instead of 28
+    // LDS fragment reads per 36 MFMAs (a wave's six patch rows serve its four output rows and three taps of a filter column;
+    // the compiler already shares equal fragment loads between taps): 80->32 at 1088x1920 0.429 -> 0.415 ms, 64->32 0.310 ->
+    // 0.301; no gain at 480x832 (two workgroups per CU instead of three).  Two waves x four rows on 8 x 32 blocks: 0.447 / 0.320.
+    static const int rows4 = getenv("OTVM_PATCH32_ROWS4") ? atoi(getenv("OTVM_PATCH32_ROWS4")) : 1;
+    if (p->dil == 1 && p->Cout <= 32 && rows4 && (int64_t)p->H * p->W >= (1 << 20)) return launch_patch<16, 32, 4, 1, 3>(a, s);
     if (p->dil == 1) return p->Cout <= 32 ? launch_patch<8, 32, 4, 1, 3>(a, s) : launch_patch<8, 64, 4, 1>(a, s);
     if (p->dil == 2) return launch_patch<8, 64, 4, 2>(a, s);
     return launch_patch<8, 64, 4, 4>(a, s);

@@ -260,6 +260,7 @@ def test_demo_dove_layout_1080p_clip_through_eval_cli(tmp_path, synth_sd):
 
 LAYERS = [  # (Cin, Cout, k, dil, H, W): real 1080p layer geometries
     (64, 64, 3, 1, 1088, 1920),      # refinement 64->64, full resolution (patch kernel)
+    (80, 32, 3, 1, 1088, 1920),      # conv_up4.0 (16x32-pixel patch blocks)
     (256, 256, 3, 1, 272, 480),      # STM decoder RF2 (wide patch kernel)
     (512, 512, 3, 4, 136, 240),      # FBA layer4 dilated conv
     (1024, 256, 1, 1, 136, 240),     # FBA layer3 1x1

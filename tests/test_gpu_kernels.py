@@ -50,6 +50,7 @@ CONV_CASES = [
     (96, 256, 1, 1, 0, 1, 352, 353, True, 1, 1, True),      # large M, Cout 256: the two-stage 256-row tiles
     (40, 128, 3, 2, 1, 1, 704, 705, True, 2, 0, False),     # large M, generic K decode (Cin % 32 != 0), stride 2
     (64, 384, 1, 1, 0, 1, 351, 353, False, 0, 0, False),    # ragged M and N tiles on the big tiles
+    (16, 32, 3, 1, 1, 1, 1030, 1031, True, 2, 0, False),    # >= 2^20 pixels, <= 32 filters: 16x32-pixel patch blocks, ragged edges
 ]
 
 
