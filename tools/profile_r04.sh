@@ -32,11 +32,15 @@ python tools/glue_bench.py --probe > $O/glue_isolated_1080p.json 2> $O/glue.err
 (cd _old 2>/dev/null && python ../tools/glue_bench.py > $O/glue_isolated_1080p_round3_tree.json 2>/dev/null)
 python bench.py --batch 2 --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_1080p_batch2.json 2> $O/bench_b2.err
 python bench.py --height 480 --width 832 --batch 4 --steps 47 --warmup 3 --no-cpu-baseline > $O/bench_480p_batch4.json 2> $O/bench_480b4.err
-for v in "OTVM_GN_PREDICT=0" "OTVM_FUSE_HEAD=0" "OTVM_EVDEC_LATE=0" "OTVM_GN_PREDICT_PASSES=3" "OTVM_FUSE_REFINE_TAIL=1" "OTVM_GN_PREDICT=1"; do
+rm -f $O/ab_1080p.txt
+for v in "OTVM_GN_PREDICT=0" "OTVM_FUSE_HEAD=0" "OTVM_EVDEC_LATE=0" "OTVM_PATCH_WIDE_NWN=1" "OTVM_PATCH32_ROWS4=0" "OTVM_GN_PREDICT=1"; do
   env $v python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['value'],2), 'frames/s')" >> $O/ab_1080p.txt
 done
 (cd _old 2>/dev/null && python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('round-3 tree (95e9ca9), same box', round(d['value'],2), 'frames/s')" >> $O/ab_1080p.txt)
 cat $O/ab_1080p.txt
+# BASELINE configs[4]: 3840x2160, T=200, every frame memorised, nothing evicted
+(unset OTVM_TUNE_FILE; python bench.py --height 2160 --width 3840 --steps 197 --warmup 3 --stress-bank --no-cpu-baseline --no-roofline > $O/bench_4k_T200_growing.json 2> $O/bench_4k.err)
+head -c 300 $O/bench_4k_T200_growing.json; echo
 find $O -name "*kernel_trace.csv" -delete
 cat $O/bench_1080p.json | head -c 700; echo; cat $O/bench_480p.json | head -c 300; echo
 head -24 $O/kernel_stats_1080p.md; cat $O/mfma_busy_1080p.md | head -16; cat $O/conv_traffic_1080p.json; head -30 $O/kernel_traffic_gbps_1080p.md

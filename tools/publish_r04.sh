@@ -12,4 +12,5 @@ cp $O/tune_1080p.json $P/${T}_autotune_1080p.json; cp $O/tune_480p.json $P/${T}_
 cp $O/layer_roofline_1080p.md $P/${T}_layer_roofline_1080p.md; cp $O/layer_roofline_480p.md $P/${T}_layer_roofline_480p.md
 cp $O/glue_isolated_1080p.json $P/${T}_glue_isolated_1080p.json; cp $O/glue_isolated_1080p_round3_tree.json $P/${T}_glue_isolated_1080p_round3_tree.json
 cp $O/ab_1080p.txt $P/${T}_ab_1080p.txt
+[ -s $O/bench_4k_T200_growing.json ] && cp $O/bench_4k_T200_growing.json $P/${T}_bench_4k_T200_growing.json
 git -C $R status --short profiles | head -40
