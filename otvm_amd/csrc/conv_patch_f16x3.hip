@@ -81,7 +81,7 @@ __device__ __forceinline__ void split4p(const f32x4 v, f16x4& hi, f16x4& lo) {
 // fragments of its BN output channels, copied verbatim from the fragment-major weight array (1-KiB blocks).
 // TAPG = 9: one weight stage per channel stage (narrow layers); TAPG = 3: wide layers (BN = 256), where nine taps of
 // weights (144 KiB) would not fit beside the patch.
-template <int TH, int BN, int NW, int DIL, int TAPG, bool INRES = false, bool HEAD = false, int NWN = 1>
+template <int TH, int BN, int NW, int DIL, int TAPG, bool INRES = false, bool HEAD = false, int NWN = 1, bool GLDS = false>
 __global__ __launch_bounds__(NW * 64)
 __attribute__((amdgpu_waves_per_eu((TAPG == 3 && BN <= 32 && !INRES) ? 3 : 1, (TAPG == 3 && BN <= 32 && !INRES) ? 3 : 10)))
 void conv_patch_f16x3_kernel(const PatchArgs pa) {
@@ -116,7 +116,12 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     constexpr int B_PIECES = TAPG * TNW * 2 * 64;                      // 16-byte pieces of one weight stage
     constexpr int B_HALFS = B_PIECES * 8;
     constexpr int EPI_HALFS = NW * 32 * 36 * 2 * (HEAD ? 2 : 1);       // epilogue patches (fp32) expressed in halfs
-    constexpr int SM_HALFS = PATCH_HALFS + B_HALFS > EPI_HALFS ? PATCH_HALFS + B_HALFS : EPI_HALFS;
+    // GLDS (round 4, the 256-channel tiles): the weight stage is copied global -> LDS by the LDS-DMA path (global_load_lds_dwordx4:
+    // the 1-KiB fragment blocks are lane-linear, exactly what it writes) into the OTHER of two stage buffers while the current
+    // stage is multiplied -- no staging registers, no ds_write pass, and the stages that keep their input patch (two of three)
+    // need ONE barrier instead of two.  Ordering: the issuing waves wait vmcnt(0), then the barrier; the fragments are read after it.
+    constexpr int NBUF = GLDS ? 2 : 1;
+    constexpr int SM_HALFS = PATCH_HALFS + NBUF * B_HALFS > EPI_HALFS ? PATCH_HALFS + NBUF * B_HALFS : EPI_HALFS;
     __shared__ __attribute__((aligned(16))) _Float16 smem[SM_HALFS];
     _Float16* Ph = smem;
     _Float16* Pl = smem + NPIX * LDP;
@@ -158,6 +163,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     f32x4 rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};      // input-normalisation table of this thread's quad
     auto prefetch = [&](int cb, int g) __attribute__((always_inline)) {
         const int cb32 = cb >> 1, ks = cb & 1;
+        _Float16* bdst = Bs + (GLDS ? ((cb * NG + g) & 1) * B_HALFS : 0);
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int i = tid + k * NT;
@@ -165,7 +171,17 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                 const int l = i & 63, blk = i >> 6;                     // blk = (tapl*TN + b)*2 + hl
                 const int hl = blk & 1, tb = blk >> 1, b = tb % TNW, tap = g * TAPG + tb / TNW;
                 const int64_t src = (((((int64_t)cb32 * 9 + tap) * nbs + nb0 + b) * 2 + ks) * 2 + hl) * 512 + l * 8;
-                rb[k] = *reinterpret_cast<const f16x8*>(p.wf + src);
+                if constexpr (GLDS)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.wf + src),
+                                                     (__attribute__((address_space(3))) void*)(bdst + i * 8), 16, 0, 0);
+                else {
+                    // a 64-channel tile on a layer with <= 32 filters (dilated layers have no 32-channel tile): the second channel
+                    // tile has no weights -- zeros, not the 2 KiB behind the array (found by tools/conv_fuzz.py --seed 4: a
+                    // memory fault when the array ends a mapped segment; its columns are never stored)
+                    f16x8 wv = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                    if (nb0 + b < nbs) wv = *reinterpret_cast<const f16x8*>(p.wf + src);
+                    rb[k] = wv;
+                }
             }
         }
         if (g == 0) {
@@ -191,10 +207,12 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
         }
     };
     auto commit = [&](int g) __attribute__((always_inline)) {
+        if constexpr (!GLDS) {
 #pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            const int i = tid + k * NT;
-            if (i < B_PIECES) *reinterpret_cast<f16x8*>(&Bs[i * 8]) = rb[k];
+            for (int k = 0; k < NB; ++k) {
+                const int i = tid + k * NT;
+                if (i < B_PIECES) *reinterpret_cast<f16x8*>(&Bs[i * 8]) = rb[k];
+            }
         }
         if (g == 0) {
 #pragma unroll
@@ -230,9 +248,19 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     for (int cb = 0; cb < ncb; ++cb) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            __syncthreads();                                            // the previous stage's LDS reads are done
-            if (!OTVM_PABL_NOCOMMIT || (cb == 0 && g == 0)) commit(g);
-            __syncthreads();
+            const _Float16* Bcur = Bs + (GLDS ? ((cb * NG + g) & 1) * B_HALFS : 0);
+            if constexpr (GLDS) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's share of the stage's weights has landed
+                __syncthreads();                                        // ... everybody's; and the previous stage's LDS reads are done
+                if (g == 0) {                                           // a new input patch (every third stage)
+                    commit(0);
+                    __syncthreads();
+                }
+            } else {
+                __syncthreads();                                        // the previous stage's LDS reads are done
+                if (!OTVM_PABL_NOCOMMIT || (cb == 0 && g == 0)) commit(g);
+                __syncthreads();
+            }
             if (!OTVM_PABL_NOLOAD) {
                 if (g + 1 < NG) prefetch(cb, g + 1);
                 else if (cb + 1 < ncb) prefetch(cb + 1, 0);
@@ -271,8 +299,8 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                         const f16x8 one = {(_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f, (_Float16)1.f};
                         bh[j] = one; bl[j] = one * (_Float16)(float)lane;
 #else
-                        bh[j] = *reinterpret_cast<const f16x8*>(&Bs[((tl * TNW + nt0 + b0 + j) * 2) * 512 + lane * 8]);
-                        bl[j] = *reinterpret_cast<const f16x8*>(&Bs[((tl * TNW + nt0 + b0 + j) * 2 + 1) * 512 + lane * 8]);
+                        bh[j] = *reinterpret_cast<const f16x8*>(&Bcur[((tl * TNW + nt0 + b0 + j) * 2) * 512 + lane * 8]);
+                        bl[j] = *reinterpret_cast<const f16x8*>(&Bcur[((tl * TNW + nt0 + b0 + j) * 2 + 1) * 512 + lane * 8]);
 #endif
                     }
 #if OTVM_PABL_NOMFMA
@@ -558,12 +586,12 @@ __global__ __launch_bounds__(256) void pack_patch_weight_kernel(const float* __r
     }
 }
 
-template <int TH, int BN, int NW, int DIL, int TAPG = 9, bool INRES = false, bool HEAD = false, int NWN = 1>
+template <int TH, int BN, int NW, int DIL, int TAPG = 9, bool INRES = false, bool HEAD = false, int NWN = 1, bool GLDS = false>
 int launch_patch(PatchArgs& a, hipStream_t s) {
     a.tiles_x = otvm_ceil_div(a.W, 32);
     a.tiles_y = otvm_ceil_div(a.H, TH);
     a.tiles_n = otvm_ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL, TAPG, INRES, HEAD, NWN>), dim3(a.tiles_x * a.tiles_y * a.tiles_n, a.batch), dim3(NW * 64), 0, s, a);
+    hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL, TAPG, INRES, HEAD, NWN, GLDS>), dim3(a.tiles_x * a.tiles_y * a.tiles_n, a.batch), dim3(NW * 64), 0, s, a);
     OTVM_CHECK_LAUNCH("otvm_conv2d(patch f16x3)");
     return 0;
 }
@@ -679,6 +707,8 @@ static int patch_run(const otvm_conv_params* p, void* stream, int choice, const 
         // LDS fragment traffic per MFMA; OTVM_PATCH_WIDE_NWN=1 keeps the round-2 arrangement (same-box A/B); 2 x 4 waves (four
         // rows x two tiles) spills 108 B
         static const int nwn = getenv("OTVM_PATCH_WIDE_NWN") ? atoi(getenv("OTVM_PATCH_WIDE_NWN")) : 2;
+        static const int glds = getenv("OTVM_PATCH_WIDE_GLDS") ? atoi(getenv("OTVM_PATCH_WIDE_GLDS")) : 1;
+        if (nwn == 2 && p->dil == 1 && glds) return launch_patch<8, 256, 8, 1, 3, false, false, 2, true>(a, s);
         if (nwn == 2 && p->dil == 1) return launch_patch<8, 256, 8, 1, 3, false, false, 2>(a, s);   // (dilated: 52 / 92 B of scratch)
         if (p->dil == 1) return launch_patch<8, 256, 8, 1, 3>(a, s);
         if (p->dil == 2) return launch_patch<8, 256, 8, 2, 3>(a, s);

@@ -51,6 +51,7 @@ CONV_CASES = [
     (40, 128, 3, 2, 1, 1, 704, 705, True, 2, 0, False),     # large M, generic K decode (Cin % 32 != 0), stride 2
     (64, 384, 1, 1, 0, 1, 351, 353, False, 0, 0, False),    # ragged M and N tiles on the big tiles
     (16, 32, 3, 1, 1, 1, 1030, 1031, True, 2, 0, False),    # >= 2^20 pixels, <= 32 filters: 16x32-pixel patch blocks, ragged edges
+    (32, 32, 3, 1, 4, 4, 17, 12, False, 1, 0, False),       # dilated, <= 32 filters on the 64-channel patch tile (second tile: no weights)
 ]
 
 
@@ -819,6 +820,7 @@ def test_reference_vectors_fba_fusion(G):
 
 @pytest.mark.parametrize("Cin,Cout,k,stride,dil,H,W,use_res,act,gn", [
     (256, 256, 3, 1, 1, 40, 56, True, 1, False),        # patch (wide) + all five tiles + K splits
+    (96, 512, 3, 1, 1, 35, 70, False, 0, True),         # patch (wide): two channel tiles, six K stages (odd: both weight buffers end a run), ragged rows / columns, fused GroupNorm sums
     (1024, 512, 3, 1, 1, 17, 30, False, 0, False),      # deep, small map: the shape class the tuner moves to 256x256 / S
     (2048, 256, 1, 1, 1, 6, 6, False, 0, True),         # PPM 1x1 with fused GroupNorm sums: split-K + statistics pass
     (64, 64, 3, 1, 1, 33, 47, False, 2, False),         # narrow output: patch, 256x64, 128x64, 64x64

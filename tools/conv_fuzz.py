@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--verbose", action="store_true", help="print every case BEFORE it is launched (to find a case that faults)")
     args = ap.parse_args()
     rng = random.Random(args.seed)
     ws = torch.empty(16 << 20, device=G.DEV)
@@ -65,13 +66,16 @@ def main():
         ra = G.to_act(res) if use_res else None
         bd = None if b is None else b.to(G.DEV)
         stats = torch.zeros(64, dtype=torch.float64, device=G.DEV) if gn else None
+        use_ws = rng.random() < 0.8
+        tag = "Cin %4d Cout %4d k%d s%d d%d p%d %3dx%-3d prec %d bias %d act %d relu_in %d res %d gn %d" % (
+            Cin, Cout, k, stride, dil, pad, H, W, prec, use_bias, act, in_relu, use_res, gn)
+        if args.verbose:
+            print("case %d: %s in_ld %d out_ld %d ws %d" % (it, tag, xa.ld, out.ld, use_ws), flush=True)
         G.conv2d(xa, cw, out, bd, stride, pad, dil, act, in_relu, ra, precision=prec, gn_stats=stats,
-                 splitk_ws=ws if rng.random() < 0.8 else None)
+                 splitk_ws=ws if use_ws else None)
         got = G.from_act(out, Cout)
         err = G.maxdiff(got, ref) / max(1.0, float(ref.abs().max()))
         worst = max(worst, err)
-        tag = "Cin %4d Cout %4d k%d s%d d%d p%d %3dx%-3d prec %d bias %d act %d relu_in %d res %d gn %d" % (
-            Cin, Cout, k, stride, dil, pad, H, W, prec, use_bias, act, in_relu, use_res, gn)
         ok = bool(torch.isfinite(got).all()) and err <= 3e-5
         if gn:
             gg = ref.double().reshape(32, Cout // 32, -1)
