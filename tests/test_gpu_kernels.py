@@ -956,6 +956,43 @@ BATCH_CONV_CASES = [
 ]
 
 
+def test_wide_patch_tile_weight_stages_are_race_free(G):
+    """The 256-channel patch tile copies its weight stages global -> LDS by LDS-DMA into alternating buffers (round 4): what
+    orders that data for the fragment reads is a counted wait + a barrier, nothing else -- an early read would pass a
+    tolerance check whenever the DMA happens to land first.  So: the forced patch configuration (tune 241) on a layer with
+    six channel stages and two channel tiles, 40 launches back to back while another stream keeps the memory system busy,
+    every result bit-identical to the first and within fp32 rounding of the reference."""
+    from otvm_amd import lib as L
+    from otvm_amd.engine import conv_params
+    lib = L.load()
+    Cin, Cout, H, W = 96, 512, 70, 101
+    x = rnd(1, Cin, H, W, seed=190)
+    w = rnd(Cout, Cin, 3, 3, seed=191, scale=1.0 / math.sqrt(Cin * 9))
+    ref = F.conv2d(x, w, None, 1, 1, 1)
+    cw, xa = G.pack_weight(w), G.to_act(x)
+    out = G.empty_act(H, W, Cout)
+    p = conv_params(xa, cw, out, None, 1, 1, 1, 0, 0, None, L.PREC_F16X3, None, None)
+    codes = (C.c_int * 64)()
+    n = int(lib.otvm_conv2d_candidates(C.byref(p), codes, 64))
+    assert 241 in list(codes[:n]), "the patch kernel must be a candidate of a 3x3 layer with 512 filters"
+    p.tune = 241
+    side = torch.cuda.Stream(device=G.DEV)
+    junk = torch.empty(64 << 20, device=G.DEV)
+    first = None
+    for it in range(40):
+        with torch.cuda.stream(side):
+            junk.add_(1.0)                                  # HBM / L2 traffic next to the launch
+        out.t.fill_(float("nan"))
+        L.check(lib.otvm_conv2d(C.byref(p), G.stream()), "patch")
+        torch.cuda.synchronize()
+        got = G.from_act(out, Cout)
+        if first is None:
+            first = got
+            assert G.maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+        else:
+            assert torch.equal(got, first), it
+
+
 @pytest.mark.parametrize("case", BATCH_CONV_CASES, ids=lambda c: "c%d_%d_k%d_s%d_%dx%d_t%d" % (c[0], c[1], c[2], c[3], c[5], c[6], c[10]))
 def test_conv_batched_launch_equals_single_launches(G, case):
     """otvm_conv_params.batch: B images through one launch == B single launches, bit for bit (same tiles, same summation
