@@ -46,7 +46,8 @@ def _newer(a, b):
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    deps = [os.path.join(HERE, "common.h"), os.path.join(os.path.dirname(PKG), "include", "otvm_hip.h"), __file__]
+    deps = [os.path.join(HERE, h) for h in sorted(os.listdir(HERE)) if h.endswith(".h")]          # common.h, head_math.h, ...
+    deps += [os.path.join(os.path.dirname(PKG), "include", "otvm_hip.h"), __file__]
     objs, relink, jobs = [], force, []
     for src, extra in SOURCES:
         s = os.path.join(HERE, src)
