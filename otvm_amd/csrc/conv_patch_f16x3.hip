@@ -120,6 +120,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     // the 1-KiB fragment blocks are lane-linear, exactly what it writes) into the OTHER of two stage buffers while the current
     // stage is multiplied -- no staging registers, no ds_write pass, and the stages that keep their input patch (two of three)
     // need ONE barrier instead of two.  Ordering: the issuing waves wait vmcnt(0), then the barrier; the fragments are read after it.
+    static_assert(!GLDS || BN == 256, "LDS-DMA weight stages copy every channel tile of the block: Cout % BN == 0 (the 256-channel tiles: patch_choice)");
     constexpr int NBUF = GLDS ? 2 : 1;
     constexpr int SM_HALFS = PATCH_HALFS + NBUF * B_HALFS > EPI_HALFS ? PATCH_HALFS + NBUF * B_HALFS : EPI_HALFS;
     __shared__ __attribute__((aligned(16))) _Float16 smem[SM_HALFS];
