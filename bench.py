@@ -119,7 +119,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist, affinity = None, None
-    if world > 1 or "RANK" in os.environ:          # launched by torch.distributed.run (also exercised with 1 rank)
+    if world > 1 or all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")):   # launched by torch.distributed.run (also exercised with 1 rank)
         import torch.distributed as dist
         from otvm_amd.dist import init_process_group, pin_rank_affinity
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -195,11 +195,11 @@ def main():
         # per-rank view (diagnosis of a scaling run): each rank's own time and the host time it spent issuing launches
         from otvm_amd.dist import reduce_device
         rdev = reduce_device(dev)
-        mine = torch.tensor([elapsed, host_issue_s], dtype=torch.float64, device=rdev)
+        mine = torch.tensor([elapsed, host_issue_s, float(dev.index)], dtype=torch.float64, device=rdev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = [dict(rank=i, seconds=float(v[0]), frames_per_sec=K / float(v[0]), host_issue_ms_per_frame=1000.0 * float(v[1]) / K)
-                    for i, v in enumerate(allr)]
+        per_rank = [dict(rank=i, device=int(v[2]), seconds=float(v[0]), frames_per_sec=K / float(v[0]),
+                         host_issue_ms_per_frame=1000.0 * float(v[1]) / K) for i, v in enumerate(allr)]
         tt = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt[0])

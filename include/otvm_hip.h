@@ -35,7 +35,7 @@ extern "C" {
 #define OTVM_PREC_F16X3 1
 
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 17   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
+#define OTVM_ABI_VERSION 18   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
                                  4: otvm_conv_params.splitk_ws; 5: otvm_preprocess_params.fg_u8/bg_u8/u8_rgb;
                                  6: otvm_conv_params.tune + otvm_conv2d_candidates;
                                  7: folded GroupNorm tables on otvm_gn_apply's residual and otvm_upsample_bilinear's input;
@@ -50,7 +50,9 @@ const char* otvm_last_error(void);
                                  16: otvm_conv_params.gn_gamma ... gn_counter (the GroupNorm scale / shift table of the OUTPUT
                                      written by the conv's last workgroup instead of a separate otvm_gn_table launch);
                                  17: otvm_gram_f16 / otvm_gn_predict (GroupNorm statistics of a 1x1 convolution's output predicted
-                                     from its input's Gram matrix: the normalisation moves into that convolution's epilogue) */
+                                     from its input's Gram matrix: the normalisation moves into that convolution's epilogue);
+                                 18: otvm_gram_params.diag / otvm_gn_predict_params.diag (conditioning + saturation diagnostics of the
+                                     predicted statistics); implicit-GEMM tiles 32 + t with LDS-DMA weight stages (tune codes) */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
@@ -272,6 +274,8 @@ typedef struct otvm_gram_params {
     const float* in_scale; const float* in_shift; int in_act;
     float* gpart; float* spart; int passes;
     int batch; int64_t x_bs; int norm_bs;            /* image b: x + b * x_bs, tables + b * norm_bs; partials are packed per image */
+    unsigned* diag;                                  /* ABI 18, optional: the layer's two diagnostic words (see otvm_gn_predict_params);
+                                                        this kernel sets bit 1 of diag[1] when an operand was clamped to +-65504   */
 } otvm_gram_params;
 int otvm_gram_block(int C);
 int64_t otvm_gram_entries(int C);
@@ -283,6 +287,10 @@ typedef struct otvm_gn_predict_params {
     const float* wscale; const float* gamma; const float* beta; const float* res_shift;
     float* scale_eff; float* bias_eff; float* stat_out;
     int batch, tab_bs, rs_bs;                        /* image b: tables + b * tab_bs floats, res_shift + b * rs_bs floats */
+    unsigned* diag;                                  /* ABI 18, optional, two words the host clears and reads: diag[0] = running maximum
+                                                        (atomicMax of float bits) of kappa = mean^2 / var over groups, images and
+                                                        launches -- the factor by which the Gram matrix's rounding error reaches the
+                                                        variance; diag[1] bit 0 = a statistic was not finite                         */
 } otvm_gn_predict_params;
 int64_t otvm_gn_predict_ws_bytes(void);
 int otvm_gn_predict(const otvm_gn_predict_params* p, void* stream);

@@ -14,6 +14,7 @@ SOURCES = [
     ("error.cpp", []),
     ("conv_igemm.hip", []),
     ("conv_f16x3.hip", []),
+    ("conv_f16x3_glds.hip", []),
     ("conv_patch_f16x3.hip", []),
     ("conv_stem_f16x3.hip", []),
     ("conv_head16_f16x3.hip", []),

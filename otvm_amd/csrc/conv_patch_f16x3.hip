@@ -14,6 +14,7 @@
 //
 // One wave owns TM = TH/NW output rows (M tiles of 32 pixels) x TN = BN/32 channel tiles.  fp32 accumulate; epilogue
 // as conv_f16x3.hip (filter scale, bias, residual, activation, optional fused GroupNorm statistics).
+#pragma clang diagnostic ignored "-Winline-asm"      // (M0 in an asm clobber list: see conv_f16x3_kernel.h)
 #include "common.h"
 #include "head_math.h"
 #include <type_traits>
@@ -58,6 +59,7 @@ struct PatchArgs {
     // ABI 17 (INRES kernels): the input is the raw GroupNorm input of a residual block's LAST normalisation, whose apply pass
     // was skipped: x' = in_act(x * in_scale[c] + in_shift[c] + in_res), in_res = the block's (materialised) identity
     const float* in_res; int in_res_ld; int64_t in_res_bs;
+    unsigned in_bytes, in_res_bytes;     // round 5: sizes of one image's input / identity views (buffer-resource ranges)
     // ABI 17 (HEAD kernels, 16 output channels): the 1x1 head + fba_fusion of the FBA decoder / refinement run in the epilogue
     // on the pixel's 16 hidden values (head_math.h); out (the hidden state) is optional then
     OtvmHeadArgs head; int64_t head_img_bs, head_alpha_bs, head_tri_bs, head_sm_bs;
@@ -162,6 +164,12 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     f32x4 rr[INRES ? NP : 1];                                          // INRES: the identity's values of the same elements
     f16x8 rb[NB];
     f32x4 rsc = {1.f, 1.f, 1.f, 1.f}, rsh = {0.f, 0.f, 0.f, 0.f};      // input-normalisation table of this thread's quad
+    // round 5: the patch is loaded through buffer resources, without a branch: a pixel outside the image carries an offset
+    // beyond the resource's range and the hardware returns zeros (the `if (inside) load` form was an exec-masked branch per
+    // load, i.e. NP extra basic blocks in the K loop)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
+    __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(INRES ? p.in_res : p.in), 0, INRES ? p.in_res_bytes : 0, 0x00020000);
     auto prefetch = [&](int cb, int g) __attribute__((always_inline)) {
         const int cb32 = cb >> 1, ks = cb & 1;
         _Float16* bdst = Bs + (GLDS ? ((cb * NG + g) & 1) * B_HALFS : 0);
@@ -172,10 +180,14 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                 const int l = i & 63, blk = i >> 6;                     // blk = (tapl*TN + b)*2 + hl
                 const int hl = blk & 1, tb = blk >> 1, b = tb % TNW, tap = g * TAPG + tb / TNW;
                 const int64_t src = (((((int64_t)cb32 * 9 + tap) * nbs + nb0 + b) * 2 + ks) * 2 + hl) * 512 + l * 8;
-                if constexpr (GLDS)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(p.wf + src),
-                                                     (__attribute__((address_space(3))) void*)(bdst + i * 8), 16, 0, 0);
-                else {
+                if constexpr (GLDS) {
+                    // issued from inline asm (round 5): the compiler orders every LDS read behind an LDS-DMA it knows about -- the
+                    // builtin was followed by `s_waitcnt vmcnt(0)` in front of the stage's first fragment read (ISA of the round-4
+                    // build), i.e. the copy never overlapped the MFMAs.  Hidden, it lands under them; the `vmcnt(0)` at the top of
+                    // the next stage and the barrier behind it are what the fragment reads rely on.
+                    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)(bdst + (i - l) * 8));
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(m0v), "v"(p.wf + src) : "m0", "memory");
+                } else {
                     // a 64-channel tile on a layer with <= 32 filters (dilated layers have no 32-channel tile): the second channel
                     // tile has no weights -- zeros, not the 2 KiB behind the array (found by tools/conv_fuzz.py --seed 4: a
                     // memory fault when the array ends a mapped segment; its columns are never stored)
@@ -193,17 +205,17 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
 #pragma unroll
             for (int k = 0; k < NP; ++k) {
                 const int idx = tid + k * NT;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (idx < NPIX * 4) {
-                    const int pix = idx >> 2, c4 = (idx & 3) * 4;
-                    const int py = pix / PW, px = pix - py * PW;
-                    const int iy = ty0 - DIL + py, ix = tx0 - DIL + px;
-                    if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W) {
-                        v = *reinterpret_cast<const f32x4*>(p.in + ((int64_t)iy * p.W + ix) * p.in_ld + cb * CB + c4);
-                        if (INRES) rr[k] = *reinterpret_cast<const f32x4*>(p.in_res + ((int64_t)iy * p.W + ix) * p.in_res_ld + cb * CB + c4);
-                    }
-                }
-                rp[k] = v;
+                const int pix = idx >> 2, c4 = (idx & 3) * 4;
+                const int py = pix / PW, px = pix - py * PW;
+                const int iy = ty0 - DIL + py, ix = tx0 - DIL + px;
+                // 0 inside the image (and inside the patch), all ones outside: pure arithmetic, no select for the compiler to
+                // turn back into a branch
+                const unsigned oob = (unsigned)((int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W) &
+                                                (int)(idx < NPIX * 4)) - 1u;
+                const unsigned e = (unsigned)(iy * p.W + ix);
+                rp[k] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(in_rsrc, ((e * (unsigned)p.in_ld + cb * CB + c4) << 2) | oob, 0, 0));
+                if (INRES)
+                    rr[k] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(res_rsrc, ((e * (unsigned)p.in_res_ld + cb * CB + c4) << 2) | oob, 0, 0));
             }
         }
     };
@@ -690,6 +702,11 @@ static int patch_run(const otvm_conv_params* p, void* stream, int choice, const 
     a.in_bs = a.batch > 1 ? p->in_bs : 0; a.out_bs = a.batch > 1 ? p->out_bs : 0; a.res_bs = a.batch > 1 ? p->res_bs : 0;
     a.gn_bs = a.batch > 1 ? p->gn_bs : 0; a.norm_bs = a.batch > 1 ? p->norm_bs : 0;
     a.in_res = p->in_res; a.in_res_ld = p->in_res_ld; a.in_res_bs = a.batch > 1 ? p->in_res_bs : 0;
+    {   // buffer-resource ranges (32-bit byte offsets; 0xFFFFFFFF marks a pixel outside the image)
+        const int64_t ib = (int64_t)p->H * p->W * p->in_ld * 4, rb = p->in_res ? (int64_t)p->H * p->W * p->in_res_ld * 4 : 0;
+        OTVM_REQUIRE(ib < 0xFFFFFFF0ll && rb < 0xFFFFFFF0ll, "otvm_conv2d(patch f16x3): input view of %lld bytes is beyond 32-bit offsets", (long long)ib);
+        a.in_bytes = (unsigned)ib; a.in_res_bytes = (unsigned)rb;
+    }
     if (hd) {
         a.head.w = hd->w; a.head.b = hd->b; a.head.n_out = hd->n_out; a.head.img = hd->img; a.head.img_ld = hd->img_ld;
         a.head.P = hd->P; a.head.alpha_out = hd->alpha_out; a.head.alpha_stride = hd->alpha_stride; a.head.tri_out = hd->tri_out;

@@ -312,17 +312,22 @@ extern "C" int otvm_trimap_encode(const float* probs, int Hp, int Wp, const uint
     if (hipMemsetAsync(flags, 0, 256, s) != hipSuccess) { otvm_set_error("otvm_trimap_encode: memset failed"); return 2; }
     int64_t nb = (P / 4 + 255) / 256;
     const int grid = (int)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb));
-    static const int dbg0 = getenv("OTVM_EDT_DBG") ? atoi(getenv("OTVM_EDT_DBG")) : 0;
-    if (!(dbg0 & 32))
+    // timing probes (results WRONG when set) exist in -DOTVM_PROBES builds only (tools/build_variant.sh): a release library
+    // does not read OTVM_EDT_DBG
+#ifdef OTVM_PROBES
+    static const int dbg = getenv("OTVM_EDT_DBG") ? atoi(getenv("OTVM_EDT_DBG")) : 0;
+#else
+    constexpr int dbg = 0;
+#endif
+    if (!(dbg & 32))
     hipLaunchKernelGGL(classify_kernel, dim3(grid), dim3(256), 0, s, probs, P, cls_override, cls_out, flags);
-    if (dbg0 & 64) return 0;
+    if (dbg & 64) return 0;
     const int len = otvm_ceil_div(Hp, EDT_SEGS);
     const dim3 cgrid(otvm_ceil_div(Wp, EDT_XB)), cblock(EDT_XB * EDT_SEGS);
     if (len <= 8) hipLaunchKernelGGL(edt_columns_kernel<8>, cgrid, cblock, 0, s, cls_out, Hp, Wp, len, g);
     else if (len <= 20) hipLaunchKernelGGL(edt_columns_kernel<20>, cgrid, cblock, 0, s, cls_out, Hp, Wp, len, g);
     else if (len <= 40) hipLaunchKernelGGL(edt_columns_kernel<40>, cgrid, cblock, 0, s, cls_out, Hp, Wp, len, g);
     else hipLaunchKernelGGL(edt_columns_tall_kernel, dim3(otvm_ceil_div(Wp, 64), 2), dim3(64), 0, s, cls_out, Hp, Wp, g);
-    static const int dbg = getenv("OTVM_EDT_DBG") ? atoi(getenv("OTVM_EDT_DBG")) : 0;     // timing probes (results WRONG when set)
     if (!(dbg & 16))
     hipLaunchKernelGGL(edt_rows_encode_kernel, dim3(Hp), dim3(256), (2 * Wp + 4 * ((Wp + 31) / 32) + 2) * sizeof(int), s, g, probs, Hp, Wp,
                        flags, x11, x11_ld, d80, d80_ld, dbg);

@@ -37,6 +37,7 @@ struct GramArgs {
     float* gpart; float* spart;
     int nk, pch, nblk, nb;
     int64_t x_bs, g_bs, s_bs; int norm_bs;
+    unsigned* diag;                 // ABI 18, optional: diag[1] |= 2 when an operand had to be clamped to fp16's range
 };
 
 constexpr int LDT = 40;                 // halfs per LDS row: 32 pixels + 8 pad = 80 bytes (conflict-free ds_read_b128, as conv_f16x3.hip)
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(BS == 256 ? 512 : 256, BS == 256 ? 1 : 2) void gram
                 r[k][i] = *reinterpret_cast<const f32x4*>(p.x + px * p.ld + chan[k]);
             }
     };
+    bool sat = false;
     auto store_chunk = [&](int c, int buf, f32x4 (&r)[MAXIT][4]) __attribute__((always_inline)) {
         _Float16* Th = smem + buf * STAGE;
         _Float16* Tl = Th + ROWS * LDT;
@@ -132,7 +134,13 @@ __global__ __launch_bounds__(BS == 256 ? 512 : 256, BS == 256 ? 1 : 2) void gram
                 t.x = t.x > 0.f ? t.x : t.x * p.in_slope; t.y = t.y > 0.f ? t.y : t.y * p.in_slope;
                 t.z = t.z > 0.f ? t.z : t.z * p.in_slope; t.w = t.w > 0.f ? t.w : t.w * p.in_slope;
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                v[i] = ok ? t : z;
+                t = ok ? t : z;
+                // the fp16 operands saturate instead of becoming inf (an inf would turn every statistic of the layer into NaN);
+                // the event is recorded -- the statistics are wrong then, the host falls back (engine.py, ABI 18)
+                const f32x4 c4 = {__builtin_amdgcn_fmed3f(t.x, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(t.y, -65504.f, 65504.f),
+                                  __builtin_amdgcn_fmed3f(t.z, -65504.f, 65504.f), __builtin_amdgcn_fmed3f(t.w, -65504.f, 65504.f)};
+                sat |= (c4.x != t.x) | (c4.y != t.y) | (c4.z != t.z) | (c4.w != t.w);      // (NaN: med3 returns a bound, NaN != x)
+                v[i] = c4;
                 ssum[k] += v[i];
             }
 #pragma unroll
@@ -209,6 +217,7 @@ __global__ __launch_bounds__(BS == 256 ? 512 : 256, BS == 256 ? 1 : 2) void gram
             }
         }
     }
+    if (sat && p.diag) atomicOr(p.diag + 1, 2u);
     // ---- partial block
     float* gp = p.gpart + ((int64_t)kc * p.nblk + blk) * (BS * BS);
     const int col = lane & 31, rbase = (lane >> 5) * 4;
@@ -243,6 +252,8 @@ struct PredArgs {
     const float* wscale; const float* gamma; const float* beta; const float* res_shift;
     float* scale_eff; float* bias_eff; float* stat_out;
     int64_t g_bs, s_bs; int ws_bs, tab_bs, rs_bs;
+    unsigned* diag;                 // ABI 18, optional: [0] = max over groups / images / launches of the bits of kappa = mean^2 / var
+                                    // (non-negative floats order like their bit patterns), [1] |= 1 for a non-finite statistic
 };
 
 // partial Gram blocks and channel sums -> (sum y, sum y^2) per group -> (mean, rstd) -> the per-channel scale / shift conv3's
@@ -370,6 +381,15 @@ __global__ __launch_bounds__(256) void gn_predict_kernel(const PredArgs pa) {
         if (var < 0.0) var = 0.0;
         t_mean[tid] = (float)mean;
         t_rstd[tid] = (float)(1.0 / sqrt(var + 1e-5));
+        if (p.diag) {
+            // conditioning of var = E[y^2] - mean^2: an error delta on E[y^2] (the fp16 operands' rounding, ~3e-7 relative after
+            // averaging) reaches var amplified by 1 + kappa.  The host reads the running maximum and switches the layer to the
+            // f16x3 Gram, or off, when it is large (engine.py)
+            const double kappa = mean * mean / (var + 1e-12);
+            const bool bad = !(sum == sum) || !(sq == sq) || !(fabs(sum) < 1e300) || !(fabs(sq) < 1e300);
+            if (bad) atomicOr(p.diag + 1, 1u);
+            else atomicMax(p.diag, __float_as_uint((float)(kappa < 3e38 ? kappa : 3e38)));
+        }
         if (p.stat_out) { p.stat_out[zb * 64 + 2 * tid] = t_mean[tid]; p.stat_out[zb * 64 + 2 * tid + 1] = t_rstd[tid]; }
     }
     __syncthreads();
@@ -439,6 +459,7 @@ extern "C" int otvm_gram_f16(const otvm_gram_params* q, void* stream) {
     const int batch = q->batch > 1 ? q->batch : 1;
     a.x_bs = batch > 1 ? q->x_bs : 0; a.norm_bs = batch > 1 ? q->norm_bs : 0;
     a.g_bs = (int64_t)a.nk * otvm_gram_entries(q->C); a.s_bs = (int64_t)a.nk * q->C;
+    a.diag = q->diag;
     const dim3 grid(a.nblk * ((a.nk + 7) / 8) * 8, batch);
     hipStream_t s = (hipStream_t)stream;
     const bool p3 = q->passes == 3;
@@ -472,6 +493,7 @@ extern "C" int otvm_gn_predict(const otvm_gn_predict_params* q, void* stream) {
     const int batch = q->batch > 1 ? q->batch : 1;
     a.g_bs = (int64_t)a.nk * a.E; a.s_bs = (int64_t)a.nk * q->C;
     a.ws_bs = PRED_WG * 64; a.tab_bs = batch > 1 ? q->tab_bs : 0; a.rs_bs = batch > 1 ? q->rs_bs : 0;
+    a.diag = q->diag;
     int nwg = a.E / 256;                                          // 64 entry quads per workgroup and round
     if (nwg > 192) nwg = 192;                                     // (several rounds per workgroup: fewer partials for the tail)
     if (nwg < otvm_ceil_div(a.C, 64)) nwg = otvm_ceil_div(a.C, 64);

@@ -84,11 +84,9 @@ FUSE_REFINE_TAIL = os.environ.get("OTVM_FUSE_REFINE_TAIL", "0") != "0"
 # refinement's is written once and not read back; two launches per frame less.  0 = conv + otvm_fba_head
 FUSE_HEAD = os.environ.get("OTVM_FUSE_HEAD", "1") != "0"
 HEAD16 = os.environ.get("OTVM_HEAD16", "1") != "0"
-# round 4, measured and rejected: the PPM chain (pooling, heads, Z table: ~110 us of small launches that need layer 4 only) on an
-# auxiliary stream BESIDE conv_up1.0's layer-4 part instead of in front of it (fork / join markers inside the launch list, captured
-# into the list's hipGraph as a second branch): 43.8 / 43.7 frames/s against 44.5 / 44.5 serial on one box -- the pooling is an
-# HBM-speed pass and takes from the convolution what it gives (work-conserving).  1 = fork (tests cover both)
-PPM_FORK = os.environ.get("OTVM_PPM_FORK", "0") != "0"                 # ... on the 16-wide matrix-core tile (csrc/conv_head16_f16x3.hip)
+# (round 4, measured and rejected, code removed in round 5: the PPM chain -- pooling, heads, Z table: ~110 us of small launches that need
+# layer 4 only -- on an auxiliary stream BESIDE conv_up1.0's layer-4 part instead of in front of it: 43.8 / 43.7 frames/s against
+# 44.5 / 44.5 serial on one box; the pooling is an HBM-speed pass and takes from the convolution what it gives.  HISTORY.md)
 # round 3: the PPM branches' third of conv_up1.0 computed from the 50 pooled pixels (otvm_ppm_conv_z / _add) instead of
 # convolving their upsampled copies; conv_up1.0 then reads layer 4 only.  OTVM_PPM_ALGEBRA=0 keeps the materialised form.
 PPM_ALGEBRA = os.environ.get("OTVM_PPM_ALGEBRA", "1") != "0"       # the four PPM heads in one launch (otvm_ppm_head)
@@ -106,6 +104,17 @@ TUNE_LOG = []           # (signature, chosen code, {code: ms}) of every shape ti
 # restart) launches the tuned configurations without timing anything.
 TUNE_FILE = os.environ.get("OTVM_TUNE_FILE")
 _TUNE_FILE_LOADED = False
+
+
+def kernel_config_digest():
+    """16 hex digits over everything that selects kernel variants in this process: the tuned configuration of every layer shape
+    AND the OTVM_* environment switches the library and the engine read (tile thresholds, kernel-variant switches such as
+    OTVM_PATCH_WIDE_NWN or OTVM_IGEMM_GLDS change fp32 summation orders without passing through the tuner).  Equal
+    digests on all ranks = identical launches on all ranks."""
+    import hashlib
+    env = sorted((k, v) for k, v in os.environ.items()
+                 if k.startswith("OTVM_") and k not in ("OTVM_TUNE_FILE", "OTVM_DIST_BACKEND", "OTVM_TEST_FULL_F64"))
+    return hashlib.sha256(repr((sorted(_TUNE_CACHE.items()), env)).encode()).hexdigest()[:16]
 
 
 def _tune_file_tag():
@@ -265,7 +274,9 @@ def pack_conv_weight(lib, dev, w, ws=False, scale=None, i_pad=None, split=True, 
         cw.w_scale = torch.empty(O, dtype=torch.float32, device=dev)
         L.check(lib.otvm_split_conv_weight_f16x3(cw.w.data_ptr(), O, O_pad, cw.K_pad, kh * kw, cw.I_pad, cw.w_hi.data_ptr(),
                                                  cw.w_lo.data_ptr(), cw.w_scale.data_ptr(), stream), "split_conv_weight")
-        if cw.I_pad % 32 == 0 and kh * kw <= 32 and WAVE_TILE:     # whole 32-channel chunks: fragment-major copy for the one-wave tile
+        # whole 32-channel chunks: the fragment-major copy -- what the LDS-DMA weight stages of the 256-row implicit-GEMM tiles
+        # copy (round 5: layers with at least 128 filters), and what the one-wave tile reads (OTVM_WAVE_TILE)
+        if cw.I_pad % 32 == 0 and kh * kw <= 32 and (WAVE_TILE or O >= 128):
             cw.w_wfrag = torch.zeros(int(lib.otvm_wave_weight_bytes_f16x3(O_pad, cw.K_pad)), dtype=torch.uint8, device=dev)
             L.check(lib.otvm_pack_wave_weight_f16x3(cw.w_hi.data_ptr(), cw.w_lo.data_ptr(), O_pad, cw.K_pad, cw.w_wfrag.data_ptr(),
                                                     stream), "pack_wave_weight")
@@ -921,7 +932,6 @@ class FramePlan:
         self._bufs = {}
         self._keep = []
         self.graphs, self._graph_warm = {}, {}
-        self._aux = None
         self._fused_stats = []
         self._convs = []
         self.n_gn = 0
@@ -962,6 +972,8 @@ class FramePlan:
             if sig not in _TUNE_CACHE:
                 n = int(self.lib.otvm_conv2d_candidates(C.byref(p), codes, 64))
                 cands = [0] + [int(codes[i]) for i in range(n)]           # 0 = the built-in heuristic, the incumbent
+                if not WAVE_TILE:                                         # (the fragment-major weights alone do not switch the one-wave tile on)
+                    cands = [c for c in cands if c // 16 - 1 != 9]
                 # the first timing of a layer runs on cold caches and ramping clocks (measured: the same kernel 14 % slower
                 # as first candidate than as second): a throw-away pass first, the incumbent timed again at the end
                 self._time_conv(p, 0, stream, reps=2)
@@ -1437,9 +1449,6 @@ class FramePlan:
         conv5 = self.PPMCAT.ch(0, 2048)
         self.POOL_B = self.raws("ppm_pool", 50 * 2048)
         self.POOL_WS_B = self.raws("ppm_ws", int(lib.otvm_ppm_pool_ws_bytes(H8, 2048)) // 4)
-        fork = PPM_FORK and ppm_alg and FUSE_PPM_HEAD
-        if fork:
-            S.append(("fork", (), "fork (PPM chain beside conv_up1.0)"))
         for b in range(self.B):                          # (three small launches per image: not batched)
             S.append((lib.otvm_ppm_pool, (conv5.img(b).ptr, H8, W8, 2048, conv5.ld, self.POOL_B[b].data_ptr(),
                                           self.POOL_WS_B[b].data_ptr()), "ppm_pool"))
@@ -1482,11 +1491,7 @@ class FramePlan:
                 yp = (C.c_void_p * 4)(*[y.img(b).ptr for y in ys])
                 self._keep.append(yp)
                 S.append((lib.otvm_ppm_conv_z, (yp, ys[0].ld, self.e.W_ppm.data_ptr(), self.PPM_Z[b].data_ptr()), "ppm_conv_z"))
-            if fork:
-                S.append(("endfork", (), "endfork"))
             self.conv(S, self.PPMCAT.ch(0, 2048), de + "conv_up1.0.main", u1, pad=1)
-            if fork:
-                S.append(("join", (), "join"))
             for b in range(self.B):
                 S.append(("ppm_add", (self.PPM_Z[b].data_ptr(), H8, W8, u1.img(b).ptr, u1.ld), b, "ppm_conv_add"))
             # the gather writes the layer's final values: it also accumulates their GroupNorm sums (bound in _bind_stats)
@@ -1642,30 +1647,14 @@ class FramePlan:
                 L.check(rc, st[2])
 
     def _launch(self, steps, tmain, handle=None):
-        """Issue ``steps`` on the torch stream ``tmain`` (raw handle ``handle``).  ("fork",) ... ("endfork",) sends the steps in
-        between to the plan's auxiliary stream, ordered behind everything issued on ``tmain`` so far; ("join",) makes ``tmain``
-        wait for them.  Inside a graph capture the auxiliary stream joins the capture through the fork event."""
+        """Issue ``steps`` on the torch stream ``tmain`` (raw handle ``handle``).  Every step must be a bound library call by now:
+        a string marker left in a list (a step _bind_stats did not rebind) is an error, not something to skip."""
         handle = tmain.cuda_stream if handle is None else handle
-        cur, aux = handle, None
         for st in steps:
             f = st[0]
             if isinstance(f, str):
-                if f == "fork":
-                    if self._aux is None:
-                        self._aux = torch.cuda.Stream(device=self.dev)
-                    aux = self._aux
-                    ev = torch.cuda.Event()
-                    ev.record(tmain)
-                    aux.wait_event(ev)
-                    cur = aux.cuda_stream
-                elif f == "endfork":
-                    cur = handle
-                elif f == "join":
-                    ev = torch.cuda.Event()
-                    ev.record(aux)
-                    tmain.wait_event(ev)
-                continue
-            rc = f(*st[1], cur)
+                raise RuntimeError("otvm_amd: unbound step %r in a launch list" % (f,))
+            rc = f(*st[1], handle)
             if rc != 0:
                 L.check(rc, st[2])
 

@@ -67,7 +67,9 @@ def main(argv=None):
         local_rank %= max(1, torch.cuda.device_count())     # gloo rehearsal: more ranks than GPUs share the devices round-robin
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    distributed = world > 1 or "RANK" in os.environ        # under a launcher (also with ONE rank: RCCL initialised and used)
+    # under a launcher (also with ONE rank: RCCL initialised and used).  A stray RANK variable alone is not a launcher: without
+    # the rendezvous variables init_process_group would hang or fail where a plain process ran before
+    distributed = world > 1 or all(k in os.environ for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"))
     if distributed:
         # one process per GPU, RCCL for the final metric reduction; OTVM_DIST_BACKEND=gloo rehearses the multi-rank path with
         # several ranks on ONE GPU (RCCL refuses that).  Each rank -- its launch thread and the IO pools it starts -- gets
@@ -106,11 +108,18 @@ def main(argv=None):
         from .dist import default_batch
         from .engine import pad_amounts
         args.batch = 1
-        if world > 1 and any(k is not None for k in keys):
+        # (--viz and --sync-io are single-clip features -- matte_batch writes no viz frames and decodes every clip of a group up
+        #  front -- so they keep batch 1 unless --batch is given explicitly)
+        if world > 1 and any(k is not None for k in keys) and not (args.viz or args.sync_io):
             def padded(k):
                 lw, uw, lh, uh = pad_amounts(k[0], k[1], 32)
                 return (k[0] + lh + uh) * (k[1] + lw + uw)
             args.batch = default_batch(max(padded(k) for k in keys if k is not None))
+    if args.batch > 1 and (args.viz or args.sync_io):
+        raise SystemExit("eval_cli: --batch %d steps clips in lock-step through matte_batch, which implements neither --viz nor "
+                         "--sync-io; drop one of them" % args.batch)
+    if rank == 0:
+        print("eval_cli: %d rank(s), lock-step batch %d per rank" % (world, args.batch))
     if distributed:
         # every rank must launch the same kernel configurations, or a clip's alpha (fp32 summation order) would depend on
         # the rank that got it: rank 0 builds -- and times -- the plans of all resolutions in the data set, the others adopt
@@ -190,13 +199,16 @@ def main(argv=None):
     summary = run_sharded(seqs, matte, rank=rank, world=world, device=reduce_device(dev) if distributed else dev,
                           batch=max(1, args.batch), matte_batch_fn=matte_batch, key_fn=resolution)
     if distributed:
-        import hashlib
         import torch.distributed as dist
         # which kernel configurations this rank launched (fp32 summation orders): identical on all ranks by construction
         # (share_tune_cache), reported so that a run can prove it
-        from .engine import _TUNE_CACHE
+        from .engine import kernel_config_digest
         digests = [None] * world
-        dist.all_gather_object(digests, hashlib.sha256(repr(sorted(_TUNE_CACHE.items())).encode()).hexdigest()[:16])
+        dist.all_gather_object(digests, kernel_config_digest())
+        if len(set(digests)) != 1 and rank == 0:
+            import warnings
+            warnings.warn("eval_cli: the ranks launched different kernel configurations (tuned choices or OTVM_* switches differ "
+                          "between ranks): a clip's last bits depend on the rank that got it.  Digests: %s" % digests)
         summary["tune_digests"] = digests
         summary["batch"] = args.batch
         dist.barrier()

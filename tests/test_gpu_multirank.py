@@ -152,3 +152,57 @@ def test_rccl_with_one_rank_through_bench_and_eval_cli(tmp_path):
     s = json.load(open(js))
     assert s["shards"] == [[0, 1]] and s["frames"] == sum(lengths) and len(s["tune_digests"]) == 1
     assert s["gt_metrics"]["frames"] == sum(lengths)
+
+
+def test_rccl_two_ranks_two_gpus(tmp_path):
+    """Arms itself on a box with at least two GPUs (the builder's and the driver's test boxes have one: SKIPPED there, visibly).
+    `bench.py --gpus 2` and `eval_cli --gpus 2` on the default backend (nccl = RCCL over xGMI), one rank per GPU -- the launch
+    the driver's scaling run uses (reference: one device per process, eval.py:42,80).  Checked: both ranks took part and sat
+    on distinct devices, every rank launched the same kernel configurations (equal tune digests), every PNG is byte-for-byte
+    the PNG of the single-rank run, the RCCL-reduced ground-truth metrics equal the single-rank sums."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs >= 2 GPUs (found %d): the RCCL two-rank path is rehearsed on gloo by "
+                    "test_two_ranks_on_one_gpu_through_eval_cli" % (torch.cuda.device_count() if torch.cuda.is_available() else 0))
+    from PIL import Image
+    env = dict(os.environ)
+    env["PYTHONPATH"] = ROOT + os.pathsep + env.get("PYTHONPATH", "")
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    env.pop("OTVM_DIST_BACKEND", None)                      # the default: nccl = RCCL
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env["OTVM_TUNE_FILE"] = os.path.join(str(tmp_path), "tune.json")
+    env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-roofline", "--height", "480", "--width", "832"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == 2 and res["dist_backend"] == "nccl" and res["scaling"] == "weak"
+    assert len(res["per_rank"]) == 2 and len({row["device"] for row in res["per_rank"]}) == 2, res["per_rank"]
+    assert res["value"] > 0 and abs(res["value"] - 2 * 3 / (res["ms_per_step"] * 3 / 1000.0)) <= 1e-6 * res["value"]
+    lengths = [4, 2, 3]
+    root = os.path.join(str(tmp_path), "data")
+    os.makedirs(root)
+    names = _v108_tree(root, lengths)
+    common = ["--data", root, "--synthetic-weights", "--skip", "3", "--trimap", "narrow", "--batch", "1"]
+    out1, out2 = os.path.join(str(tmp_path), "out1"), os.path.join(str(tmp_path), "out2")
+    j1, j2 = os.path.join(str(tmp_path), "s1.json"), os.path.join(str(tmp_path), "s2.json")
+    r = subprocess.run([sys.executable, "-m", "otvm_amd.eval_cli"] + common + ["--out", out1, "--summary-json", j1],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    env["MASTER_PORT"] = str(_free_port())
+    r = subprocess.run([sys.executable, "-m", "otvm_amd.eval_cli", "--gpus", "2"] + common + ["--out", out2, "--summary-json", j2],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    s1, s2 = json.load(open(j1)), json.load(open(j2))
+    assert s2["shards"] == [[0], [1, 2]] and s1["shards"] == [[0, 1, 2]] and s1["frames"] == s2["frames"] == sum(lengths)
+    assert len(s2["tune_digests"]) == 2 and len(set(s2["tune_digests"])) == 1, s2["tune_digests"]
+    for clip, T in zip(names, lengths):
+        for t in range(T):
+            rel = os.path.join("alpha", "test", "s4_OTVM", "pred", clip, "%05d.png" % t)
+            a1, a2 = np.asarray(Image.open(os.path.join(out1, rel))), np.asarray(Image.open(os.path.join(out2, rel)))
+            assert np.array_equal(a1, a2), rel
+    g1, g2 = s1["gt_metrics"], s2["gt_metrics"]
+    assert g1["frames"] == g2["frames"] == sum(lengths)
+    for k in ("sad", "mse", "mse_mean", "dtssd_mean", "dtssd_sum_err2", "dtssd_mask_sum"):
+        assert abs(g1[k] - g2[k]) <= 1e-12 * max(1.0, abs(g1[k])), (k, g1[k], g2[k])

@@ -34,14 +34,17 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
 
 def test_ctypes_struct_matches_c_layout():
     """sizeof(otvm_conv_params) / otvm_preprocess_params / otvm_ppm_head_params as compiled by gcc == the ctypes mirrors."""
-    src = '#include <stdio.h>\n#include "otvm_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n", sizeof(otvm_conv_params), sizeof(otvm_preprocess_params), sizeof(otvm_ppm_head_params), sizeof(otvm_gn_apply_params));return 0;}\n'
+    src = ('#include <stdio.h>\n#include "otvm_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(otvm_conv_params), '
+           'sizeof(otvm_preprocess_params), sizeof(otvm_ppm_head_params), sizeof(otvm_gn_apply_params), sizeof(otvm_gram_params), '
+           'sizeof(otvm_gn_predict_params));return 0;}\n')
     exe = os.path.join(ROOT, "otvm_amd", "csrc", "build", "abi_sizes")
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
-    a, b, c, d = (int(v) for v in subprocess.check_output([exe]).split())
+    a, b, c, d, e, f = (int(v) for v in subprocess.check_output([exe]).split())
     from otvm_amd import lib as L
     assert ctypes.sizeof(L.ConvParams) == a and ctypes.sizeof(L.PreprocessParams) == b and ctypes.sizeof(L.PpmHeadParams) == c
     assert ctypes.sizeof(L.GnApplyParams) == d
+    assert ctypes.sizeof(L.GramParams) == e and ctypes.sizeof(L.GnPredictParams) == f      # (ABI 18: + diag)
 
 
 def test_bank_policy_engine_equals_oracle():

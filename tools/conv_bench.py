@@ -48,6 +48,10 @@ def main():
         x = Act(torch.randn(H * W * (Cin + pl), device=dev), H, W, Cin, Cin + pl)
         w = torch.randn(Cout, Cin, k, k, device=dev) / math.sqrt(Cin * k * k)
         cw = pack_conv_weight(lib, dev, w, split=True, stream=st)
+        if cw.w_wfrag is None and cw.I_pad % 32 == 0 and k * k <= 32:       # narrow layers: the one-wave tile's copy, for --tune all
+            O_pad = cw.w_hi.numel() // cw.K_pad
+            cw.w_wfrag = torch.zeros(int(lib.otvm_wave_weight_bytes_f16x3(O_pad, cw.K_pad)), dtype=torch.uint8, device=dev)
+            L.check(lib.otvm_pack_wave_weight_f16x3(cw.w_hi.data_ptr(), cw.w_lo.data_ptr(), O_pad, cw.K_pad, cw.w_wfrag.data_ptr(), st))
         Ho = (H + 2 * pad - dil * (k - 1) - 1) // stride + 1
         Wo = (W + 2 * pad - dil * (k - 1) - 1) // stride + 1
         out = Act(torch.empty(Ho * Wo * (max(4, Cout) + pl), device=dev), Ho, Wo, Cout, max(4, Cout) + pl)
@@ -66,6 +70,7 @@ def main():
         else:
             tunes = [int(v) for v in args.tune.split(",")]
         names = {0: "256x256", 1: "256x128", 2: "128x128", 3: "128x64", 4: "64x64", 5: "256x64", 6: "256x32", 7: "256x128w4", 8: "128x256w4", 9: "wave64", 10: "64x64D", 11: "128x64D", 12: "stem", 13: "256x256w4", 14: "patch"}
+        names.update({32 + t: n + "G" for t, n in list(names.items()) if t in (0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11)})     # LDS-DMA weight stages
         for tune in tunes:
             p.tune = tune
             for _ in range(3):
