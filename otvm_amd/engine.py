@@ -74,7 +74,22 @@ FUSE_GN_PREDICT = os.environ.get("OTVM_GN_PREDICT", "1") != "0"
 # per block cost more than the pass they replace, and the fp16 pass's noise on the statistics (~ 1 / sqrt(pixels)) grows
 GN_PREDICT_MIN_PIXELS = int(os.environ.get("OTVM_GN_PREDICT_MIN_PIXELS", "16384"))
 GN_PREDICT_PASSES = int(os.environ.get("OTVM_GN_PREDICT_PASSES", "1"))
+# ... and for these bottleneck widths (planes of conv3's INPUT; "64,128,256,512" = all four stages of the FBA encoder)
+GN_PREDICT_PLANES = tuple(int(v) for v in os.environ.get("OTVM_GN_PREDICT_PLANES", "64,128,256,512").split(",") if v)
 GN_PREDICT_DS = os.environ.get("OTVM_GN_PREDICT_DS", "1") != "0"
+# round 5 (ABI 18): conditioning guard of the predicted statistics.  var = E[y^2] - mean^2 receives the Gram matrix's rounding error
+# (fp16 operands: ~3e-7 of E[y^2] after averaging) amplified by 1 + kappa, kappa = mean^2 / var of the output group.  The
+# prediction kernel keeps the running maximum of kappa per layer (and flags non-finite statistics / saturated fp16 operands); the
+# host reads it after the first frame of every clip (the caller synchronises there anyway) and every few frames in between:
+#   kappa > KAPPA_P3  -> that layer's Gram matrix is computed on f16x3 operands from now on (22-bit operands: error ~1e-9 of E[y^2])
+#   kappa > KAPPA_OFF, non-finite, saturated -> the prediction is switched off for this engine: the plans are rebuilt on the
+#                        accumulated route (statistics summed from conv3's own output, round 3) at the next clip boundary
+# and a first frame whose statistics tripped either threshold is computed again before it is returned.
+# Measured (tests/test_gpu_kernels.py::test_gn_predict_conditioning_guard, kappa = 1667): relative error of rstd 4.6e-4 with the
+# fp16 Gram matrix, 8.2e-6 with the f16x3 one, i.e. (1 + kappa) x 2.8e-7 and (1 + kappa) x 4.9e-9 -- the thresholds keep it
+# below ~1.5e-6 in every regime (the accumulated route itself is at 1e-7 .. 1e-6).
+GN_PREDICT_KAPPA_P3 = float(os.environ.get("OTVM_GN_PREDICT_KAPPA_P3", "4"))
+GN_PREDICT_KAPPA_OFF = float(os.environ.get("OTVM_GN_PREDICT_KAPPA_OFF", "256"))
 # round 4 (ABI 17): the refinement's last BasicBlock ends in bn2 -> (+ identity) -> ReLU with ONE reader, pred.0 (a 3x3 patch
 # conv): its staging normalises, adds the identity and applies the ReLU (otvm_conv_params.in_res) -- the 535 MB block output
 # is never written (one 1.6 GB apply pass less per frame, 535 MB more read by pred.0).  0 = round 3's apply pass
@@ -387,6 +402,10 @@ class HipEngine:
         self._guard_ev = None
         self._guard_what = {}
         self.use_graphs = USE_GRAPHS
+        self.gn_predict_off = False   # set by predict_check: the plans are (re)built without the predicted GroupNorm tails
+        self.gn_predict_log = []      # (layer, kappa, action) of every intervention of the conditioning guard
+        self._diag_host = None
+        self._diag_ev = None
         self.keep_hid_d = False      # training forward (otvm_amd/train.py): the decoder's hidden state must exist in memory
         global _TUNE_FILE_LOADED
         if not _TUNE_FILE_LOADED:
@@ -547,6 +566,65 @@ class HipEngine:
             self._guard_ev = torch.cuda.Event()
             self._guard_ev.record(torch.cuda.current_stream(self.dev))
 
+    # ------------------------------------------------------------------ conditioning guard of the predicted GroupNorm statistics
+    def _predict_verdict(self, pl, words):
+        """words: the plan's diagnostic words on the host.  Applies the policy above; returns "ok", "p3" (at least one layer was
+        switched to the f16x3 Gram matrix) or "off"."""
+        import struct
+        import warnings
+        verdict = "ok"
+        for name, q, slot in pl._predicted:
+            kappa = struct.unpack("f", struct.pack("i", int(words[2 * slot])))[0]
+            flags = int(words[2 * slot + 1])
+            if flags or kappa > GN_PREDICT_KAPPA_OFF:
+                why = ("non-finite statistic" if flags & 1 else "fp16 operand saturated") if flags else "kappa %.3g" % kappa
+                self.gn_predict_log.append((name, kappa, "off: " + why))
+                if not self.gn_predict_off:
+                    warnings.warn("otvm_amd: the predicted GroupNorm statistics of %s are ill-conditioned (%s): the prediction is "
+                                  "switched off for this model (statistics accumulated from the convolution's output instead; "
+                                  "OTVM_GN_PREDICT=0 does the same from the start)" % (name, why))
+                self.gn_predict_off = True
+                verdict = "off"
+            elif kappa > GN_PREDICT_KAPPA_P3 and q.passes == 1:
+                q.passes = 3                                   # (the launch list holds a reference to q: effective from the next launch)
+                self.gn_predict_log.append((name, kappa, "f16x3 Gram matrix"))
+                if verdict == "ok":
+                    verdict = "p3"
+        return verdict
+
+    def predict_check(self, pl, sync):
+        """sync: read the plan's diagnostic words now.  Otherwise look at the last non-blocking copy, if it has landed, and start a
+        new one every 8 frames (as guard_check)."""
+        if not pl._predicted or self.gn_predict_off:
+            return "ok"
+        if sync:
+            words = pl.diag.cpu().tolist()
+            pl.diag.zero_()
+            self._diag_ev = None
+            return self._predict_verdict(pl, words)
+        verdict = "ok"
+        if self._diag_ev is not None and self._diag_ev[0].query():
+            ev, owner = self._diag_ev
+            self._diag_ev = None
+            if owner is pl:
+                verdict = self._predict_verdict(pl, self._diag_host.tolist())
+        if self._diag_ev is None and self.frame_counter % 8 == 0:
+            if self._diag_host is None:
+                self._diag_host = torch.zeros(2 * 64, dtype=torch.int32).pin_memory()
+            self._diag_host.copy_(pl.diag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(self.dev))
+            self._diag_ev = (ev, pl)
+        return verdict
+
+    def _drop_plans(self):
+        """Forget every plan and everything bound to one (bank slots carry launch parameters of the plan that made them)."""
+        torch.cuda.synchronize(self.dev)
+        self.plans.clear()
+        self.bank, self.free_slots, self.pending = [], [], None
+        self.ev_dec = None
+        self.last_plan = None
+
     # ------------------------------------------------------------------ plans
     def plan(self, H, W, B=1):
         key = (H, W) if B == 1 else (H, W, B)
@@ -588,7 +666,8 @@ class HipEngine:
                                  frame_id, None if cls_override is None else [cls_override], frames_rgb, inputs_ready)[0]
 
     def _frame_batch(self, a_l, fg_l, bg_l, tri_gt_l, first_frame=False, last_frame=False, memorize=False, max_memory_num=2,
-                     dilate_kernel=None, frame_id=None, cls_override=None, frames_rgb=False, inputs_ready=None, train=None):
+                     dilate_kernel=None, frame_id=None, cls_override=None, frames_rgb=False, inputs_ready=None, train=None,
+                     _recheck=2):
         """The same frame step for B independent sequences in LOCK-STEP (round 3): lists of B inputs of one resolution, one
         memory schedule (first_frame / last_frame / memorize / max_memory_num apply to all), per-sequence banks.  Every
         (train: buffers of the training-mode forward, otvm_amd/train.py -- the heads' full outputs and the raw logits are
@@ -857,6 +936,22 @@ class HipEngine:
         self.last_alpha_u8 = outs[0]["alpha_u8"]
         self.last_alpha_u8_b = [o["alpha_u8"] for o in outs]
         self.last_plan = pl
+        if pl._predicted and not self.gn_predict_off:
+            # conditioning guard of the predicted GroupNorm statistics (see GN_PREDICT_KAPPA_*): a clip's first frame is checked
+            # before it is returned (one synchronisation per clip) and computed again if a layer had to change its route -- the
+            # bank is empty there, so the frame call is repeatable; later frames are watched without synchronising
+            verdict = self.predict_check(pl, sync=first_frame)
+            if first_frame and verdict != "ok" and _recheck > 0:
+                if verdict == "off":
+                    self._drop_plans()                        # (rebuilt below without the predicted tails)
+                return self._frame_batch(a_l, fg_l, bg_l, tri_gt_l, first_frame, last_frame, memorize, max_memory_num, dilate_kernel,
+                                         frame_id, cls_override, frames_rgb, None, train, _recheck=_recheck - 1)
+        elif self.gn_predict_off and pl._predicted and first_frame:
+            # the guard tripped in the middle of the previous clip: this clip's first frame ran on a plan that still predicts --
+            # rebuild now and compute it again
+            self._drop_plans()
+            return self._frame_batch(a_l, fg_l, bg_l, tri_gt_l, first_frame, last_frame, memorize, max_memory_num, dilate_kernel,
+                                     frame_id, cls_override, frames_rgb, None, train, _recheck=0)
         if self.check_finite and not all(bool(torch.isfinite(o["alpha"]).all()) for o in outs):
             raise FloatingPointError("otvm_amd: non-finite alpha at frame %d -- an activation probably left fp16's range on the "
                                      "f16x3 path; rerun with model.precision = 'f32' (exact-fp32 MFMA)" % frame_id)
@@ -934,6 +1029,8 @@ class FramePlan:
         self.graphs, self._graph_warm = {}, {}
         self._fused_stats = []
         self._convs = []
+        self._predicted = []                                  # (layer, otvm_gram_params, slot in self.diag) of every predicted tail
+        self.diag = None
         self.n_gn = 0
         self.steps = {}
         self._build()
@@ -1242,8 +1339,9 @@ class FramePlan:
         e, lib, sd = self.e, self.lib, self.e.sd
         wname = p + ".conv3"
         gp = e.GP.get(wname) if hasattr(e, "GP") else None
-        if not (FUSE_GN_PREDICT and gp is not None and FUSE_GN_APPLY and FUSE_GN_STATS and FUSE_GN_TABLE and FUSE_GN_APPLY_IGEMM
-                and cp2 is not None and (GN_PREDICT_DS or not has_ds) and t2.P >= GN_PREDICT_MIN_PIXELS):
+        if not (FUSE_GN_PREDICT and not e.gn_predict_off and gp is not None and FUSE_GN_APPLY and FUSE_GN_STATS and FUSE_GN_TABLE and FUSE_GN_APPLY_IGEMM
+                and cp2 is not None and (GN_PREDICT_DS or not has_ds) and t2.P >= GN_PREDICT_MIN_PIXELS
+                and planes in GN_PREDICT_PLANES):
             return False
         w = e.W[wname]
         probe = conv_params(t2, w, out, None, 1, 0, 1, RELU, 0, x, e.precision, (1, 1, RELU))
@@ -1270,6 +1368,12 @@ class FramePlan:
         q.in_scale, q.in_shift, q.in_act = sc, sh, RELU
         q.gpart, q.spart, q.passes = gpart.data_ptr(), spart.data_ptr(), GN_PREDICT_PASSES
         q.batch, q.x_bs, q.norm_bs = B, t2.bs, nbs
+        if self.diag is None:
+            self.diag = self.raw("gnpred_diag", 2 * 64, torch.int32)     # [layer][kappa bits, flags] (ABI 18)
+        slot = len(self._predicted)
+        assert slot < 64
+        q.diag = self.diag.data_ptr() + 8 * slot
+        self._predicted.append((p, q, slot))
         self._keep.append(q)
         S.append((lib.otvm_gram_f16, (C.byref(q),), "gram " + p))
         tab = self.raw("gnpred_" + p, 2 * C4 * B)                        # [B][scale_eff C4 | bias_eff C4]
@@ -1283,6 +1387,7 @@ class FramePlan:
         r.res_shift = 0 if rsh is None else rsh
         r.scale_eff, r.bias_eff = tab.data_ptr(), tab.data_ptr() + 4 * C4
         r.batch, r.tab_bs, r.rs_bs = B, 2 * C4, 0 if rsh is None else rnbs
+        r.diag = q.diag
         self._keep.append(r)
         S.append((lib.otvm_gn_predict, (C.byref(r),), "gn_predict " + p))
         cp3 = self.conv(S, t2, wname, out, in_norm=(sc, sh, RELU, nbs), residual=idt, act=RELU)

@@ -216,10 +216,38 @@ def fullsize_fixture():
     print(name, "bank", res["bank"].tolist(), "alpha mean %.4f" % res["alpha"].mean(), "self-noise", noise, flips)
 
 
+# BASELINE configs[2] geometry (1920x1080 -> padded 1088x1920, the only padded BASELINE size), produced by the reference itself:
+# the first frame and one propagated frame (memory read over one slot).  Round 5 (at this size the HIP path was
+# compared with the oracle only).  Kept small (6.2 MB): the alpha of frame 1 as float32 (the compared quantity), frame 0's alpha
+# as its per-row sums (an anchor for the first frame), the class maps as uint8.  ~1 min per frame on 8 threads.
+C1080 = ("c1080_1920x1080_s5m5", 1080, 1920, 2, "demo", 5, 5, 12, 9)
+
+
+def c1080_fixture():
+    name, H, W, T, style, skip, max_num, dk, cs = C1080
+    res = run_sequence(H, W, T, style, skip, max_num, dk, cs)
+    alt = self_noise(H, W, T, style, skip, max_num, dk, cs)
+    noise = [float(np.abs(alt["alpha"][t] - res["alpha"][t]).max()) for t in range(T)]
+    flips = [int((alt["trimap"][t].argmax(0) != res["trimap"][t].argmax(0)).sum()) for t in range(T)]
+    tri = res["trimap"]
+    np.savez_compressed(os.path.join(HERE, "seq_%s.npz" % name), alpha1=res["alpha"][1].astype(np.float32),
+                        alpha0_rowsum=res["alpha"][0].astype(np.float64).sum(1).astype(np.float32), bank=res["bank"],
+                        trimap_cls=tri.argmax(1).astype(np.uint8), key_probe=res["key_probe"])
+    meta = dict(H=H, W=W, T=T, style=style, skip=skip, max_num=max_num, dilate_kernel=dk, clip_seed=cs, weight_seed=0,
+                bank=res["bank"].tolist(), reference_self_noise_alpha_maxabs=noise, reference_self_noise_trimap_flips=flips)
+    path = os.path.join(HERE, "fullsize.json")
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    doc[name] = meta
+    json.dump(doc, open(path, "w"), indent=1)
+    print(name, "bank", res["bank"].tolist(), "alpha mean %.4f" % res["alpha"].mean(), "self-noise", noise, flips)
+
+
 def main():
     torch.set_num_threads(8)
     if "--c480" in sys.argv:
         return fullsize_fixture()
+    if "--c1080" in sys.argv:
+        return c1080_fixture()
     meta = {}
     for (name, H, W, T, style, skip, max_num, dk, cs) in SEQUENCES:
         res = run_sequence(H, W, T, style, skip, max_num, dk, cs)

@@ -209,6 +209,45 @@ def test_480p_reference_generated_fixture(synth_sd):
             assert dg <= 1e-3, "frame %d: alpha max-abs vs the reference-generated fixture %.3e" % (t, dg)
 
 
+def test_1080p_reference_generated_fixture(synth_sd):
+    """BASELINE configs[2] geometry (1920x1080 -> padded 1088x1920, the only padded BASELINE size) against a fixture produced by
+    the REFERENCE itself (tests/golden/seq_c1080_1920x1080_s5m5.npz: tests/golden/make_golden.py --c1080 from the imported
+    reference; round 5): the first frame (anchored by the reference's per-row alpha sums) and one propagated
+    frame with the memory read, whose alpha is compared at the contract value -- directly, not through the oracle."""
+    import json
+    import os
+    from tests.common import GOLDEN, clip_inputs, frame_flags, load_golden
+    meta = json.load(open(os.path.join(GOLDEN, "fullsize.json")))["c1080_1920x1080_s5m5"]
+    gold = load_golden("c1080_1920x1080_s5m5")
+    m = _model(synth_sd)
+    outs, nflips = [], []
+    for t, (a, fg, bg, tg) in enumerate(clip_inputs(meta)):
+        out = m(a, fg, fg.clone(), tri_gt=tg, _frame_id=t, **frame_flags(meta, t))
+        torch.cuda.synchronize()
+        outs.append(out[3][0, 0, 0].cpu().numpy())
+        pl = m._engine.last_plan
+        cls = pl.CLS.reshape(pl.Hp, pl.Wp)[pl.lh:pl.lh + meta["H"], pl.lw:pl.lw + meta["W"]].cpu().numpy()
+        flips = int((cls != gold["trimap_cls"][t]).sum())
+        nflips.append(flips)
+        print("1080p reference fixture frame %d: class map differs from the reference's at %d pixels (reference vs itself with "
+              "another summation order: %d)" % (t, flips, meta["reference_self_noise_trimap_flips"][t]))
+    # frame 0: per-row sums (1920 values each): a 1e-3 max-abs error on every pixel of a row would move its sum by 1.9
+    d0 = float(np.abs(outs[0].astype(np.float64).sum(1) - gold["alpha0_rowsum"]).max())
+    d1 = float(np.abs(outs[1] - gold["alpha1"]).max())
+    print("1080p reference fixture: frame 0 row sums max-abs %.3e; frame 1 alpha max-abs vs the reference %.3e (reference self-noise "
+          "%.1e)" % (d0, d1, meta["reference_self_noise_alpha_maxabs"][1]))
+    assert d0 <= 0.25, d0
+    if sum(nflips) == 0:
+        assert d1 <= 1e-3, "frame 1: alpha max-abs vs the reference-generated fixture %.3e" % d1
+    else:
+        # the 3-class argmax in front of the distance transform is the path's one discontinuity (tests/test_gpu_frame.py): with a
+        # near-tie broken the other way the fixture is not comparable pixel by pixel around that pixel -- the reference differs
+        # from ITSELF there under another summation order.  Then: a handful of flips at most, and everything else inside 1e-3
+        bad = int((np.abs(outs[1] - gold["alpha1"]) > 1e-3).sum())
+        assert max(nflips) <= 4 * max(1, max(meta["reference_self_noise_trimap_flips"])) and bad <= 2000, (nflips, bad, d1)
+    assert m.memories["frames"] == [0]                         # (the last frame does not memorise, alpha/model.py:461)
+
+
 def test_demo_dove_layout_1080p_clip_through_eval_cli(tmp_path, synth_sd):
     """BASELINE configs[0]: a clip laid out exactly like the reference's demo/dove (11 JPEG frames of 1920x1080 under
     <root>/dove/frames/00000.jpg.., ONE grayscale trimap <root>/dove/trimap/00000.png with the levels {0, 128, 254},

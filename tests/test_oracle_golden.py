@@ -124,6 +124,30 @@ def test_oracle_fullsize_sequence_vs_reference(synth_sd):
         assert da <= 1e-3 and flips <= 8 and dtop <= 5e-3, (t, da, flips, dtop)
 
 
+def test_oracle_1080p_frame_pair_vs_reference(synth_sd):
+    """BASELINE configs[2] geometry (1920x1080, padded to 1088x1920 -- the only padded BASELINE size): the first frame and one
+    propagated frame matted by the REFERENCE itself (tests/golden/make_golden.py --c1080, round 5) against the oracle.  Pins the
+    oracle where the big tiles, the padding crop and the 8160-position memory read are real.  ~1 min of CPU."""
+    import json
+    meta = json.load(open(os.path.join(GOLDEN, "fullsize.json")))["c1080_1920x1080_s5m5"]
+    gold = load_golden("c1080_1920x1080_s5m5")
+    orc = O.OtvmOracle(synth_sd, dilate_kernel=meta["dilate_kernel"])
+    for t, (a, fg, bg, tri_gt) in enumerate(clip_inputs(meta)):
+        out = orc.frame(a, fg, bg, tri_gt=tri_gt, frame_id=t, **frame_flags(meta, t))
+        assert len(orc.bank) == gold["bank"][t]
+        alpha = out[3][0, 0, 0].numpy()
+        flips = int((out[1][0, 0].numpy().argmax(0) != gold["trimap_cls"][t]).sum())
+        if t == 0:
+            d = float(np.abs(alpha.astype(np.float64).sum(1) - gold["alpha0_rowsum"]).max())
+            print("c1080 t=0 row sums max-abs %.2e, class flips %d" % (d, flips))
+            assert d <= 0.05 and flips <= 16, (d, flips)
+        else:
+            d = float(np.abs(alpha - gold["alpha1"]).max())
+            print("c1080 t=1 alpha %.2e class flips %d (reference's own reorder noise: %.1e, %d flips)"
+                  % (d, flips, meta["reference_self_noise_alpha_maxabs"][1], meta["reference_self_noise_trimap_flips"][1]))
+            assert d <= 1e-3 and flips <= 16, (d, flips)
+
+
 def test_oracle_stages_vs_reference(synth_sd):
     """Per-stage tensors of two consecutive frames (reference forward hooks) against the oracle's captures."""
     from otvm_amd.synth_data import synthetic_clip
