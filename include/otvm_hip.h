@@ -27,12 +27,17 @@ extern "C" {
 #define OTVM_ACT_RELU 1
 #define OTVM_ACT_LEAKY 2 /* negative slope 0.01 (nn.LeakyReLU default, FBA/models.py:305) */
 
-/* Convolution arithmetic.  Both accumulate in fp32 and meet the reference's 1e-3 fp32 contract:
+/* Convolution arithmetic.  F32 and F16X3 accumulate in fp32 and meet the reference's 1e-3 fp32 contract:
  *   F32   : v_mfma_f32_32x32x2_f32, exact fp32 products (157 TFLOP/s peak);
  *   F16X3 : each fp32 operand split into fp16 hi+lo (22 significant bits), three
- *           v_mfma_f32_32x32x16_f16 passes hi*hi + hi*lo + lo*hi (833 TFLOP/s fp32-equivalent peak). */
+ *           v_mfma_f32_32x32x16_f16 passes hi*hi + hi*lo + lo*hi (833 TFLOP/s fp32-equivalent peak);
+ *   F16   : (ABI 18) a LABELLED reduced-precision mode, never a default and not covered by the parity contract: operands rounded
+ *           to fp16 once, ONE v_mfma_f32_32x32x16_f16 pass, fp32 accumulate -- in the implicit-GEMM and 3x3 patch kernels; the
+ *           other f16x3 kernels (stems, 16-wide head tile, fused STM bottleneck, memory read) keep their three passes.  Takes
+ *           the f16x3 weight arrays (w_hi / w_scale / w_frag / w_wfrag).                                                   */
 #define OTVM_PREC_F32 0
 #define OTVM_PREC_F16X3 1
+#define OTVM_PREC_F16 2
 
 const char* otvm_last_error(void);
 #define OTVM_ABI_VERSION 18   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
@@ -97,7 +102,7 @@ typedef struct {
     float* out;       int Ho, Wo, Cout, out_ld;
     int kh, kw, stride, pad, dil;
     int in_relu, act;
-    int precision;                                  /* OTVM_PREC_F32 | OTVM_PREC_F16X3           */
+    int precision;                                  /* OTVM_PREC_F32 | OTVM_PREC_F16X3 | OTVM_PREC_F16 */
     const void* w_hi; const void* w_lo;             /* f16x3: split weights [O_pad][K_pad] fp16   */
     const float* w_scale;                           /* f16x3: per-filter power-of-two scale [Cout] */
     const void* w_frag;                             /* f16x3, optional: fragment-major weights for the 3x3 patch kernel

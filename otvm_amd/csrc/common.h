@@ -27,6 +27,8 @@ void otvm_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int otvm_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// f16x3 and its single-pass sibling "f16" share kernels, weight formats and dispatch; they differ in the MFMA passes per product
+static inline bool otvm_prec_is_split(int precision) { return precision == OTVM_PREC_F16X3 || precision == OTVM_PREC_F16; }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE setting: done once per (kernel, device), not once per
 // process (a process driving engines on several GPUs).  `done`: one zero-initialised flag array per kernel.

@@ -438,6 +438,7 @@ static int launch_wave(Conv3Args& a, hipStream_t s, int ksplit) {
 }
 
 static int launch_tile(int tile, Conv3Args& a, hipStream_t s, int S) {
+    if (a.npass == 1) return otvm_launch_tile_p1(tile, a, s, S);       // precision "f16": conv_f16x3_p1.hip / _p1g.hip
     switch (tile) {
         case T256x256: return launch3<256, 256, 4, 2>(a, s, S);
         case T256x128: return launch3<256, 128, 4, 2>(a, s, S);
@@ -485,6 +486,7 @@ static bool config_ok(const otvm_conv_params* p, int tile, int S) {
     if ((bt == T64x64D || bt == T128x64D) && !f16x3_fast_layout(p->kh * p->kw, p->Cin)) return false;
     if (tile == T64x64W1 && !(p->w_wfrag && f16x3_fast_layout(p->kh * p->kw, p->Cin) && (p->in_ld & 3) == 0)) return false;
     if (tile == T64x64W1 && p->res_scale) return false;           // (the one-wave tile's epilogue has no residual scale)
+    if (p->precision == OTVM_PREC_F16 && (tile == T64x64W1 || tile == T256x256W4)) return false;   // (no single-pass form)
     // LDS-DMA weight stages: fragment-major weights, whole chunks, the input view inside a 2-GiB buffer resource
     if (is_glds_tile(tile) && !(p->w_wfrag && f16x3_fast_layout(p->kh * p->kw, p->Cin) && (p->in_ld & 3) == 0 &&
                                 (int64_t)p->H * p->W * p->in_ld * 4 < (1ll << 31))) return false;
@@ -536,7 +538,7 @@ static int glds_mode() {
 
 extern "C" int otvm_conv2d_candidates(const otvm_conv_params* p, int* out, int max_n) {
     int n = 0;
-    if (!p || !out || p->precision != OTVM_PREC_F16X3) return 0;
+    if (!p || !out || !otvm_prec_is_split(p->precision)) return 0;
     auto add = [&](int code) { if (n < max_n) out[n++] = code; };
     if (otvm_conv2d_stem_eligible(p)) add(tune_code(T_STEM, 1));
     if (otvm_conv2d_patch_eligible(p)) add(tune_code(T_PATCH, 1));
@@ -571,7 +573,7 @@ extern "C" int otvm_conv2d_candidates(const otvm_conv_params* p, int* out, int m
 
 // the whole-chunk implicit-GEMM kernels fold the producer's GroupNorm apply into their A staging (NORM_IN)
 int otvm_conv2d_igemm_accepts_input_norm(const otvm_conv_params* p) {
-    return p && p->precision == OTVM_PREC_F16X3 && f16x3_fast_layout(p->kh * p->kw, p->Cin) && !p->in_relu && p->w_hi ? 1 : 0;
+    return p && otvm_prec_is_split(p->precision) && f16x3_fast_layout(p->kh * p->kw, p->Cin) && !p->in_relu && p->w_hi ? 1 : 0;
 }
 
 int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
@@ -603,6 +605,7 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     a.M = p->Ho * p->Wo; a.taps = p->kh * p->kw; a.nchunks = p->K_pad / 32;
     a.split_stride = 0;
     a.wf = (const _Float16*)p->w_wfrag;
+    a.npass = p->precision == OTVM_PREC_F16 ? 1 : 3;
     a.tail = otvm_gn_tail_of(p);
     a.in_scale = p->in_scale; a.in_shift = p->in_shift;
     a.in_slope = p->in_act == OTVM_ACT_RELU ? 0.f : (p->in_act == OTVM_ACT_LEAKY ? 0.01f : 1.f);
@@ -638,29 +641,31 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
         static const int min_chunks = getenv("OTVM_SPLITK_MINCHUNKS") ? atoi(getenv("OTVM_SPLITK_MINCHUNKS")) : 8;
         if (S > a.nchunks / min_chunks) S = a.nchunks / min_chunks;
         if (p->gn_stats && a.nchunks < 256 && tiles > 8) S = 1;
-        while (S >= 2 && !config_ok(p, wide ? T128x128 : T128x64, S)) --S;
-        if (tiles < 192 && S >= 2) return run_config(p, a, wide ? T128x128 : T128x64, S, s);
+        const int tk = wide ? T128x128 : T128x64;
+        while (S >= 2 && !config_ok(p, tk, S)) --S;
+        if (tiles < 192 && S >= 2) return run_config(p, a, glds_mode() && config_ok(p, T_GLDS + tk, S) ? T_GLDS + tk : tk, S, s);
     }
-    if (p->Cout <= 32) return launch3<256, 32, 4, 1>(a, s);
-    if (p->Cout <= 64) return (M >= 256 * 128) ? launch3<256, 64, 4, 1>(a, s) : launch3<64, 64, 2, 2>(a, s);
+    // round 5: every tile in its LDS-DMA form wherever that is legal (OTVM_IGEMM_GLDS=0: the register-staged forms, for A/B runs)
+    const int use_glds = glds_mode();
+    auto pick = [&](int t) { return use_glds && config_ok(p, T_GLDS + t, 1) ? T_GLDS + t : t; };
+    if (p->Cout <= 32) return launch_tile(pick(T256x32), a, s, 1);
+    if (p->Cout <= 64) return launch_tile(pick((M >= 256 * 128) ? T256x64 : T64x64), a, s, 1);
     // Tile choice by workgroup count (thresholds tuned on the whole 1080p frame after the 256-row tiles got their
     // second LDS stage: 256x256 from 256 workgroups (was 480), 256x128 from 128 (was 480): 36.8 -> 37.8 frames/s;
     // OTVM_T_* override them for sweeps).
-    // round 5: the LDS-DMA form of the two big tiles wherever it is legal (OTVM_IGEMM_GLDS=0: the register-staged form, for A/B runs)
-    const int use_glds = glds_mode();
     if (config_ok(p, T256x256, 1)) {
         const int64_t huge = (int64_t)otvm_ceil_div(M, 256) * otvm_ceil_div(p->Cout, 256);
         static const int t_huge = getenv("OTVM_T_HUGE") ? atoi(getenv("OTVM_T_HUGE")) : 256;
-        if (huge >= t_huge) return launch_tile(use_glds && config_ok(p, T_GLDS + T256x256, 1) ? T_GLDS + T256x256 : T256x256, a, s, 1);
+        if (huge >= t_huge) return launch_tile(pick(T256x256), a, s, 1);
     }
     const int64_t big = (int64_t)otvm_ceil_div(M, 256) * otvm_ceil_div(p->Cout, 128);
     static const int t_big = getenv("OTVM_T_BIG") ? atoi(getenv("OTVM_T_BIG")) : 128;
-    if (big >= t_big) return launch_tile(use_glds && config_ok(p, T_GLDS + T256x128, 1) ? T_GLDS + T256x128 : T256x128, a, s, 1);
+    if (big >= t_big) return launch_tile(pick(T256x128), a, s, 1);
     const int64_t mid = (int64_t)otvm_ceil_div(M, 128) * otvm_ceil_div(p->Cout, 128);
     static const int t_mid = getenv("OTVM_T_MID") ? atoi(getenv("OTVM_T_MID")) : 384;
-    if (mid >= t_mid) return launch3<128, 128, 2, 2>(a, s);
+    if (mid >= t_mid) return launch_tile(pick(T128x128), a, s, 1);
     const int64_t sm = (int64_t)otvm_ceil_div(M, 128) * otvm_ceil_div(p->Cout, 64);
     static const int t_sm = getenv("OTVM_T_SM") ? atoi(getenv("OTVM_T_SM")) : 384;
-    if (sm >= t_sm) return launch3<128, 64, 2, 2>(a, s);
-    return launch3<64, 64, 2, 2>(a, s);
+    if (sm >= t_sm) return launch_tile(pick(T128x64), a, s, 1);
+    return launch_tile(pick(T64x64), a, s, 1);
 }

@@ -74,10 +74,13 @@ struct Conv3Args {
     int ws_bs; const float* res_scale; int rs_bs;
     unsigned in_bytes;           // GLDS tiles: size of one image's input view (the buffer resource's range; < 2^31, launch3)
     int batch;                   // images of the launch (gridDim.z)
+    int npass;                   // 3 = f16x3, 1 = precision "f16" (one MFMA pass on fp16-rounded operands; conv_f16x3_p1.hip)
 };
 
 // conv_f16x3_glds.hip: the LDS-DMA form of implicit-GEMM tile `base` (the enum of conv_f16x3.hip), K split over S workgroups
 int otvm_launch_glds_tile(int base, Conv3Args& a, hipStream_t s, int S);
+// conv_f16x3_p1.hip: the single-pass ("f16") form of tile `tile` (register-staged t or LDS-DMA 32 + t)
+int otvm_launch_tile_p1(int tile, Conv3Args& a, hipStream_t s, int S);
 
 namespace {
 
@@ -112,7 +115,11 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
 // waited for by a hand-counted `s_waitcnt vmcnt(N)` in front of the chunk's one barrier, N = the activation loads issued after
 // it, which stay in flight across the barrier.  For N to be a constant the activation loads are buffer loads without a branch:
 // a padding lane carries an out-of-range offset and the hardware returns zeros (no exec-masked load, no select afterwards).
-template <int BM, int BN, int WM, int WN, bool FAST, bool RELU_IN, bool DB = false, bool NORM_IN = false, bool GLDS = false>
+//
+// NPASS (round 5): 3 = the f16x3 operand split (fp32-class results).  1 = precision "f16", a LABELLED reduced-precision mode
+// (BASELINE configs[2] as written: "bf16 MFMA conv"): operands rounded to fp16 once (round to nearest), ONE MFMA pass, fp32
+// accumulate; the lo halves are neither computed, staged nor read.  Not the default and not parity-graded.
+template <int BM, int BN, int WM, int WN, bool FAST, bool RELU_IN, bool DB = false, bool NORM_IN = false, bool GLDS = false, int NPASS = 3>
 __global__ __launch_bounds__(WM* WN * 64)
 __attribute__((amdgpu_waves_per_eu((BM * BN == 32768 && WM * WN == 4) ? 2 : 1, (BM * BN == 32768 && WM * WN == 4) ? 2 : 10)))
 void conv_igemm_f16x3_kernel(const Conv3Args pa) {
@@ -209,7 +216,20 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
     // chunk c's blocks -> stage `buf`.  The immediate offset of an LDS-DMA instruction moves BOTH addresses, and the blocks are
     // consecutive on both sides.  (s_nop: one wait state between the SALU write of M0 and its use)
     auto dma_b = [&](int c, int buf) __attribute__((always_inline)) {
-        if constexpr (GLDS) {
+        if constexpr (GLDS && NPASS == 1) {
+            // the hi blocks only (blocks 0 and 2 of a 32-filter tile's four): they keep their places in the stage
+            const _Float16* src = dma_src + (int64_t)c * 2048;
+            const unsigned dst = dma_dst + (unsigned)buf * B_BUF_BYTES;
+            if constexpr (NBL >= 4) {
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:2048"
+                             :: "s"(dst), "v"(src) : "m0", "memory");
+                if constexpr (NBL == 8)
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\tglobal_load_lds_dwordx4 %1, off offset:2048"
+                                 :: "s"(dst + 4096u), "v"(src + (int64_t)p.nchunks * 2048) : "m0", "memory");
+            } else if (NBL == 2 || (g0 & 1) == 0) {               // (NBL == 1: the odd waves own lo blocks -- wave-uniform)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(dst), "v"(src) : "m0", "memory");
+            }
+        } else if constexpr (GLDS) {
             const _Float16* src = dma_src + (int64_t)c * 2048;
             const unsigned dst = dma_dst + (unsigned)buf * B_BUF_BYTES;
             if constexpr (NBL == 8) {                                  // (immediate offsets end at 4095: two base addresses)
@@ -333,7 +353,7 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
             for (int i = 0; i < B_LD; ++i) {
                 if (BN % B_ROWS == 0 || brow + B_ROWS * i < BN) {
                     rbh[i] = *reinterpret_cast<const f16x8*>(p.wh + woff0 + i * wstep + cw * BK);
-                    rbl[i] = *reinterpret_cast<const f16x8*>(p.wl + woff0 + i * wstep + cw * BK);
+                    if (NPASS == 3) rbl[i] = *reinterpret_cast<const f16x8*>(p.wl + woff0 + i * wstep + cw * BK);
                 }
             }
         }
@@ -367,16 +387,21 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
             }
             const f32x4 z = {0.f, 0.f, 0.f, 0.f};
             if (!GLDS || NORM_IN) v = (okmask >> i) & 1u ? v : z;      // (GLDS: a padding lane was loaded as zeros; the normalisation moves them)
-            split4(v, hi, lo);
-            *reinterpret_cast<f16x4*>(&Ah[(arow + A_ROWS * i) * LDH + ak]) = hi;
-            *reinterpret_cast<f16x4*>(&Al[(arow + A_ROWS * i) * LDH + ak]) = lo;
+            if constexpr (NPASS == 3) {
+                split4(v, hi, lo);
+                *reinterpret_cast<f16x4*>(&Ah[(arow + A_ROWS * i) * LDH + ak]) = hi;
+                *reinterpret_cast<f16x4*>(&Al[(arow + A_ROWS * i) * LDH + ak]) = lo;
+            } else {
+                hi = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};        // round to nearest
+                *reinterpret_cast<f16x4*>(&Ah[(arow + A_ROWS * i) * LDH + ak]) = hi;
+            }
         }
         if constexpr (!GLDS) {
 #pragma unroll
             for (int i = 0; i < B_LD; ++i) {
                 if (BN % B_ROWS == 0 || brow + B_ROWS * i < BN) {
                     *reinterpret_cast<f16x8*>(&Bh[(brow + B_ROWS * i) * LDH + bk]) = rbh[i];
-                    *reinterpret_cast<f16x8*>(&Bl[(brow + B_ROWS * i) * LDH + bk]) = rbl[i];
+                    if (NPASS == 3) *reinterpret_cast<f16x8*>(&Bl[(brow + B_ROWS * i) * LDH + bk]) = rbl[i];
                 }
             }
         }
@@ -403,7 +428,7 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
         for (int a = 0; a < TM; ++a) {
             const int o = ((wm * TM + a) * 32 + frow) * LDH + 16 * ks + fk;
             ah[a] = *reinterpret_cast<const f16x8*>(&Ah[o]);
-            al[a] = *reinterpret_cast<const f16x8*>(&Al[o]);
+            if (NPASS == 3) al[a] = *reinterpret_cast<const f16x8*>(&Al[o]);
         }
 #if OTVM_ABL_NOLDSRD
         if (buf < 0)
@@ -413,11 +438,11 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
             if constexpr (GLDS) {                       // fragment blocks [n-tile][k-step][hi|lo][lane][8]
                 const int o = (((wn * TN + b) * 2 + ks) * 2) * 512 + lane * 8;
                 bh[b] = *reinterpret_cast<const f16x8*>(&Bh[o]);
-                bl[b] = *reinterpret_cast<const f16x8*>(&Bh[o + 512]);
+                if (NPASS == 3) bl[b] = *reinterpret_cast<const f16x8*>(&Bh[o + 512]);
             } else {
                 const int o = ((wn * TN + b) * 32 + frow) * LDH + 16 * ks + fk;
                 bh[b] = *reinterpret_cast<const f16x8*>(&Bh[o]);
-                bl[b] = *reinterpret_cast<const f16x8*>(&Bl[o]);
+                if (NPASS == 3) bl[b] = *reinterpret_cast<const f16x8*>(&Bl[o]);
             }
         }
 #if OTVM_ABL_NOMFMA
@@ -425,16 +450,18 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
         return;
 #endif
         // three passes over the accumulator tiles, so consecutive MFMAs never share an accumulator
+        if constexpr (NPASS == 3) {
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+            for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < TN; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[b], acc[a][b], 0, 0, 0);
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
+            for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int b = 0; b < TN; ++b)
-                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < TN; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+        }
 #pragma unroll
         for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -768,7 +795,7 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
 }
 
 // FAST_ONLY: tiles that config_ok() only offers to whole-chunk layers do not instantiate the generic-decode kernels
-template <int BM, int BN, int WM, int WN, bool DB = false, bool FAST_ONLY = false, bool GLDS = false>
+template <int BM, int BN, int WM, int WN, bool DB = false, bool FAST_ONLY = false, bool GLDS = false, int NPASS = 3>
 int launch3(Conv3Args& a, hipStream_t s, int ksplit = 1) {
     a.tiles_m = otvm_ceil_div(a.M, BM);
     a.tiles_n = otvm_ceil_div(a.Cout, BN);
@@ -793,12 +820,12 @@ int launch3(Conv3Args& a, hipStream_t s, int ksplit = 1) {
         a.in_bytes = (unsigned)bytes;
     }
     if (fast) {
-        if (a.in_scale) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, false, DB, true, GLDS>), grid, block, 0, s, a);
-        else if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, true, DB, false, GLDS>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, false, DB, false, GLDS>), grid, block, 0, s, a);
+        if (a.in_scale) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, false, DB, true, GLDS, NPASS>), grid, block, 0, s, a);
+        else if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, true, DB, false, GLDS, NPASS>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, false, DB, false, GLDS, NPASS>), grid, block, 0, s, a);
     } else if constexpr (!DB && !FAST_ONLY) {
-        if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, true, false>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, false, false>), grid, block, 0, s, a);
+        if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, true, false, false, false, NPASS>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, false, false, false, false, NPASS>), grid, block, 0, s, a);
     } else {
         otvm_set_error("otvm_conv2d(f16x3): this tile takes whole-chunk layers only");
         return 1;

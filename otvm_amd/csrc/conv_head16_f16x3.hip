@@ -26,6 +26,7 @@ namespace {
 struct Head16Args {
     const float* in; const _Float16* wf; const float* wscale; const float* bias; float* out;
     int H, W, in_ld, out_ld, act;
+    unsigned in_bytes;                   // size of one image's input view (buffer-resource range)
     int tiles_x, tiles_y;
     int64_t in_bs, out_bs;
     OtvmHeadArgs head; int64_t head_img_bs, head_alpha_bs, head_tri_bs, head_sm_bs;
@@ -46,7 +47,10 @@ __device__ __forceinline__ void split4h(const f32x4 v, f16x4& hi, f16x4& lo) {
                (_Float16)(v.w - (float)h23.y)};
 }
 
-__global__ __launch_bounds__(256, 2) void conv_head16_f16x3_kernel(const Head16Args pa) {
+#ifndef OTVM_HEAD16_WGS
+#define OTVM_HEAD16_WGS 3                // workgroups per CU the register budget is set for (LDS: 3 x 54 400 B fit 160 KiB)
+#endif
+__global__ __launch_bounds__(256, OTVM_HEAD16_WGS) void conv_head16_f16x3_kernel(const Head16Args pa) {
     Head16Args p = pa;
     {
         const int zb = blockIdx.y;
@@ -66,28 +70,21 @@ __global__ __launch_bounds__(256, 2) void conv_head16_f16x3_kernel(const Head16A
     const int tile_x = blockIdx.x % p.tiles_x, tile_y = blockIdx.x / p.tiles_x;
     const int ty0 = tile_y * TH, tx0 = tile_x * TW;
 
-    // ---- the weights of all nine taps: 18 coalesced 16-byte loads per lane, resident for the whole kernel
-    f16x8 wh[9], wl[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        wh[t] = *reinterpret_cast<const f16x8*>(p.wf + (t * 2 + 0) * 512 + lane * 8);
-        wl[t] = *reinterpret_cast<const f16x8*>(p.wf + (t * 2 + 1) * 512 + lane * 8);
-    }
     // ---- the input patch: 10 x 34 pixels x 32 channels, loaded and split once (zero outside the image: the conv's padding)
     constexpr int NP = (NPIX * 8 + 255) / 256;
+    // (round 5: buffer loads without a branch -- a pixel outside the image carries an out-of-range offset and reads zeros)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     f32x4 rp[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const int idx = tid + k * 256;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (idx < NPIX * 8) {
-            const int pix = idx >> 3, c4 = (idx & 7) * 4;
-            const int py = pix / PW, px = pix - py * PW;
-            const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
-            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-                v = *reinterpret_cast<const f32x4*>(p.in + ((int64_t)iy * p.W + ix) * p.in_ld + c4);
-        }
-        rp[k] = v;
+        const int pix = idx >> 3, c4 = (idx & 7) * 4;
+        const int py = pix / PW, px = pix - py * PW;
+        const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
+        const unsigned oob = (unsigned)((int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W) & (int)(idx < NPIX * 8)) - 1u;
+        rp[k] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(
+            in_rsrc, (((unsigned)(iy * p.W + ix) * (unsigned)p.in_ld + c4) << 2) | oob, 0, 0));
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -99,6 +96,14 @@ __global__ __launch_bounds__(256, 2) void conv_head16_f16x3_kernel(const Head16A
             *reinterpret_cast<f16x4*>(&Ph[pix * LDP + c4]) = hi;
             *reinterpret_cast<f16x4*>(&Pl[pix * LDP + c4]) = lo;
         }
+    }
+    // ---- the weights of all nine taps: 18 coalesced 16-byte loads per lane (L2-resident), in registers for the tap loop; issued
+    // behind the patch so that their 72 registers and the patch's 44 are not live together
+    f16x8 wh[9], wl[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        wh[t] = *reinterpret_cast<const f16x8*>(p.wf + (t * 2 + 0) * 512 + lane * 8);
+        wl[t] = *reinterpret_cast<const f16x8*>(p.wf + (t * 2 + 1) * 512 + lane * 8);
     }
     __syncthreads();
 
@@ -208,6 +213,8 @@ int otvm_conv2d_head16_impl(const otvm_conv_params* p, const otvm_head_params* h
     Head16Args a;
     a.in = p->in; a.wf = (const _Float16*)hd->w16; a.wscale = p->w_scale; a.bias = p->bias; a.out = p->out;
     a.H = p->H; a.W = p->W; a.in_ld = p->in_ld; a.out_ld = p->out_ld; a.act = p->act;
+    OTVM_REQUIRE((int64_t)p->H * p->W * p->in_ld * 4 < 0xFFFFFFF0ll, "otvm_conv2d_head (16-wide tile): input view beyond 32-bit offsets");
+    a.in_bytes = (unsigned)((int64_t)p->H * p->W * p->in_ld * 4);
     a.tiles_x = otvm_ceil_div(p->W, TW); a.tiles_y = otvm_ceil_div(p->H, TH);
     const int batch = p->batch > 1 ? p->batch : 1;
     a.in_bs = batch > 1 ? p->in_bs : 0; a.out_bs = batch > 1 ? p->out_bs : 0;

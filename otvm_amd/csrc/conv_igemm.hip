@@ -306,11 +306,11 @@ extern "C" int otvm_pack_conv_weight(const float* w_oihw, int O, int I, int kh, 
 int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream);   // conv_f16x3.hip
 
 extern "C" int otvm_conv2d(const otvm_conv_params* p, void* stream) {
-    OTVM_REQUIRE(p && p->in && p->out && (p->w || p->precision == OTVM_PREC_F16X3), "otvm_conv2d: null pointer");
+    OTVM_REQUIRE(p && p->in && p->out && (p->w || otvm_prec_is_split(p->precision)), "otvm_conv2d: null pointer");
     OTVM_REQUIRE(p->Cin % 4 == 0 && p->in_ld % 4 == 0, "otvm_conv2d: Cin (%d) and in_ld (%d) must be multiples of 4",
                  p->Cin, p->in_ld);
     OTVM_REQUIRE(((uintptr_t)p->in & 15) == 0 && ((uintptr_t)p->w & 15) == 0, "otvm_conv2d: in/w must be 16-byte aligned");
-    OTVM_REQUIRE(p->precision == OTVM_PREC_F32 || p->precision == OTVM_PREC_F16X3, "otvm_conv2d: unknown precision %d",
+    OTVM_REQUIRE(p->precision == OTVM_PREC_F32 || otvm_prec_is_split(p->precision), "otvm_conv2d: unknown precision %d",
                  p->precision);
     // the in-tile group reduction works on power-of-two runs of channels: 32 groups of 2, 4, 8, ... channels
     OTVM_REQUIRE(!p->gn_stats || (p->Cout % 64 == 0 && ((p->Cout / 32) & (p->Cout / 32 - 1)) == 0 &&
@@ -326,7 +326,7 @@ extern "C" int otvm_conv2d(const otvm_conv_params* p, void* stream) {
                  "otvm_conv2d: fused input normalisation requested for a layer otvm_conv2d_accepts_input_norm() rejects");
     OTVM_REQUIRE(!p->gn_scale_out || (p->gn_stats && p->gn_shift_out && p->gn_gamma && p->gn_beta && p->gn_counter),
                  "otvm_conv2d: gn_scale_out needs gn_stats, gn_shift_out, gn_gamma, gn_beta and gn_counter");
-    if (p->precision == OTVM_PREC_F16X3) return otvm_conv2d_f16x3_impl(p, stream);
+    if (otvm_prec_is_split(p->precision)) return otvm_conv2d_f16x3_impl(p, stream);
     if (p->gn_scale_out) {            // exact fp32: the kernels below leave the table to one more launch
         otvm_conv_params q = *p;
         q.gn_scale_out = nullptr;

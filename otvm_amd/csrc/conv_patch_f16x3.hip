@@ -83,7 +83,8 @@ __device__ __forceinline__ void split4p(const f32x4 v, f16x4& hi, f16x4& lo) {
 // fragments of its BN output channels, copied verbatim from the fragment-major weight array (1-KiB blocks).
 // TAPG = 9: one weight stage per channel stage (narrow layers); TAPG = 3: wide layers (BN = 256), where nine taps of
 // weights (144 KiB) would not fit beside the patch.
-template <int TH, int BN, int NW, int DIL, int TAPG, bool INRES = false, bool HEAD = false, int NWN = 1, bool GLDS = false>
+// NPASS = 1: precision "f16" (one MFMA pass on fp16-rounded operands; conv_f16x3_kernel.h has the definition of the mode)
+template <int TH, int BN, int NW, int DIL, int TAPG, bool INRES = false, bool HEAD = false, int NWN = 1, bool GLDS = false, int NPASS = 3>
 __global__ __launch_bounds__(NW * 64)
 __attribute__((amdgpu_waves_per_eu((TAPG == 3 && BN <= 32 && !INRES) ? 3 : 1, (TAPG == 3 && BN <= 32 && !INRES) ? 3 : 10)))
 void conv_patch_f16x3_kernel(const PatchArgs pa) {
@@ -122,7 +123,8 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     // the 1-KiB fragment blocks are lane-linear, exactly what it writes) into the OTHER of two stage buffers while the current
     // stage is multiplied -- no staging registers, no ds_write pass, and the stages that keep their input patch (two of three)
     // need ONE barrier instead of two.  Ordering: the issuing waves wait vmcnt(0), then the barrier; the fragments are read after it.
-    static_assert(!GLDS || BN == 256, "LDS-DMA weight stages copy every channel tile of the block: Cout % BN == 0 (the 256-channel tiles: patch_choice)");
+    // (LDS-DMA weight stages copy every channel tile of the block: the host offers them to layers with Cout % BN == 0 only)
+    static_assert(!GLDS || TAPG == 3, "LDS-DMA weight stages: the 3-tap stages (two buffers fit beside the patch)");
     constexpr int NBUF = GLDS ? 2 : 1;
     constexpr int SM_HALFS = PATCH_HALFS + NBUF * B_HALFS > EPI_HALFS ? PATCH_HALFS + NBUF * B_HALFS : EPI_HALFS;
     __shared__ __attribute__((aligned(16))) _Float16 smem[SM_HALFS];
@@ -179,6 +181,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
             if (i < B_PIECES) {
                 const int l = i & 63, blk = i >> 6;                     // blk = (tapl*TN + b)*2 + hl
                 const int hl = blk & 1, tb = blk >> 1, b = tb % TNW, tap = g * TAPG + tb / TNW;
+                if (NPASS == 1 && hl) continue;                         // (wave-uniform: a wave copies whole 1-KiB blocks)
                 const int64_t src = (((((int64_t)cb32 * 9 + tap) * nbs + nb0 + b) * 2 + ks) * 2 + hl) * 512 + l * 8;
                 if constexpr (GLDS) {
                     // issued from inline asm (round 5): the compiler orders every LDS read behind an LDS-DMA it knows about -- the
@@ -224,6 +227,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 const int i = tid + k * NT;
+                if (NPASS == 1 && ((i >> 6) & 1)) continue;
                 if (i < B_PIECES) *reinterpret_cast<f16x8*>(&Bs[i * 8]) = rb[k];
             }
         }
@@ -249,10 +253,15 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                     }
                     f16x4 hi, lo;
-                    split4p(v, hi, lo);
                     const int pix = idx >> 2, c4 = (idx & 3) * 4;
-                    *reinterpret_cast<f16x4*>(&Ph[pix * LDP + c4]) = hi;
-                    *reinterpret_cast<f16x4*>(&Pl[pix * LDP + c4]) = lo;
+                    if constexpr (NPASS == 3) {
+                        split4p(v, hi, lo);
+                        *reinterpret_cast<f16x4*>(&Ph[pix * LDP + c4]) = hi;
+                        *reinterpret_cast<f16x4*>(&Pl[pix * LDP + c4]) = lo;
+                    } else {
+                        hi = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};    // round to nearest
+                        *reinterpret_cast<f16x4*>(&Ph[pix * LDP + c4]) = hi;
+                    }
                 }
             }
         }
@@ -296,7 +305,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
 #else
                     const int o = ((wave_m * TM + a + ky * DIL) * PW + kx * DIL + frow) * LDP + 8 * fh;
                     ah[a] = *reinterpret_cast<const f16x8*>(&Ph[o]);
-                    al[a] = *reinterpret_cast<const f16x8*>(&Pl[o]);
+                    if (NPASS == 3) al[a] = *reinterpret_cast<const f16x8*>(&Pl[o]);
 #endif
                 }
                 // B fragments are read for GB channel tiles at a time, then three passes over the GB x TM accumulators:
@@ -313,23 +322,25 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                         bh[j] = one; bl[j] = one * (_Float16)(float)lane;
 #else
                         bh[j] = *reinterpret_cast<const f16x8*>(&Bcur[((tl * TNW + nt0 + b0 + j) * 2) * 512 + lane * 8]);
-                        bl[j] = *reinterpret_cast<const f16x8*>(&Bcur[((tl * TNW + nt0 + b0 + j) * 2 + 1) * 512 + lane * 8]);
+                        if (NPASS == 3) bl[j] = *reinterpret_cast<const f16x8*>(&Bcur[((tl * TNW + nt0 + b0 + j) * 2 + 1) * 512 + lane * 8]);
 #endif
                     }
 #if OTVM_PABL_NOMFMA
                     if (ah[0][0] == (_Float16)12345.f) acc[0][0][0] += (float)bh[0][0] + (float)bl[0][0] + (float)al[0][0];
                     continue;
 #endif
+                    if constexpr (NPASS == 3) {
 #pragma unroll
-                    for (int j = 0; j < GB; ++j)
+                        for (int j = 0; j < GB; ++j)
 #pragma unroll
-                        for (int a = 0; a < TM; ++a)
-                            acc[a][b0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[j], acc[a][b0 + j], 0, 0, 0);
+                            for (int a = 0; a < TM; ++a)
+                                acc[a][b0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[a], bh[j], acc[a][b0 + j], 0, 0, 0);
 #pragma unroll
-                    for (int j = 0; j < GB; ++j)
+                        for (int j = 0; j < GB; ++j)
 #pragma unroll
-                        for (int a = 0; a < TM; ++a)
-                            acc[a][b0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[j], acc[a][b0 + j], 0, 0, 0);
+                            for (int a = 0; a < TM; ++a)
+                                acc[a][b0 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[a], bl[j], acc[a][b0 + j], 0, 0, 0);
+                    }
 #pragma unroll
                     for (int j = 0; j < GB; ++j)
 #pragma unroll
@@ -599,12 +610,12 @@ __global__ __launch_bounds__(256) void pack_patch_weight_kernel(const float* __r
     }
 }
 
-template <int TH, int BN, int NW, int DIL, int TAPG = 9, bool INRES = false, bool HEAD = false, int NWN = 1, bool GLDS = false>
+template <int NPASS, int TH, int BN, int NW, int DIL, int TAPG = 9, bool INRES = false, bool HEAD = false, int NWN = 1, bool GLDS = false>
 int launch_patch(PatchArgs& a, hipStream_t s) {
     a.tiles_x = otvm_ceil_div(a.W, 32);
     a.tiles_y = otvm_ceil_div(a.H, TH);
     a.tiles_n = otvm_ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL, TAPG, INRES, HEAD, NWN, GLDS>), dim3(a.tiles_x * a.tiles_y * a.tiles_n, a.batch), dim3(NW * 64), 0, s, a);
+    hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL, TAPG, INRES, HEAD, NWN, GLDS, NPASS>), dim3(a.tiles_x * a.tiles_y * a.tiles_n, a.batch), dim3(NW * 64), 0, s, a);
     OTVM_CHECK_LAUNCH("otvm_conv2d(patch f16x3)");
     return 0;
 }
@@ -646,20 +657,20 @@ static int patch_choice(const otvm_conv_params* p, bool forced = false) {
 // the fused input normalisation (otvm_conv_params.in_scale): this kernel, or the whole-chunk implicit-GEMM kernels
 int otvm_conv2d_igemm_accepts_input_norm(const otvm_conv_params* p);       // conv_f16x3.hip
 extern "C" int otvm_conv2d_accepts_input_norm(const otvm_conv_params* p) {
-    return p && p->precision == OTVM_PREC_F16X3 && (patch_choice(p) != 0 || otvm_conv2d_igemm_accepts_input_norm(p)) ? 1 : 0;
+    return p && otvm_prec_is_split(p->precision) && (patch_choice(p) != 0 || otvm_conv2d_igemm_accepts_input_norm(p)) ? 1 : 0;
 }
 // which kernel family would take it: 0 none, 1 the patch kernel (the heuristic's choice for this layer), 2 an implicit-GEMM tile.
 // A host may prefer a separate apply pass over 2 for a KxK layer: the implicit GEMM stages (and normalises) every input
 // element once per tap -- on the 3x3 512-channel layers that cost 40 us per launch against 20 for the pass it replaced.
 extern "C" int otvm_conv2d_input_norm_kind(const otvm_conv_params* p) {
-    if (!p || p->precision != OTVM_PREC_F16X3) return 0;
+    if (!p || !otvm_prec_is_split(p->precision)) return 0;
     if (patch_choice(p) != 0) return 1;
     return otvm_conv2d_igemm_accepts_input_norm(p) ? 2 : 0;
 }
 
 // ABI 17: in_res (the identity added inside the fused input normalisation) exists on the narrow dilation-1 patch tiles
 extern "C" int otvm_conv2d_accepts_input_residual(const otvm_conv_params* p) {
-    return p && p->precision == OTVM_PREC_F16X3 && patch_choice(p) == 1 && p->dil == 1 && p->in_scale && !p->in_relu ? 1 : 0;
+    return p && otvm_prec_is_split(p->precision) && patch_choice(p) == 1 && p->dil == 1 && p->in_scale && !p->in_relu ? 1 : 0;
 }
 
 int otvm_conv2d_patch_eligible(const otvm_conv_params* p) {
@@ -673,7 +684,7 @@ int otvm_conv2d_head16_impl(const otvm_conv_params* p, const otvm_head_params* h
 // ABI 17: 3x3 conv to 16 channels with the FBA head in its epilogue (include/otvm_hip.h)
 extern "C" int otvm_conv2d_head(const otvm_conv_params* p, const otvm_head_params* hd, void* stream) {
     OTVM_REQUIRE(p && hd && p->in && hd->w && hd->b && hd->img, "otvm_conv2d_head: null pointer");
-    OTVM_REQUIRE(p->precision == OTVM_PREC_F16X3 && p->Cout == 16 && patch_choice(p) == 1 && p->dil == 1 && !p->residual &&
+    OTVM_REQUIRE(otvm_prec_is_split(p->precision) && p->Cout == 16 && patch_choice(p) == 1 && p->dil == 1 && !p->residual &&
                      !p->gn_stats && !p->in_res && p->w_scale,
                  "otvm_conv2d_head: a 3x3 stride-1 f16x3 layer with 16 output channels, no residual / statistics");
     OTVM_REQUIRE(hd->n_out == 7 || (hd->n_out == 10 && hd->tri_out), "otvm_conv2d_head: n_out must be 7, or 10 with tri_out");
@@ -687,7 +698,8 @@ int otvm_conv2d_patch_f16x3_forced(const otvm_conv_params* p, void* stream) { re
 // returns -1 when the layer is not eligible (caller falls back to the implicit-GEMM kernel)
 int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream) { return patch_run(p, stream, patch_choice(p)); }
 
-static int patch_run(const otvm_conv_params* p, void* stream, int choice, const otvm_head_params* hd) {
+template <int NPASS>
+static int patch_run_t(const otvm_conv_params* p, void* stream, int choice, const otvm_head_params* hd) {
     if (choice == 0) return -1;
     const bool is_wide = choice == 2;
     PatchArgs a;
@@ -713,12 +725,12 @@ static int patch_run(const otvm_conv_params* p, void* stream, int choice, const 
         a.head.sm = hd->sm; a.head.sm_ld = hd->sm_ld; a.head.out7 = nullptr; a.head.logits_out = nullptr;
         a.head_img_bs = a.batch > 1 ? hd->img_bs : 0; a.head_alpha_bs = a.batch > 1 ? hd->alpha_bs : 0;
         a.head_tri_bs = a.batch > 1 ? hd->tri_bs : 0; a.head_sm_bs = a.batch > 1 ? hd->sm_bs : 0;
-        return launch_patch<8, 32, 4, 1, 3, false, true>(a, s);
+        return launch_patch<3, 8, 32, 4, 1, 3, false, true>(a, s);      // (the head epilogue: f16x3 in either mode)
     }
     if (p->in_res) {
         OTVM_REQUIRE(otvm_conv2d_accepts_input_residual(p) && !is_wide && (p->in_res_ld & 3) == 0 && ((uintptr_t)p->in_res & 15) == 0,
                      "otvm_conv2d: in_res needs in_scale on a 3x3 stride-1 dilation-1 layer with <= 64 output channels");
-        return p->Cout <= 32 ? launch_patch<8, 32, 4, 1, 3, true>(a, s) : launch_patch<8, 64, 4, 1, 9, true>(a, s);
+        return p->Cout <= 32 ? launch_patch<3, 8, 32, 4, 1, 3, true>(a, s) : launch_patch<3, 8, 64, 4, 1, 9, true>(a, s);
     }
     if (is_wide) {
         // the eight waves as 4 x 2 (two rows x four channel tiles each) instead of 8 x 1 (one row x eight tiles): a third less
@@ -726,15 +738,15 @@ static int patch_run(const otvm_conv_params* p, void* stream, int choice, const 
         // rows x two tiles) spills 108 B
         static const int nwn = getenv("OTVM_PATCH_WIDE_NWN") ? atoi(getenv("OTVM_PATCH_WIDE_NWN")) : 2;
         static const int glds = getenv("OTVM_PATCH_WIDE_GLDS") ? atoi(getenv("OTVM_PATCH_WIDE_GLDS")) : 1;
-        if (nwn == 2 && p->dil == 1 && glds) return launch_patch<8, 256, 8, 1, 3, false, false, 2, true>(a, s);
-        if (nwn == 2 && p->dil == 1) return launch_patch<8, 256, 8, 1, 3, false, false, 2>(a, s);   // (dilated: 52 / 92 B of scratch)
-        if (p->dil == 1) return launch_patch<8, 256, 8, 1, 3>(a, s);
-        if (p->dil == 2) return launch_patch<8, 256, 8, 2, 3>(a, s);
-        return launch_patch<8, 256, 8, 4, 3>(a, s);
+        if (nwn == 2 && p->dil == 1 && glds) return launch_patch<NPASS, 8, 256, 8, 1, 3, false, false, 2, true>(a, s);
+        if (nwn == 2 && p->dil == 1) return launch_patch<NPASS, 8, 256, 8, 1, 3, false, false, 2>(a, s);   // (dilated: 52 / 92 B of scratch)
+        if (p->dil == 1) return launch_patch<NPASS, 8, 256, 8, 1, 3>(a, s);
+        if (p->dil == 2) return launch_patch<NPASS, 8, 256, 8, 2, 3>(a, s);
+        return launch_patch<NPASS, 8, 256, 8, 4, 3>(a, s);
     }
     static const int th16 = getenv("OTVM_PATCH_TH16") ? atoi(getenv("OTVM_PATCH_TH16")) : 0;
     if (p->dil == 1 && th16 && (int64_t)p->H * p->W >= (1 << 18))      // 16x32 pixel blocks, 8 waves: half the weight stream per pixel
-        return p->Cout <= 32 ? launch_patch<16, 32, 8, 1>(a, s) : launch_patch<16, 64, 8, 1>(a, s);
+        return p->Cout <= 32 ? launch_patch<NPASS, 16, 32, 8, 1>(a, s) : launch_patch<NPASS, 16, 64, 8, 1>(a, s);
     // (measured and rejected, round 2: 16x32-pixel blocks with 8 waves -- half the weight stream and less halo per pixel --
     // 64->64 at 1088x1920 0.604 vs 0.604 ms, 64->32 0.317 vs 0.306, 32->16 0.201 vs 0.187: the weight stream is not the limit)
     // <= 32 output channels: 3-tap weight stages (46 KB of LDS instead of 58) and 158 registers -> three workgroups per CU
@@ -749,8 +761,21 @@ static int patch_run(const otvm_conv_params* p, void* stream, int choice, const 
     // the compiler already shares equal fragment loads between taps): 80->32 at 1088x1920 0.429 -> 0.415 ms, 64->32 0.310 ->
     // 0.301; no gain at 480x832 (two workgroups per CU instead of three).  Two waves x four rows on 8 x 32 blocks: 0.447 / 0.320.
     static const int rows4 = getenv("OTVM_PATCH32_ROWS4") ? atoi(getenv("OTVM_PATCH32_ROWS4")) : 1;
-    if (p->dil == 1 && p->Cout <= 32 && rows4 && (int64_t)p->H * p->W >= (1 << 20)) return launch_patch<16, 32, 4, 1, 3>(a, s);
-    if (p->dil == 1) return p->Cout <= 32 ? launch_patch<8, 32, 4, 1, 3>(a, s) : launch_patch<8, 64, 4, 1>(a, s);
-    if (p->dil == 2) return launch_patch<8, 64, 4, 2>(a, s);
-    return launch_patch<8, 64, 4, 4>(a, s);
+    static const int glds32 = getenv("OTVM_PATCH32_GLDS") ? atoi(getenv("OTVM_PATCH32_GLDS")) : 0;   // (LDS-DMA weight stages: neutral, see below)
+    if (p->dil == 1 && p->Cout <= 32 && rows4 && (int64_t)p->H * p->W >= (1 << 20))
+        return glds32 ? launch_patch<NPASS, 16, 32, 4, 1, 3, false, false, 1, true>(a, s) : launch_patch<NPASS, 16, 32, 4, 1, 3>(a, s);
+    // round 5: 64 output channels with 3-tap weight stages copied by LDS-DMA into alternating buffers (as the 256-channel tiles):
+    // the nine-tap stage moved 36 KiB of weights per 16 input channels through registers (9 x 16 bytes per lane + 9 ds_write_b128)
+    // Measured neutral (profiles/r05_patch_narrow_glds_ab.txt: 64->64 at 1088x1920 0.548 vs 0.550 ms, 320->64 0.516 vs 0.507, 64->32
+    // 0.272 vs 0.275; whole frame 45.91 vs 45.92 frames/s): the tenth variant this tile does not respond to.  Off by default.
+    static const int glds64 = getenv("OTVM_PATCH64_GLDS") ? atoi(getenv("OTVM_PATCH64_GLDS")) : 0;
+    if (p->dil == 1 && p->Cout > 32 && glds64) return launch_patch<NPASS, 8, 64, 4, 1, 3, false, false, 1, true>(a, s);   // (both channel tiles have weights)
+    if (p->dil == 1 && p->Cout <= 32 && glds32) return launch_patch<NPASS, 8, 32, 4, 1, 3, false, false, 1, true>(a, s);
+    if (p->dil == 1) return p->Cout <= 32 ? launch_patch<NPASS, 8, 32, 4, 1, 3>(a, s) : launch_patch<NPASS, 8, 64, 4, 1>(a, s);
+    if (p->dil == 2) return launch_patch<NPASS, 8, 64, 4, 2>(a, s);
+    return launch_patch<NPASS, 8, 64, 4, 4>(a, s);
+}
+
+static int patch_run(const otvm_conv_params* p, void* stream, int choice, const otvm_head_params* hd) {
+    return p->precision == OTVM_PREC_F16 ? patch_run_t<1>(p, stream, choice, hd) : patch_run_t<3>(p, stream, choice, hd);
 }

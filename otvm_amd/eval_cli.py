@@ -38,7 +38,8 @@ def main(argv=None):
     ap.add_argument("--trimap", default="medium", choices=["narrow", "medium", "wide"])
     ap.add_argument("--skip", type=int, default=10)          # cfg.TEST.MEMORY_SKIP_FRAME (config.py:23)
     ap.add_argument("--max-num", type=int, default=5)        # cfg.TEST.MEMORY_MAX_NUM   (config.py:22)
-    ap.add_argument("--precision", default=None, choices=["f32", "f16x3"])
+    ap.add_argument("--precision", default=None, choices=["f32", "f16x3", "f16"],
+                    help="f16x3 (default, fp32-class), f32 (exact-fp32 MFMA), f16 (one fp16 MFMA pass: reduced precision, labelled mode)")
     ap.add_argument("--gpus", type=int, default=None, help="start this many ranks, one per GPU (default: the launcher's)")
     ap.add_argument("--sync-io", action="store_true", help="write PNGs synchronously in the frame loop (as eval.py does)")
     ap.add_argument("--batch", type=int, default=None,

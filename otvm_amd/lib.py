@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so")   # env: kernel-variant A/B runs
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
-PREC_F32, PREC_F16X3 = 0, 1
+PREC_F32, PREC_F16X3, PREC_F16 = 0, 1, 2
 ABI_VERSION = 18         # include/otvm_hip.h OTVM_ABI_VERSION
 
 

@@ -225,8 +225,7 @@ def test_1080p_reference_generated_fixture(synth_sd):
         out = m(a, fg, fg.clone(), tri_gt=tg, _frame_id=t, **frame_flags(meta, t))
         torch.cuda.synchronize()
         outs.append(out[3][0, 0, 0].cpu().numpy())
-        pl = m._engine.last_plan
-        cls = pl.CLS.reshape(pl.Hp, pl.Wp)[pl.lh:pl.lh + meta["H"], pl.lw:pl.lw + meta["W"]].cpu().numpy()
+        cls = out[1][0, 0].argmax(0).cpu().numpy()               # class map of the OUTPUT trimap, as the fixture stores it
         flips = int((cls != gold["trimap_cls"][t]).sum())
         nflips.append(flips)
         print("1080p reference fixture frame %d: class map differs from the reference's at %d pixels (reference vs itself with "
@@ -237,14 +236,10 @@ def test_1080p_reference_generated_fixture(synth_sd):
     print("1080p reference fixture: frame 0 row sums max-abs %.3e; frame 1 alpha max-abs vs the reference %.3e (reference self-noise "
           "%.1e)" % (d0, d1, meta["reference_self_noise_alpha_maxabs"][1]))
     assert d0 <= 0.25, d0
-    if sum(nflips) == 0:
-        assert d1 <= 1e-3, "frame 1: alpha max-abs vs the reference-generated fixture %.3e" % d1
-    else:
-        # the 3-class argmax in front of the distance transform is the path's one discontinuity (tests/test_gpu_frame.py): with a
-        # near-tie broken the other way the fixture is not comparable pixel by pixel around that pixel -- the reference differs
-        # from ITSELF there under another summation order.  Then: a handful of flips at most, and everything else inside 1e-3
-        bad = int((np.abs(outs[1] - gold["alpha1"]) > 1e-3).sum())
-        assert max(nflips) <= 4 * max(1, max(meta["reference_self_noise_trimap_flips"])) and bad <= 2000, (nflips, bad, d1)
+    # (the output trimap's class map flips at a handful of near-tie pixels under ANY other fp32 summation order -- the reference
+    #  against itself: 3 / 4 pixels -- so it is bounded, not required to be equal)
+    assert max(nflips) <= 64, nflips
+    assert d1 <= 1e-3, "frame 1: alpha max-abs vs the reference-generated fixture %.3e" % d1
     assert m.memories["frames"] == [0]                         # (the last frame does not memorise, alpha/model.py:461)
 
 

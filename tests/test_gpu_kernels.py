@@ -327,6 +327,54 @@ def test_conv_fused_input_groupnorm_implicit_gemm(G, case):
         assert float((gotc - want).abs().max()) <= 3e-5 * max(1.0, float(want.abs().max()))
 
 
+@pytest.mark.parametrize("Cin,Cout,k,dil,H,W,tune", [
+    (256, 256, 3, 1, 40, 56, 0),                    # heuristic: patch or an LDS-DMA tile
+    (256, 256, 3, 1, 40, 56, (32 + 0 + 1) * 16 + 1),    # 256x256 LDS-DMA tile (hi blocks only in the weight stage)
+    (512, 128, 1, 1, 33, 47, (32 + 2 + 1) * 16 + 1),    # 128x128 LDS-DMA tile
+    (512, 128, 1, 1, 33, 47, (3 + 1) * 16 + 2),         # register-staged 128x64, K split over 2
+    (128, 512, 1, 1, 33, 47, (32 + 8 + 1) * 16 + 1),    # 4-wave 128x256 LDS-DMA tile (two DMA bases)
+    (64, 64, 3, 1, 33, 47, 0),                      # narrow patch tile
+    (80, 32, 3, 1, 50, 33, 0),                      # 32-channel patch tile, 5 stages
+    (24, 64, 7, 2, 40, 64, (3 + 1) * 16 + 1),           # generic K decode (7x7 stem shape on an implicit-GEMM tile)
+])
+def test_conv_single_pass_f16_mode(G, Cin, Cout, k, dil, H, W, tune):
+    """precision 2 (OTVM_PREC_F16, round 5): the labelled reduced-precision mode -- ONE MFMA pass on fp16-rounded operands in the
+    implicit-GEMM and patch kernels.  Against a float64 convolution: the error of an fp16-operand product (2^-11 per operand,
+    averaged over K), i.e. far above f16x3's and far below a wrong result -- and exactly the float64 convolution of the
+    fp16-ROUNDED operands up to fp32 accumulation (the mode computes what it says)."""
+    from otvm_amd import lib as L
+    from otvm_amd.engine import conv_params
+    lib = L.load()
+    pad = dil * (k - 1) // 2
+    stride = 2 if k == 7 else 1
+    x = rnd(1, Cin, H, W, seed=410)
+    w = rnd(Cout, Cin, k, k, seed=411, scale=1.0 / math.sqrt(Cin * k * k))
+    b = rnd(Cout, seed=412)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride, pad, dil)
+    cw, xa, bd = G.pack_weight(w), G.to_act(x), b.to(G.DEV)
+    out = G.empty_act(ref.shape[2], ref.shape[3], Cout)
+    ws = torch.empty(8 << 20, device=G.DEV)
+    err = {}
+    for prec in (L.PREC_F16X3, L.PREC_F16):
+        out.t.fill_(float("nan"))
+        p = conv_params(xa, cw, out, bd, stride, pad, dil, 0, 0, None, prec, None, ws)
+        p.tune = tune
+        L.check(lib.otvm_conv2d(C.byref(p), G.stream()), "conv precision %d" % prec)
+        torch.cuda.synchronize()
+        got = G.from_act(out, Cout).double()
+        assert torch.isfinite(got).all()
+        err[prec] = float((got - ref).abs().max()) / float(ref.abs().max())
+    # the operands as the kernel rounds them: weights per filter scaled by a power of two (exact), round to nearest
+    xh = x.half().double()
+    wh = w.half().double()
+    ref16 = F.conv2d(xh, wh, b.double(), stride, pad, dil)
+    e16 = float((got - ref16).abs().max()) / float(ref.abs().max())
+    print("   f16x3 %.2e, f16 %.2e of max|y| against float64; f16 against the float64 convolution of the rounded operands %.2e"
+          % (err[L.PREC_F16X3], err[L.PREC_F16], e16))
+    assert err[L.PREC_F16X3] <= 2e-5 and 1e-5 < err[L.PREC_F16] <= 4e-3, err
+    assert e16 <= 3e-5, e16
+
+
 def test_f16x3_is_fp32_class(G):
     """Error of the split-fp16 path vs an fp64 reference, next to the exact-fp32 MFMA path, on operands
     spanning 1e-3 .. 30 (the dropped lo*lo term is 2^-22 relative)."""
