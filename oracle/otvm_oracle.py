@@ -166,6 +166,12 @@ class OtvmOracle:
         reference's float32 arithmetic, it is part of the definition): the tests use it to measure how far the
         reference's own fp32 forward is from the exact value of its algorithm on a given frame -- the summation-order
         noise any two fp32 implementations differ by."""
+        # Host threads.  PyTorch's default (one per physical core) is the slowest setting on a many-core GPU host: measured on the
+        # MI355X box (256 logical CPUs, default 128 threads; profiles/r05_oracle_threads.txt) a 1080p first frame takes 19.2 s on
+        # 128 threads, 11.2 s on 64, 8.3 s on 32, 7.5 s on 16 -- oneDNN's convolutions of this size do not scale past a few dozen
+        # cores and pay for the synchronisation.  Default: at most 32.
+        if threads is None and torch.get_num_threads() > 32:
+            threads = 32
         if threads:
             torch.set_num_threads(threads)
         self.dtype = dtype

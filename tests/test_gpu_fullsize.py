@@ -414,7 +414,9 @@ def test_4k_growing_bank_frame_vs_oracle(synth_sd):
     import os
     from oracle.otvm_oracle import OtvmOracle
     from otvm_amd.synth_data import synthetic_clip
-    H, W, T, t_s = 2160, 3840, 6, 3
+    # (round 5: frame 3 is the clip's LAST frame -- no memorize on either side: the compared quantity is the frame that READS the
+    #  three slots; the CPU oracle's Encoder_M pass at 4K was a fifth of this test's 217 s.  Memorize at 4K: the frames before.)
+    H, W, T, t_s = 2160, 3840, 4, 3
     frames, tri = synthetic_clip(H, W, t_s + 1, seed=29)
     m = _model(synth_sd)
     flags = lambda t: dict(first_frame=(t == 0), last_frame=(t == T - 1), memorize=True, max_memory_num=64)
@@ -437,7 +439,7 @@ def test_4k_growing_bank_frame_vs_oracle(synth_sd):
         orc64.bank = [(k.double(), v.double(), f) for k, v, f in orc.bank]
     a, fg, tg = _clip_tensors(frames, tri, t_s, H, W)
     _frame_vs_oracle(m, orc, a, fg, tg, t_s, flags(t_s), "4K growing bank (T_read=3, float64 memory read in the oracle)", orc64=orc64)
-    assert m.memories["frames"] == [b[2] for b in orc.bank] == [0, 1, 2, 3]
+    assert m.memories["frames"] == [b[2] for b in orc.bank] == [0, 1, 2]
 
 
 def test_4k_large_input_runs_and_is_deterministic(synth_sd):
