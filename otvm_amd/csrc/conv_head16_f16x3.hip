@@ -47,9 +47,35 @@ __device__ __forceinline__ void split4h(const f32x4 v, f16x4& hi, f16x4& lo) {
                (_Float16)(v.w - (float)h23.y)};
 }
 
+// timing probes for tools/build_variant.sh (the results are WRONG with any of them set): which part of the kernel costs what
+#ifndef OTVM_H16_NOPATCH
+#define OTVM_H16_NOPATCH 0     // no global loads of the input patch (LDS is filled from constants)
+#endif
+#ifndef OTVM_H16_NOW
+#define OTVM_H16_NOW 0         // no weight loads
+#endif
+#ifndef OTVM_H16_NOMFMA
+#define OTVM_H16_NOMFMA 0      // no fragment reads, no MFMAs
+#endif
+#ifndef OTVM_H16_NOHEAD
+#define OTVM_H16_NOHEAD 0      // no per-pixel head: alpha = the first hidden value
+#endif
+#ifndef OTVM_H16_NOSTORE
+#define OTVM_H16_NOSTORE 0     // the head is evaluated, nothing is stored but alpha
+#endif
 #ifndef OTVM_HEAD16_WGS
 #define OTVM_HEAD16_WGS 3                // workgroups per CU the register budget is set for (LDS: 3 x 54 400 B fit 160 KiB)
 #endif
+// N_OUT = 7 / 10: the head's width (its loops unrolled without run-time tests); FAST = the layer as the frame issues it --
+// LeakyReLU and a bias -- with the epilogue's constants (filter scales, bias) read as whole vectors; the generic form keeps the
+// run-time activation switch.
+// Round 5 (tools/head_bench.py, profiles/r05_head16_ablation.txt): the per-pixel head cost 67 of the launch's 174 us, and not for
+// its arithmetic -- its 170 weights were fetched by (wave-uniform) GLOBAL loads inside the epilogue, each batch waited for with
+// vmcnt(0) right where it was issued, the pixel's RGB likewise, and the sixteen filter scales / biases one s_load + wait + branch
+// each (the run-time `act` switch and `if (bias)` per element kept the compiler from batching them).  Now: every thread fetches
+// ONE of the head's weights and its pixel's RGB at the top of the kernel (the latency passes under the patch load and the tap
+// loop), the weights go through 680 bytes of LDS behind the epilogue rows and are read as broadcast ds_read_b128.
+template <int N_OUT, bool FAST>
 __global__ __launch_bounds__(256, OTVM_HEAD16_WGS) void conv_head16_f16x3_kernel(const Head16Args pa) {
     Head16Args p = pa;
     {
@@ -66,9 +92,21 @@ __global__ __launch_bounds__(256, OTVM_HEAD16_WGS) void conv_head16_f16x3_kernel
     __shared__ __attribute__((aligned(16))) _Float16 smem[PATCH_HALFS > EPI_HALFS ? PATCH_HALFS : EPI_HALFS];
     _Float16* Ph = smem;
     _Float16* Pl = smem + NPIX * LDP;
+    static_assert(EPI_HALFS + 2 * (N_OUT * 17 + 3) <= PATCH_HALFS, "the head's weights live behind the epilogue rows");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tile_x = blockIdx.x % p.tiles_x, tile_y = blockIdx.x / p.tiles_x;
     const int ty0 = tile_y * TH, tx0 = tile_x * TW;
+    // ---- what the epilogue needs from global memory, requested first: one value of the head's [N_OUT][16] weights + [N_OUT] bias
+    // per thread, and the RGB of the pixel this lane finishes (lanes 0-31: the wave's first image row, 32-63: the second)
+    const int ea = lane >> 5, epx = lane & 31;
+    const int ey = ty0 + wave * 2 + ea, ex = tx0 + epx;
+    const bool e_in = ey < p.H && ex < p.W;
+    const int64_t em = e_in ? (int64_t)ey * p.W + ex : 0;
+    float hwv = 0.f;
+    if (tid < N_OUT * 17) hwv = tid < N_OUT * 16 ? p.head.w[tid] : p.head.b[tid - N_OUT * 16];
+    float eim[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) eim[c] = p.head.img[em * p.head.img_ld + c];
 
     // ---- the input patch: 10 x 34 pixels x 32 channels, loaded and split once (zero outside the image: the conv's padding)
     constexpr int NP = (NPIX * 8 + 255) / 256;
@@ -83,8 +121,12 @@ __global__ __launch_bounds__(256, OTVM_HEAD16_WGS) void conv_head16_f16x3_kernel
         const int py = pix / PW, px = pix - py * PW;
         const int iy = ty0 - 1 + py, ix = tx0 - 1 + px;
         const unsigned oob = (unsigned)((int)((unsigned)iy < (unsigned)p.H) & (int)((unsigned)ix < (unsigned)p.W) & (int)(idx < NPIX * 8)) - 1u;
+#if OTVM_H16_NOPATCH
+        rp[k] = f32x4{(float)(idx & 7), 0.5f, -0.25f, (float)oob};
+#else
         rp[k] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(
             in_rsrc, (((unsigned)(iy * p.W + ix) * (unsigned)p.in_ld + c4) << 2) | oob, 0, 0));
+#endif
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -102,8 +144,12 @@ __global__ __launch_bounds__(256, OTVM_HEAD16_WGS) void conv_head16_f16x3_kernel
     f16x8 wh[9], wl[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
+#if OTVM_H16_NOW
+        { const _Float16 c1 = (_Float16)(float)(lane + t); wh[t] = f16x8{c1, c1, c1, c1, c1, c1, c1, c1}; wl[t] = wh[t] * (_Float16)0.001f; }
+#else
         wh[t] = *reinterpret_cast<const f16x8*>(p.wf + (t * 2 + 0) * 512 + lane * 8);
         wl[t] = *reinterpret_cast<const f16x8*>(p.wf + (t * 2 + 1) * 512 + lane * 8);
+#endif
     }
     __syncthreads();
 
@@ -119,6 +165,9 @@ __global__ __launch_bounds__(256, OTVM_HEAD16_WGS) void conv_head16_f16x3_kernel
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int t = ky * 3 + kx;
+#if OTVM_H16_NOMFMA
+            acc[0][0][0] += (float)wh[t][0] + (float)wl[t][1]; if (t) continue;
+#endif
             f16x8 ah[2][2], al[2][2];
 #pragma unroll
             for (int a = 0; a < 2; ++a)
@@ -146,36 +195,57 @@ __global__ __launch_bounds__(256, OTVM_HEAD16_WGS) void conv_head16_f16x3_kernel
     // ---- epilogue: C / D of the 16x16 tile: column (channel) = lane & 15, row (pixel) = 4 (lane >> 4) + register
     __syncthreads();                                             // every wave is done with the patch
     float* ep = reinterpret_cast<float*>(smem) + wave * (2 * 32 * EPL);
+    typedef __attribute__((address_space(3))) float lds_float;
+    float* hw_gen = reinterpret_cast<float*>(smem) + 4 * (2 * 32 * EPL);      // behind the four waves' rows
+    if (tid < N_OUT * 17) hw_gen[tid] = hwv;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ep[(a * 32 + m * 16 + 4 * (lane >> 4) + r) * EPL + (lane & 15)] = acc[a][m][r];
-    const int a = lane >> 5, px = lane & 31;
-    const int y = ty0 + wave * 2 + a, x = tx0 + px;
+    __syncthreads();                                             // the head's weights are in place (the rows are wave-private)
     float h[16];
+    if constexpr (FAST) {
+        // filter scales and bias: two wave-uniform 64-byte vectors (scalar loads, batched by the compiler), LeakyReLU inline
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(&ep[(a * 32 + px) * EPL + 4 * k]);
-        f32x4 sc4, bi4 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            sc4[j] = p.wscale[4 * k + j];
-            if (p.bias) bi4[j] = p.bias[4 * k + j];
+        for (int k = 0; k < 4; ++k) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(&ep[(ea * 32 + epx) * EPL + 4 * k]);
+            const f32x4 sc4 = *reinterpret_cast<const f32x4*>(p.wscale + 4 * k);
+            const f32x4 bi4 = *reinterpret_cast<const f32x4*>(p.bias + 4 * k);
+            v = v * sc4 + bi4;                                    // (the arithmetic of the convolutions' epilogues)
+            h[4 * k] = v.x > 0.f ? v.x : 0.01f * v.x; h[4 * k + 1] = v.y > 0.f ? v.y : 0.01f * v.y;
+            h[4 * k + 2] = v.z > 0.f ? v.z : 0.01f * v.z; h[4 * k + 3] = v.w > 0.f ? v.w : 0.01f * v.w;
         }
-        v = v * sc4 + bi4;                                        // (the arithmetic of the convolutions' epilogues)
-        h[4 * k] = otvm_act(v.x, p.act); h[4 * k + 1] = otvm_act(v.y, p.act);
-        h[4 * k + 2] = otvm_act(v.z, p.act); h[4 * k + 3] = otvm_act(v.w, p.act);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(&ep[(ea * 32 + epx) * EPL + 4 * k]);
+            f32x4 sc4, bi4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sc4[j] = p.wscale[4 * k + j];
+                if (p.bias) bi4[j] = p.bias[4 * k + j];
+            }
+            v = v * sc4 + bi4;
+            h[4 * k] = otvm_act(v.x, p.act); h[4 * k + 1] = otvm_act(v.y, p.act);
+            h[4 * k + 2] = otvm_act(v.z, p.act); h[4 * k + 3] = otvm_act(v.w, p.act);
+        }
     }
-    if (y < p.H && x < p.W) {
-        const int64_t m = (int64_t)y * p.W + x;
+    if (e_in) {
         if (p.out) {
 #pragma unroll
             for (int k = 0; k < 4; ++k)
-                *reinterpret_cast<f32x4*>(p.out + m * p.out_ld + 4 * k) = f32x4{h[4 * k], h[4 * k + 1], h[4 * k + 2], h[4 * k + 3]};
+                *reinterpret_cast<f32x4*>(p.out + em * p.out_ld + 4 * k) = f32x4{h[4 * k], h[4 * k + 1], h[4 * k + 2], h[4 * k + 3]};
         }
-        otvm_head_pixel(h, p.head, m);
+        const lds_float* hw = (const lds_float*)hw_gen;
+#if OTVM_H16_NOHEAD
+        p.head.alpha_out[em * p.head.alpha_stride] = h[0] + eim[0] + hw[3];
+#elif OTVM_H16_NOSTORE
+        { OtvmHeadArgs q = p.head; q.tri_out = nullptr; q.sm = nullptr; otvm_head_pixel_w<N_OUT, const lds_float*>(h, q, em, hw, hw + N_OUT * 16, eim); }
+#else
+        otvm_head_pixel_w<N_OUT, const lds_float*>(h, p.head, em, hw, hw + N_OUT * 16, eim);
+#endif
     }
 }
 
@@ -223,7 +293,17 @@ int otvm_conv2d_head16_impl(const otvm_conv_params* p, const otvm_head_params* h
     a.head.sm = hd->sm; a.head.sm_ld = hd->sm_ld; a.head.out7 = nullptr; a.head.logits_out = nullptr;
     a.head_img_bs = batch > 1 ? hd->img_bs : 0; a.head_alpha_bs = batch > 1 ? hd->alpha_bs : 0;
     a.head_tri_bs = batch > 1 ? hd->tri_bs : 0; a.head_sm_bs = batch > 1 ? hd->sm_bs : 0;
-    hipLaunchKernelGGL(conv_head16_f16x3_kernel, dim3(a.tiles_x * a.tiles_y, batch), dim3(256), 0, (hipStream_t)stream, a);
+    OTVM_REQUIRE(hd->n_out == 7 || hd->n_out == 10, "otvm_conv2d_head (16-wide tile): a head of 7 or 10 outputs (got %d)", hd->n_out);
+    const dim3 grid(a.tiles_x * a.tiles_y, batch);
+    hipStream_t s = (hipStream_t)stream;
+    const bool fast = p->act == OTVM_ACT_LEAKY && p->bias && ((uintptr_t)p->bias & 15) == 0 && ((uintptr_t)p->w_scale & 15) == 0;
+    if (hd->n_out == 7) {
+        if (fast) hipLaunchKernelGGL((conv_head16_f16x3_kernel<7, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_head16_f16x3_kernel<7, false>), grid, dim3(256), 0, s, a);
+    } else {
+        if (fast) hipLaunchKernelGGL((conv_head16_f16x3_kernel<10, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv_head16_f16x3_kernel<10, false>), grid, dim3(256), 0, s, a);
+    }
     OTVM_CHECK_LAUNCH("otvm_conv2d_head (16-wide tile)");
     return 0;
 }

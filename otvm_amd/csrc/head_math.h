@@ -17,9 +17,13 @@ struct OtvmHeadArgs {
 __device__ __forceinline__ float otvm_sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ float otvm_clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
 
-__device__ __forceinline__ void otvm_head_pixel(const float (&h)[16], const OtvmHeadArgs& q, int64_t i) {
+// N_OUT_T = 7 / 10: the head's width known at compile time (0: q.n_out at run time); WP = where the head's weights / bias are read
+// from -- `const float*` (global memory, wave-uniform addresses) or an LDS pointer (the 16-wide conv stages them once per
+// workgroup, round 5); im = the pixel's composited RGB, loaded by the caller (early, so that its latency is not exposed here)
+template <int N_OUT_T, typename WP>
+__device__ __forceinline__ void otvm_head_pixel_w(const float (&h)[16], const OtvmHeadArgs& q, int64_t i, WP w, WP b, const float (&im)[3]) {
 #pragma clang fp contract(off)
-    const int n_out = q.n_out;
+    const int n_out = N_OUT_T ? N_OUT_T : q.n_out;
     const int64_t P = q.P;
     float o[10];
 #pragma unroll
@@ -27,18 +31,17 @@ __device__ __forceinline__ void otvm_head_pixel(const float (&h)[16], const Otvm
         if (j < n_out) {
             float acc = 0.f;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) acc += q.w[j * 16 + k] * h[k];
-            o[j] = acc + q.b[j];
+            for (int k = 0; k < 16; ++k) acc += w[j * 16 + k] * h[k];
+            o[j] = acc + b[j];
         } else {
             o[j] = 0.f;
         }
     }
     float al = otvm_clamp01(o[0]);
-    float im[3], F[3], B[3];
+    float F[3], B[3];
     float num = 0.f, den = 0.f;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        im[c] = q.img[i * q.img_ld + c];
         const float f0 = otvm_sigmoidf(o[1 + c]), b0 = otvm_sigmoidf(o[4 + c]);
         float fn = al * im[c] + (1.f - al * al) * f0 - al * (1.f - al) * b0;
         float bn = (1.f - al) * im[c] + (2.f * al - al * al) * b0 - al * (1.f - al) * fn;
@@ -78,4 +81,9 @@ __device__ __forceinline__ void otvm_head_pixel(const float (&h)[16], const Otvm
             q.sm[i * q.sm_ld + 5] = al;                     // alpha         -> conv1_a
         }
     }
+}
+
+__device__ __forceinline__ void otvm_head_pixel(const float (&h)[16], const OtvmHeadArgs& q, int64_t i) {
+    const float im[3] = {q.img[i * q.img_ld], q.img[i * q.img_ld + 1], q.img[i * q.img_ld + 2]};
+    otvm_head_pixel_w<0, const float*>(h, q, i, q.w, q.b, im);
 }
