@@ -634,27 +634,32 @@ def test_fba_head(G):
             assert G.maxdiff(s[:, 21], al.flatten()) <= 2e-6
 
 
-@pytest.mark.parametrize("wide16", [False, True], ids=["tile32", "tile16"])
+@pytest.mark.parametrize("wide16", [False, True, "generic"], ids=["tile32", "tile16", "tile16-relu-nobias"])
 @pytest.mark.parametrize("n_out,H,W,write_hid", [(7, 40, 64, False), (7, 37, 45, True), (10, 24, 96, True), (10, 19, 33, True)])
 def test_conv_with_head_epilogue(G, n_out, H, W, write_hid, wide16):
     """otvm_conv2d_head: conv3x3 32 -> 16 + LeakyReLU with the 1x1 head + fba_fusion (+ softmax of the trimap logits) in its
     epilogue (FBA/models.py:383-388, 425-432) == otvm_conv2d followed by otvm_fba_head: the hidden state bit for bit (same
     tiles, same epilogue arithmetic), the head's outputs to fp32 rounding; interior and edge tiles, with and without the
-    hidden state written."""
+    hidden state written.  "tile16-relu-nobias": the 16-wide kernel's generic instantiation (any activation, optional bias; the frame
+    only issues LeakyReLU + bias, the compile-time fast path)."""
     from otvm_amd import lib as L
     from otvm_amd.engine import conv_params
     lib, st = L.load(), G.stream()
     P = H * W
+    generic = wide16 == "generic"
+    act = 1 if generic else 2
     x = rnd(1, 32, H, W, seed=80)
     w, b = rnd(16, 32, 3, 3, seed=81, scale=1.0 / math.sqrt(32 * 9)), rnd(16, seed=82, scale=0.2)
     hw, hb = rnd(n_out, 16, seed=83, scale=0.4).contiguous().to(G.DEV), rnd(n_out, seed=84, scale=0.3).to(G.DEV)
     img = torch.rand(1, 3, H, W, generator=torch.Generator().manual_seed(85))
     xa, ia = G.to_act(x), G.to_act(img, c_pad=4, ld=8)
     cw = G.pack_weight(w)
-    bd = b.to(G.DEV)
+    bd = None if generic else b.to(G.DEV)
+    if generic:
+        b = torch.zeros_like(b)
     # reference route
     hid0 = G.empty_act(H, W, 16, ld=24)
-    G.conv2d(xa, cw, hid0, bd, pad=1, act=2, precision=1)
+    G.conv2d(xa, cw, hid0, bd, pad=1, act=act, precision=1)
     a0 = torch.full((2 * P,), float("nan"), device=G.DEV)
     t0 = torch.full((3 * P,), float("nan"), device=G.DEV)
     sm0 = torch.zeros(P * 24, device=G.DEV)
@@ -665,7 +670,7 @@ def test_conv_with_head_epilogue(G, n_out, H, W, write_hid, wide16):
     a1 = torch.full((2 * P,), float("nan"), device=G.DEV)
     t1 = torch.full((3 * P,), float("nan"), device=G.DEV)
     sm1 = torch.zeros(P * 24, device=G.DEV)
-    p = conv_params(xa, cw, hid1, bd, 1, 1, 1, 2, 0, None, 1)
+    p = conv_params(xa, cw, hid1, bd, 1, 1, 1, act, 0, None, 1)
     if not write_hid:
         p.out, p.out_ld = 0, 0
     h = L.HeadParams()
@@ -681,7 +686,8 @@ def test_conv_with_head_epilogue(G, n_out, H, W, write_hid, wide16):
     if write_hid and not wide16:
         assert torch.equal(G.from_act(hid1), G.from_act(hid0))
     if write_hid:
-        ref = F.leaky_relu(F.conv2d(x.double(), w.double(), b.double(), padding=1), 0.01).float()
+        ref = F.conv2d(x.double(), w.double(), b.double(), padding=1)
+        ref = (torch.relu(ref) if generic else F.leaky_relu(ref, 0.01)).float()
         assert G.maxdiff(G.from_act(hid1), ref) <= 2e-5 * max(1.0, float(ref.abs().max()))
     assert G.maxdiff(a1[::2].cpu(), a0[::2].cpu()) <= (1e-6 if not wide16 else 2e-5)
     if n_out == 10:
