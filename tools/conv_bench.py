@@ -36,6 +36,8 @@ def main():
     ap.add_argument("--gn", type=int, default=0, help="fused GroupNorm statistics in the epilogue")
     ap.add_argument("--bias", type=int, default=0)
     ap.add_argument("--pad-ld", type=int, default=0, help="extra floats per pixel row of the input / output / residual views (ld = C + pad)")
+    ap.add_argument("--zero", type=int, default=0, help="power probe: 1 = all-zero input, 2 = all-zero weights, 3 = both (the matrix cores' "
+                                                        "power depends on the operands; times only)")
     ap.add_argument("--tune", default="0", help="otvm_conv_params.tune codes to time, comma separated; 'all' = every candidate")
     args = ap.parse_args()
     shapes = [tuple(int(v) for v in s.split(",")) for s in args.shape] if args.shape else DEFAULT
@@ -47,6 +49,10 @@ def main():
         pl = args.pad_ld
         x = Act(torch.randn(H * W * (Cin + pl), device=dev), H, W, Cin, Cin + pl)
         w = torch.randn(Cout, Cin, k, k, device=dev) / math.sqrt(Cin * k * k)
+        if args.zero & 1:
+            x.t.zero_()
+        if args.zero & 2:
+            w.zero_()
         cw = pack_conv_weight(lib, dev, w, split=True, stream=st)
         if cw.w_wfrag is None and cw.I_pad % 32 == 0 and k * k <= 32:       # narrow layers: the one-wave tile's copy, for --tune all
             O_pad = cw.w_hi.numel() // cw.K_pad
