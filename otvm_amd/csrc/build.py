@@ -15,6 +15,7 @@ SOURCES = [
     ("conv_igemm.hip", []),
     ("conv_f16x3.hip", []),
     ("conv_f16x3_glds.hip", []),
+    ("conv_f16x3_m16.hip", []),
     ("conv_f16x3_p1.hip", []),
     ("conv_f16x3_p1g.hip", []),
     ("conv_patch_f16x3.hip", []),

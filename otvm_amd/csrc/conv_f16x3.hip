@@ -409,15 +409,18 @@ int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream);    //
 enum { T256x256 = 0, T256x128, T128x128, T128x64, T64x64, T256x64, T256x32, T256x128W4, T128x256W4, T64x64W1, T64x64D, T128x64D,
        T_STEM = 12, T256x256W4 = 13, T_PATCH = 14, T_COUNT = 15,
        // round 5: tile t with LDS-DMA weight stages = T_GLDS + t (conv_f16x3_glds.hip; see the kernel's GLDS comment)
-       T_GLDS = 32 };
+       T_GLDS = 32,
+       // ... and T_M16 + t: the LDS-DMA tile t multiplying with v_mfma_f32_16x16x32_f16 (conv_f16x3_m16.hip; the kernel's M16 comment)
+       T_M16 = 64 };
 static inline int tune_code(int tile, int S) { return (tile + 1) * 16 + S; }
-static inline bool is_glds_tile(int t) {
-    const int b = t - T_GLDS;
+static inline bool is_m16_tile(int t) { return t >= T_M16 && t < T_M16 + T_STEM; }
+static inline bool is_glds_tile(int t) {                    // (either matrix-core form)
+    const int b = t - (is_m16_tile(t) ? T_M16 : T_GLDS);
     return b == T256x256 || b == T256x128 || b == T128x128 || b == T128x64 || b == T64x64 || b == T256x64 || b == T256x32 ||
            b == T256x128W4 || b == T128x256W4 || b == T64x64D || b == T128x64D;
 }
 static inline bool is_gemm_tile(int t) { return (t >= 0 && t < T_STEM) || t == T256x256W4 || is_glds_tile(t); }
-static inline int base_tile(int t) { return is_glds_tile(t) ? t - T_GLDS : t; }
+static inline int base_tile(int t) { return is_glds_tile(t) ? t - (is_m16_tile(t) ? T_M16 : T_GLDS) : t; }
 static const int TILE_BM_[T_COUNT] = {256, 256, 128, 128, 64, 256, 256, 256, 128, 64, 64, 128, 0, 256, 0};
 static const int TILE_BN_[T_COUNT] = {256, 128, 128, 64, 64, 64, 32, 128, 256, 64, 64, 64, 0, 256, 0};
 static inline int TILE_BM(int t) { return TILE_BM_[base_tile(t)]; }
@@ -464,7 +467,7 @@ static int launch_tile(int tile, Conv3Args& a, hipStream_t s, int S) {
         // nothing to overlap its own fragment reads with.  Kept as a forced configuration (tune code 225), not a candidate.
         case T256x256W4: return launch3<256, 256, 2, 2, false, true>(a, s, S);
     }
-    if (is_glds_tile(tile)) return otvm_launch_glds_tile(tile - T_GLDS, a, s, S);
+    if (is_glds_tile(tile)) return is_m16_tile(tile) ? otvm_launch_m16_tile(tile - T_M16, a, s, S) : otvm_launch_glds_tile(tile - T_GLDS, a, s, S);
     otvm_set_error("otvm_conv2d(f16x3): unknown tile %d", tile);
     return 1;
 }
@@ -486,7 +489,7 @@ static bool config_ok(const otvm_conv_params* p, int tile, int S) {
     if ((bt == T64x64D || bt == T128x64D) && !f16x3_fast_layout(p->kh * p->kw, p->Cin)) return false;
     if (tile == T64x64W1 && !(p->w_wfrag && f16x3_fast_layout(p->kh * p->kw, p->Cin) && (p->in_ld & 3) == 0)) return false;
     if (tile == T64x64W1 && p->res_scale) return false;           // (the one-wave tile's epilogue has no residual scale)
-    if (p->precision == OTVM_PREC_F16 && (tile == T64x64W1 || tile == T256x256W4)) return false;   // (no single-pass form)
+    if (p->precision == OTVM_PREC_F16 && (tile == T64x64W1 || tile == T256x256W4 || is_m16_tile(tile))) return false;   // (no single-pass form)
     // LDS-DMA weight stages: fragment-major weights, whole chunks, the input view inside a 2-GiB buffer resource
     if (is_glds_tile(tile) && !(p->w_wfrag && f16x3_fast_layout(p->kh * p->kw, p->Cin) && (p->in_ld & 3) == 0 &&
                                 (int64_t)p->H * p->W * p->in_ld * 4 < (1ll << 31))) return false;
@@ -535,6 +538,18 @@ static int glds_mode() {
     static const int m = getenv("OTVM_IGEMM_GLDS") ? atoi(getenv("OTVM_IGEMM_GLDS")) : 1;
     return m;
 }
+// the 16x16x32 form of the LDS-DMA tiles: 2 (default) = instead of the 32x32x16 form everywhere; 1 = offered to the tuner next to
+// the 32x32x16 form and taken by the heuristic on maps of >= OTVM_IGEMM_M16_MIN_PIXELS output pixels; 0 = never (A/B runs).
+// Whole frame, one box, alternating (profiles/r05_igemm_mfma16_ab.txt): 1080p 47.51 (2) / 47.36 (1) / 46.51 (0) frames/s,
+// 832x480 153.2 / 153.2 / 153.3
+static int m16_mode() {
+    static const int m = getenv("OTVM_IGEMM_M16") ? atoi(getenv("OTVM_IGEMM_M16")) : 2;
+    return m;
+}
+static int64_t m16_min_pixels() {
+    static const int64_t v = getenv("OTVM_IGEMM_M16_MIN_PIXELS") ? atoll(getenv("OTVM_IGEMM_M16_MIN_PIXELS")) : 16384;
+    return v;
+}
 
 extern "C" int otvm_conv2d_candidates(const otvm_conv_params* p, int* out, int max_n) {
     int n = 0;
@@ -564,7 +579,9 @@ extern "C" int otvm_conv2d_candidates(const otvm_conv_params* p, int* out, int m
             // the tile's LDS-DMA form, where it exists and the layer qualifies (fragment-major weights, whole chunks), REPLACES the
             // register-staged form in the list (OTVM_IGEMM_GLDS=2 offers both, 0 the staged form only: A/B runs)
             const bool g_ok = glds_mode() != 0 && is_glds_tile(T_GLDS + t) && config_ok(p, T_GLDS + t, S);
-            if (g_ok) add(tune_code(T_GLDS + t, S));
+            const bool m_ok = g_ok && m16_mode() != 0 && config_ok(p, T_M16 + t, S);
+            if (g_ok && !(m_ok && m16_mode() == 2)) add(tune_code(T_GLDS + t, S));
+            if (m_ok) add(tune_code(T_M16 + t, S));
             if ((!g_ok || glds_mode() == 2) && config_ok(p, t, S)) add(tune_code(t, S));
         }
     }
@@ -643,11 +660,12 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
         if (p->gn_stats && a.nchunks < 256 && tiles > 8) S = 1;
         const int tk = wide ? T128x128 : T128x64;
         while (S >= 2 && !config_ok(p, tk, S)) --S;
-        if (tiles < 192 && S >= 2) return run_config(p, a, glds_mode() && config_ok(p, T_GLDS + tk, S) ? T_GLDS + tk : tk, S, s);
+        if (tiles < 192 && S >= 2) return run_config(p, a, glds_mode() && config_ok(p, T_GLDS + tk, S) ? (m16_mode() == 2 && config_ok(p, T_M16 + tk, S) ? T_M16 : T_GLDS) + tk : tk, S, s);
     }
     // round 5: every tile in its LDS-DMA form wherever that is legal (OTVM_IGEMM_GLDS=0: the register-staged forms, for A/B runs)
     const int use_glds = glds_mode();
-    auto pick = [&](int t) { return use_glds && config_ok(p, T_GLDS + t, 1) ? T_GLDS + t : t; };
+    const bool use_m16 = m16_mode() == 2 || (m16_mode() == 1 && M >= m16_min_pixels());
+    auto pick = [&](int t) { return use_glds && config_ok(p, T_GLDS + t, 1) ? (use_m16 && config_ok(p, T_M16 + t, 1) ? T_M16 : T_GLDS) + t : t; };
     if (p->Cout <= 32) return launch_tile(pick(T256x32), a, s, 1);
     if (p->Cout <= 64) return launch_tile(pick((M >= 256 * 128) ? T256x64 : T64x64), a, s, 1);
     // Tile choice by workgroup count (thresholds tuned on the whole 1080p frame after the 256-row tiles got their

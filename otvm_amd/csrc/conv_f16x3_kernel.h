@@ -79,6 +79,8 @@ struct Conv3Args {
 
 // conv_f16x3_glds.hip: the LDS-DMA form of implicit-GEMM tile `base` (the enum of conv_f16x3.hip), K split over S workgroups
 int otvm_launch_glds_tile(int base, Conv3Args& a, hipStream_t s, int S);
+// conv_f16x3_m16.hip: the LDS-DMA tile `base` on v_mfma_f32_16x16x32_f16 (M16)
+int otvm_launch_m16_tile(int base, Conv3Args& a, hipStream_t s, int S);
 // conv_f16x3_p1.hip: the single-pass ("f16") form of tile `tile` (register-staged t or LDS-DMA 32 + t)
 int otvm_launch_tile_p1(int tile, Conv3Args& a, hipStream_t s, int S);
 
@@ -119,7 +121,8 @@ __device__ __forceinline__ void split4(const f32x4 v, f16x4& hi, f16x4& lo) {
 // NPASS (round 5): 3 = the f16x3 operand split (fp32-class results).  1 = precision "f16", a LABELLED reduced-precision mode
 // (BASELINE configs[2] as written: "bf16 MFMA conv"): operands rounded to fp16 once (round to nearest), ONE MFMA pass, fp32
 // accumulate; the lo halves are neither computed, staged nor read.  Not the default and not parity-graded.
-template <int BM, int BN, int WM, int WN, bool FAST, bool RELU_IN, bool DB = false, bool NORM_IN = false, bool GLDS = false, int NPASS = 3>
+template <int BM, int BN, int WM, int WN, bool FAST, bool RELU_IN, bool DB = false, bool NORM_IN = false, bool GLDS = false, int NPASS = 3,
+          bool M16T = false>
 __global__ __launch_bounds__(WM* WN * 64)
 __attribute__((amdgpu_waves_per_eu((BM * BN == 32768 && WM * WN == 4) ? 2 : 1, (BM * BN == 32768 && WM * WN == 4) ? 2 : 10)))
 void conv_igemm_f16x3_kernel(const Conv3Args pa) {
@@ -153,6 +156,20 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
     // LDS work issue under its own MFMAs.
     constexpr bool DBUF = DB || (BM == 256 && BN >= 128 && WM * WN == 8) || (BM == 256 && BN == 256);   // (the 4-wave 256x128 / 128x256 tiles: one stage, two workgroups per CU)
     static_assert(!GLDS || FAST, "LDS-DMA weight stages: whole-chunk layers");
+    // M16 (round 5): the matrix cores of this part do ~10 % more work per joule with v_mfma_f32_16x16x32_f16 than with
+    // v_mfma_f32_32x32x16_f16 (tools/probes/mfma_variants_probe.hip: 1800 vs 1615-1665 TFLOP/s f16 sustained under the power
+    // limit, random operands; a quarter of the accumulator read-modify-write per FLOP), and the frame's launches are bound by that
+    // limit (profiles/r05_zero_operand_power_probe.txt).  The M16 form of an LDS-DMA tile (tile 64 + t, conv_f16x3_m16.hip; a
+    // candidate of its own for the plan-time tuner: it wins on the maps that keep the chip at its power limit, -2 ... -10 % per
+    // launch, and loses on small maps, where its extra fragment reads are not free) multiplies a 32-deep chunk with 16x16x32
+    // instructions: a 32x32 accumulator tile is four 16x16 sub-tiles (quad q = 2 si + sj of its sixteen registers: rows
+    // 16 si + 4 (lane >> 4) + r, columns 16 sj + (lane & 15)); the two "halves" of a chunk that the K loop interleaves with the
+    // staging are the column halves sj = 0 / 1 instead of the two k-steps.  Neither stage layout changes: an A fragment is row
+    // 16 t + (lane & 15), k-octet lane >> 4 of the [row][32 + 8] stage; a B fragment is ONE ds_read_b128 across the k-step 0 and
+    // k-step 1 blocks of the fragment-major weights (lanes 0-31 read the first block, 32-63 the second, slot
+    // (lane & 15) + 16 sj + 32 ((lane >> 4) & 1): filter 16 sj + (lane & 15), k-octet lane >> 4 -- conflict-free).
+    constexpr bool M16 = M16T;
+    static_assert(!M16T || (GLDS && NPASS == 3), "the 16x16x32 form exists for the f16x3 LDS-DMA tiles");
     // LDS: two-stage tiles [A0 | B0 | A1 | B1]; single-stage GLDS tiles [A | B0 | B1] -- their weight copy of chunk c + 1 runs
     // while chunk c is multiplied, so the B stage alone is doubled (BN * 128 bytes more)
     constexpr int BST = BN * 64;                               // halfs of one GLDS weight stage
@@ -389,8 +406,12 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
             if (!GLDS || NORM_IN) v = (okmask >> i) & 1u ? v : z;      // (GLDS: a padding lane was loaded as zeros; the normalisation moves them)
             if constexpr (NPASS == 3) {
                 split4(v, hi, lo);
-                *reinterpret_cast<f16x4*>(&Ah[(arow + A_ROWS * i) * LDH + ak]) = hi;
-                *reinterpret_cast<f16x4*>(&Al[(arow + A_ROWS * i) * LDH + ak]) = lo;
+                // M16: k-octet o of row r sits at octet o ^ f(r), f = bit 2 ^ bit 3 of r: with the plain layout the 16x16x32
+                // A fragment (row lane & 15, octet lane >> 4, 80-byte rows) is a 2-way bank conflict in every lane group
+                const int row = arow + A_ROWS * i;
+                const int akx = M16 ? (ak ^ ((((row >> 2) ^ (row >> 3)) & 1) << 3)) : ak;
+                *reinterpret_cast<f16x4*>(&Ah[row * LDH + akx]) = hi;
+                *reinterpret_cast<f16x4*>(&Al[row * LDH + akx]) = lo;
             } else {
                 hi = f16x4{(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};        // round to nearest
                 *reinterpret_cast<f16x4*>(&Ah[(arow + A_ROWS * i) * LDH + ak]) = hi;
@@ -411,6 +432,43 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
         const _Float16* Al = Ah + BM * LDH;
         const _Float16* Bh = b_stage(buf, bbuf < 0 ? buf : bbuf);
         const _Float16* Bl = Bh + BN * LDH;
+        if constexpr (M16) {
+            const int sj = ks, l15 = lane & 15, oct = lane >> 4;
+            f16x8 bh[TN], bl[TN];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                const int o = (((wn * TN + b) * 2 + (lane >> 5)) * 2) * 512 + (l15 + 16 * sj + 32 * (oct & 1)) * 8;
+                bh[b] = *reinterpret_cast<const f16x8*>(&Bh[o]);
+                bl[b] = *reinterpret_cast<const f16x8*>(&Bh[o + 512]);
+            }
+            auto quad = [](const f32x16& c, int q) __attribute__((always_inline)) { return f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]}; };
+            auto put = [](f32x16& c, int q, const f32x4 v) __attribute__((always_inline)) { c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w; };
+#pragma unroll
+            for (int si = 0; si < 2; ++si) {
+                f16x8 ah[TM], al[TM];
+#pragma unroll
+                for (int a = 0; a < TM; ++a) {
+                    const int o = ((wm * TM + a) * 32 + 16 * si + l15) * LDH + 8 * (oct ^ (((l15 >> 2) ^ (l15 >> 3)) & 1));
+                    ah[a] = *reinterpret_cast<const f16x8*>(&Ah[o]);
+                    al[a] = *reinterpret_cast<const f16x8*>(&Al[o]);
+                }
+                const int q = 2 * si + sj;
+                // three passes over the TM x TN sub-tiles: consecutive MFMAs never share an accumulator
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) put(acc[a][b], q, __builtin_amdgcn_mfma_f32_16x16x32_f16(al[a], bh[b], quad(acc[a][b], q), 0, 0, 0));
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) put(acc[a][b], q, __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bl[b], quad(acc[a][b], q), 0, 0, 0));
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b) put(acc[a][b], q, __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[a], bh[b], quad(acc[a][b], q), 0, 0, 0));
+            }
+            return;
+        }
         const int frow = lane & 31, fk = (lane >> 5) * 8;
         f16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #if OTVM_ABL_NOLDSRD
@@ -587,6 +645,11 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
     }
 
     const int col = lane & 31, rbase = (lane >> 5) * 4;
+    // where accumulator register e of a 32x32 tile sits inside the tile (M16: four 16x16 sub-tiles, see above)
+    auto acc_row = [&](int e) __attribute__((always_inline)) -> int {
+        return M16 ? 16 * (e >> 3) + 4 * (lane >> 4) + (e & 3) : (e & 3) + 8 * (e >> 2) + rbase;
+    };
+    auto acc_col = [&](int e) __attribute__((always_inline)) -> int { return M16 ? 16 * ((e >> 2) & 1) + (lane & 15) : col; };
     // ---- epilogue.  Each 32x32 accumulator tile goes through a wave-private LDS patch (144-byte rows) so that it
     // leaves as 16-byte row-major accesses: 4 store instructions per tile instead of 16, and bias / residual are
     // read as float4.  (With scalar accesses the residual read alone ran at 0.7 TB/s on the K=64 layers.)
@@ -651,7 +714,7 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) rres[r4] = rnext[r4];
 #pragma unroll
-                for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
+                for (int e = 0; e < 16; ++e) patch[acc_row(e) * 36 + acc_col(e)] = acc[a][b][e];
                 if (RES && t + 1 < TM * TN) load_res(t + 1, rnext);
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
@@ -701,7 +764,7 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
                     }
                 }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
+                for (int e = 0; e < 16; ++e) patch[acc_row(e) * 36 + acc_col(e)] = acc[a][b][e];
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int row = r4 * 8 + prow;
@@ -751,6 +814,65 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
         const int seg = cg < 32 ? cg : 32;                  // lanes of one 32-column tile that share a group
         for (int i = threadIdx.x; i < 2 * BN; i += blockDim.x) gred[i] = 0.0;
         __syncthreads();
+        if constexpr (M16) {
+            // a lane owns two columns of a 32-column tile (sj = 0 / 1) and four rows of each of its 16-row halves; the lanes
+            // that share a column are lane ^ 16, lane ^ 32, lane ^ 48
+#pragma unroll
+            for (int b = 0; b < TN; ++b) {
+                float s2[2], ss2[2];
+#pragma unroll
+                for (int sj = 0; sj < 2; ++sj) {
+                    const int n = n0 + (wn * TN + b) * 32 + 16 * sj + (lane & 15);
+                    float s = 0.f, ss = 0.f;
+                    if (n < p.Cout) {
+                        const float sc_ = p.wscale[n];
+                        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+                        for (int a = 0; a < TM; ++a)
+#pragma unroll
+                            for (int si = 0; si < 2; ++si)
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const int m = m0 + (wm * TM + a) * 32 + 16 * si + 4 * (lane >> 4) + r;
+                                    if (m < p.M) {
+                                        const float v = acc[a][b][4 * (2 * si + sj) + r] * sc_ + bias;
+                                        s += v;
+                                        ss += v * v;
+                                    }
+                                }
+                    }
+                    s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
+                    s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+                    s2[sj] = s; ss2[sj] = ss;
+                }
+                if (seg == 32) {                                // the tile's 32 columns lie in one group
+                    float s = s2[0] + s2[1], ss = ss2[0] + ss2[1];
+                    for (int off = 1; off < 16; off <<= 1) {
+                        s += __shfl_xor(s, off);
+                        ss += __shfl_xor(ss, off);
+                    }
+                    const int nl = (wn * TN + b) * 32;
+                    if (lane == 0 && n0 + nl < p.Cout) {
+                        atomicAdd(&gred[2 * (nl / cg)], (double)s);
+                        atomicAdd(&gred[2 * (nl / cg) + 1], (double)ss);
+                    }
+                } else {                                        // seg = cg <= 16 consecutive columns per group
+#pragma unroll
+                    for (int sj = 0; sj < 2; ++sj) {
+                        float s = s2[sj], ss = ss2[sj];
+                        for (int off = 1; off < seg; off <<= 1) {
+                            s += __shfl_xor(s, off);
+                            ss += __shfl_xor(ss, off);
+                        }
+                        const int nl = (wn * TN + b) * 32 + 16 * sj + (lane & 15);
+                        if (lane < 16 && (lane & (seg - 1)) == 0 && n0 + nl < p.Cout) {
+                            atomicAdd(&gred[2 * (nl / cg)], (double)s);
+                            atomicAdd(&gred[2 * (nl / cg) + 1], (double)ss);
+                        }
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int nl = (wn * TN + b) * 32 + col;        // column inside the tile
@@ -795,7 +917,7 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
 }
 
 // FAST_ONLY: tiles that config_ok() only offers to whole-chunk layers do not instantiate the generic-decode kernels
-template <int BM, int BN, int WM, int WN, bool DB = false, bool FAST_ONLY = false, bool GLDS = false, int NPASS = 3>
+template <int BM, int BN, int WM, int WN, bool DB = false, bool FAST_ONLY = false, bool GLDS = false, int NPASS = 3, bool M16T = false>
 int launch3(Conv3Args& a, hipStream_t s, int ksplit = 1) {
     a.tiles_m = otvm_ceil_div(a.M, BM);
     a.tiles_n = otvm_ceil_div(a.Cout, BN);
@@ -820,9 +942,9 @@ int launch3(Conv3Args& a, hipStream_t s, int ksplit = 1) {
         a.in_bytes = (unsigned)bytes;
     }
     if (fast) {
-        if (a.in_scale) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, false, DB, true, GLDS, NPASS>), grid, block, 0, s, a);
-        else if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, true, DB, false, GLDS, NPASS>), grid, block, 0, s, a);
-        else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, false, DB, false, GLDS, NPASS>), grid, block, 0, s, a);
+        if (a.in_scale) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, false, DB, true, GLDS, NPASS, M16T>), grid, block, 0, s, a);
+        else if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, true, DB, false, GLDS, NPASS, M16T>), grid, block, 0, s, a);
+        else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, true, false, DB, false, GLDS, NPASS, M16T>), grid, block, 0, s, a);
     } else if constexpr (!DB && !FAST_ONLY) {
         if (a.in_relu) hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, true, false, false, false, NPASS>), grid, block, 0, s, a);
         else hipLaunchKernelGGL((conv_igemm_f16x3_kernel<BM, BN, WM, WN, false, false, false, false, false, NPASS>), grid, block, 0, s, a);

@@ -1067,12 +1067,12 @@ class FramePlan:
         if not (AUTOTUNE and self.e.precision == L.PREC_F16X3):
             return
         stream = torch.cuda.current_stream(self.dev).cuda_stream
-        codes = (C.c_int * 64)()
+        codes = (C.c_int * 128)()
         timed_any = False
         for p, name in convs:
             sig = self._signature(p)
             if sig not in _TUNE_CACHE:
-                n = int(self.lib.otvm_conv2d_candidates(C.byref(p), codes, 64))
+                n = int(self.lib.otvm_conv2d_candidates(C.byref(p), codes, 128))
                 cands = [0] + [int(codes[i]) for i in range(n)]           # 0 = the built-in heuristic, the incumbent
                 if not WAVE_TILE:                                         # (the fragment-major weights alone do not switch the one-wave tile on)
                     cands = [c for c in cands if c // 16 - 1 != 9]

@@ -70,13 +70,14 @@ def main():
         ws = torch.empty(16 << 20, device=dev)
         p.splitk_ws, p.splitk_ws_bytes = ws.data_ptr(), ws.numel() * 4
         if args.tune == "all":
-            codes = (C.c_int * 64)()
-            n = int(lib.otvm_conv2d_candidates(C.byref(p), codes, 64))
+            codes = (C.c_int * 128)()
+            n = int(lib.otvm_conv2d_candidates(C.byref(p), codes, 128))
             tunes = [0] + [int(codes[i]) for i in range(n)]
         else:
             tunes = [int(v) for v in args.tune.split(",")]
         names = {0: "256x256", 1: "256x128", 2: "128x128", 3: "128x64", 4: "64x64", 5: "256x64", 6: "256x32", 7: "256x128w4", 8: "128x256w4", 9: "wave64", 10: "64x64D", 11: "128x64D", 12: "stem", 13: "256x256w4", 14: "patch"}
         names.update({32 + t: n + "G" for t, n in list(names.items()) if t in (0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11)})     # LDS-DMA weight stages
+        names.update({64 + t: n + "M" for t, n in list(names.items()) if t in (0, 1, 2, 3, 4, 5, 6, 7, 8, 10, 11)})     # ... on 16x16x32 MFMAs
         for tune in tunes:
             p.tune = tune
             for _ in range(3):

@@ -52,7 +52,7 @@ def main():
     pl = eng.last_plan
     lib = L.load()
     st = torch.cuda.current_stream().cuda_stream
-    codes = (C.c_int * 64)()
+    codes = (C.c_int * 128)()
     bad = n_cfg = 0
     worst, zero_refs = 0.0, 0
     stats_scratch = torch.zeros(64, dtype=torch.float64, device=dev)
@@ -60,7 +60,7 @@ def main():
         Ho, Wo, ld = int(p.Ho), int(p.Wo), int(p.out_ld)
         # the plan buffer may be a channel slice of a wider one: rows of out_ld floats, the first Cout columns are compared
         ptr = int(p.out)
-        n = int(lib.otvm_conv2d_candidates(C.byref(p), codes, 64))
+        n = int(lib.otvm_conv2d_candidates(C.byref(p), codes, 128))
         cands = [0] + [int(codes[i]) for i in range(n)]
         keep_tune, keep_stats, keep_tab = int(p.tune), p.gn_stats, p.gn_scale_out
         if p.gn_stats:
