@@ -42,6 +42,9 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #ifndef OTVM_PABL_NOEPI
 #define OTVM_PABL_NOEPI 0      // no output stores / residual loads
 #endif
+#ifndef OTVM_PM16_NOKXP
+#define OTVM_PM16_NOKXP 0      // (A/B build, results right) M16 tiles: taps paired (t, t + 1) on every dilation
+#endif
 
 namespace {
 
@@ -79,14 +82,34 @@ __device__ __forceinline__ void split4p(const f32x4 v, f16x4& hi, f16x4& lo) {
                (_Float16)(v.w - (float)h23.y)};
 }
 
+// M16: MFMA row r of a 16-pixel A fragment holds pixel pi16(r) of its 16-pixel run (see the kernel's M16 comment): rows
+// {0-3, 12-15} <-> pixels = 0, 1 mod 4; rows 4-11 <-> pixels = 2, 3 mod 4
+__device__ __forceinline__ int pi16(int r) {
+    const int k = (r < 4) ? r : (r < 12 ? r - 4 : r - 8);          // index inside the row's class (0 ... 7)
+    return 4 * (k >> 1) + (k & 1) + ((r >= 4 && r < 12) ? 2 : 0);
+}
+
 // Per stage (16 input channels) a workgroup holds in LDS the split input patch and, per group of TAPG taps, the B
 // fragments of its BN output channels, copied verbatim from the fragment-major weight array (1-KiB blocks).
 // TAPG = 9: one weight stage per channel stage (narrow layers); TAPG = 3: wide layers (BN = 256), where nine taps of
 // weights (144 KiB) would not fit beside the patch.
 // NPASS = 1: precision "f16" (one MFMA pass on fp16-rounded operands; conv_f16x3_kernel.h has the definition of the mode)
-template <int TH, int BN, int NW, int DIL, int TAPG, bool INRES = false, bool HEAD = false, int NWN = 1, bool GLDS = false, int NPASS = 3>
+// M16 (round 5): the nine-tap tiles on v_mfma_f32_16x16x32_f16 -- the instruction does ~10 % more work per joule than
+// v_mfma_f32_32x32x16_f16 under this chip's power limit (profiles/r05_igemm_mfma16_ab.txt) and these launches are bound by it.
+// A stage still holds 16 input channels, so the K = 32 of one instruction is filled with TWO of the stage's 27 (tap, pass)
+// products: lanes 0-31 (k-octets 0, 1) carry one, lanes 32-63 (k-octets 2, 3) the other.  Taps 0 ... 7 go as four pairs
+// (t, t') x {lo.hi, hi.lo, hi.hi}; tap 8 as [hi | lo] x [hi | hi] (hi.hi + lo.hi) and [hi | lo] x [lo | 0] (hi.lo): 14 instructions'
+// worth of K for 13.5 (3.7 % idle).  A 32 x 32 accumulator tile is four 16 x 16 sub-tiles (registers 4 q ... 4 q + 3 of quad
+// q = 2 si + sj: pixel 16 si + PI(4 (lane >> 4) + j), channel 16 sj + (lane & 15)).  The patch lies PLANAR in LDS,
+// [hi | lo][k-octet][pixel] x 16 bytes (no padding: 64 instead of 96 bytes per pixel), the octet planes 64 bytes apart mod 256:
+// with the row permutation PI (rows {0-3, 12-15} <-> pixels {0, 1, 4, 5, 8, 9, 12, 13}) every lane group of a ds_read_b128 A
+// fragment ({0-3, 12-15, 20-27}, ...: rows {0-3, 12-15} of one octet + rows 4-11 of the other) covers sixteen distinct 16-byte
+// bank slots for ANY tap offset, and the staging ds_write_b64 (four pixels x four quads per 16 lanes) is conflict-free too.
+// B fragments come from the unchanged 1-KiB blocks: slot (lane & 15) + 16 sj + 32 (octet & 1) of tap t or t + 1.
+template <int TH, int BN, int NW, int DIL, int TAPG, bool INRES = false, bool HEAD = false, int NWN = 1, bool GLDS = false, int NPASS = 3,
+          bool M16 = false>
 __global__ __launch_bounds__(NW * 64)
-__attribute__((amdgpu_waves_per_eu((TAPG == 3 && BN <= 32 && !INRES) ? 3 : 1, (TAPG == 3 && BN <= 32 && !INRES) ? 3 : 10)))
+__attribute__((amdgpu_waves_per_eu((TAPG == 3 && BN <= 32 && !INRES) ? 3 : (M16 ? 2 : 1), (TAPG == 3 && BN <= 32 && !INRES) ? 3 : 10)))
 void conv_patch_f16x3_kernel(const PatchArgs pa) {
     PatchArgs p = pa;
     {
@@ -115,7 +138,9 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     constexpr int PW = 32 + 2 * DIL, PH = TH + 2 * DIL, NPIX = PH * PW;
     constexpr int NG = 9 / TAPG;
     static_assert(BN % 32 == 0 && 9 % TAPG == 0, "bad tile");
-    constexpr int PATCH_HALFS = 2 * NPIX * LDP;                        // hi + lo
+    static_assert(!M16 || (TAPG == 9 && NPASS == 3 && !HEAD && NWN == 1 && !GLDS), "the 16x16x32 form: nine-tap f16x3 tiles");
+    constexpr int PLANE = ((NPIX + 11) / 16) * 16 + 4;                 // M16: pixels per octet plane, = 4 mod 16 (>= NPIX)
+    constexpr int PATCH_HALFS = M16 ? 2 * 2 * PLANE * 8 : 2 * NPIX * LDP;   // hi + lo
     constexpr int B_PIECES = TAPG * TNW * 2 * 64;                      // 16-byte pieces of one weight stage
     constexpr int B_HALFS = B_PIECES * 8;
     constexpr int EPI_HALFS = NW * 32 * 36 * 2 * (HEAD ? 2 : 1);       // epilogue patches (fp32) expressed in halfs
@@ -129,7 +154,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     constexpr int SM_HALFS = PATCH_HALFS + NBUF * B_HALFS > EPI_HALFS ? PATCH_HALFS + NBUF * B_HALFS : EPI_HALFS;
     __shared__ __attribute__((aligned(16))) _Float16 smem[SM_HALFS];
     _Float16* Ph = smem;
-    _Float16* Pl = smem + NPIX * LDP;
+    _Float16* Pl = smem + (M16 ? 2 * PLANE * 8 : NPIX * LDP);
     _Float16* Bs = smem + PATCH_HALFS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -254,7 +279,12 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                     }
                     f16x4 hi, lo;
                     const int pix = idx >> 2, c4 = (idx & 3) * 4;
-                    if constexpr (NPASS == 3) {
+                    if constexpr (M16) {
+                        split4p(v, hi, lo);
+                        const int o = (((idx >> 1) & 1) * PLANE + pix) * 8 + (idx & 1) * 4;     // [octet][pixel][8 halfs]
+                        *reinterpret_cast<f16x4*>(&Ph[o]) = hi;
+                        *reinterpret_cast<f16x4*>(&Pl[o]) = lo;
+                    } else if constexpr (NPASS == 3) {
                         split4p(v, hi, lo);
                         *reinterpret_cast<f16x4*>(&Ph[pix * LDP + c4]) = hi;
                         *reinterpret_cast<f16x4*>(&Pl[pix * LDP + c4]) = lo;
@@ -292,6 +322,77 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
             // fragments in registers, every patch row of the column read once and used for all (output row, ky) pairs: a
             // third of the LDS fragment reads per MFMA with 4 rows per wave -- 64->64 at 1088x1920 0.543 vs 0.526 ms,
             // 64->32 0.300 vs 0.304, 320->64 at 544x960 0.591 vs 0.520: the kernel is not bound by LDS fragment reads)
+            if constexpr (M16) {
+                const int l15 = lane & 15, oct = (lane >> 4) & 1, hs = lane >> 5;
+                const int abase = (oct * PLANE + wave_m * TM * PW + pi16(l15)) * 8;
+                const int bbase = (l15 + 32 * oct) * 8;
+                auto quad = [](const f32x16& c, int q) __attribute__((always_inline)) { return f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]}; };
+                auto put = [](f32x16& c, int q, const f32x4 v) __attribute__((always_inline)) { c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w; };
+                // one K = 32 pass over the wave's TM x TN tiles: 4 TM TN instructions on as many accumulator quads
+                auto pass = [&](const f16x8 (&A)[TM][2], const f16x8 (&B)[TN][2]) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int b = 0; b < TN; ++b)
+#pragma unroll
+                            for (int si = 0; si < 2; ++si)
+#pragma unroll
+                                for (int sj = 0; sj < 2; ++sj)
+                                    put(acc[a][b], 2 * si + sj, __builtin_amdgcn_mfma_f32_16x16x32_f16(A[a][si], B[b][sj], quad(acc[a][b], 2 * si + sj), 0, 0, 0));
+                };
+                constexpr int TAPB = TNW * 2 * 512;                         // halfs of one tap's weight blocks
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    // pairs (kx 0, ky) + (kx 1, ky) for ky = 0, 1, 2 (taps ky and 3 + ky: with DIL = 1 the A fragment of output row
+                    // a, tap row ky is the one of row a + 1, tap row ky - 1 -- read once), then (kx 2, ky 0) + (kx 2, ky 1)
+                    // (dilated tiles share nothing and pair (t, t + 1): the kx-pairs cost them 40 registers)
+                    constexpr bool KXP = DIL == 1 && !OTVM_PM16_NOKXP;
+                    const int t1 = !KXP ? 2 * pr : (pr < 3 ? pr : 6), t2 = !KXP ? 2 * pr + 1 : (pr < 3 ? 3 + pr : 7);
+                    // (the lane-dependent part is the same for the three kx-pairs: equal addresses are equal expressions)
+                    const int o1 = ((t1 % 3) * DIL * PW + (t1 / 3) * DIL) * 8, o2 = ((t2 % 3) * DIL * PW + (t2 / 3) * DIL) * 8;
+                    const int ao = !KXP ? abase + (hs ? o2 : o1)
+                                        : (pr < 3 ? abase + hs * (DIL * 8) + pr * DIL * PW * 8 : abase + 2 * DIL * 8 + hs * (DIL * PW * 8));
+                    const int bo = bbase + (hs ? t2 : t1) * TAPB;
+                    f16x8 ah[TM][2], al[TM][2], bh[TN][2], bl[TN][2];
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int si = 0; si < 2; ++si) {
+                            ah[a][si] = *reinterpret_cast<const f16x8*>(&Ph[ao + (a * PW + 16 * si) * 8]);
+                            al[a][si] = *reinterpret_cast<const f16x8*>(&Pl[ao + (a * PW + 16 * si) * 8]);
+                        }
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int sj = 0; sj < 2; ++sj) {
+                            bh[b][sj] = *reinterpret_cast<const f16x8*>(&Bcur[bo + ((nt0 + b) * 2) * 512 + 16 * sj * 8]);
+                            bl[b][sj] = *reinterpret_cast<const f16x8*>(&Bcur[bo + ((nt0 + b) * 2 + 1) * 512 + 16 * sj * 8]);
+                        }
+                    pass(al, bh);
+                    pass(ah, bl);
+                    pass(ah, bh);
+                }
+                {   // tap 8: [hi | lo] x [hi | hi], then [hi | lo] x [lo | 0]
+                    constexpr int o8 = (2 * DIL * PW + 2 * DIL) * 8;
+                    const _Float16* Ahl = hs ? Pl : Ph;
+                    f16x8 ax[TM][2], bhh[TN][2], bl0[TN][2];
+#pragma unroll
+                    for (int a = 0; a < TM; ++a)
+#pragma unroll
+                        for (int si = 0; si < 2; ++si) ax[a][si] = *reinterpret_cast<const f16x8*>(&Ahl[abase + o8 + (a * PW + 16 * si) * 8]);
+                    const f16x8 zero8 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+#pragma unroll
+                        for (int sj = 0; sj < 2; ++sj) {
+                            bhh[b][sj] = *reinterpret_cast<const f16x8*>(&Bcur[bbase + 8 * TAPB + ((nt0 + b) * 2) * 512 + 16 * sj * 8]);
+                            const f16x8 l = *reinterpret_cast<const f16x8*>(&Bcur[bbase + 8 * TAPB + ((nt0 + b) * 2 + 1) * 512 + 16 * sj * 8]);
+                            bl0[b][sj] = hs ? zero8 : l;
+                        }
+                    pass(ax, bl0);
+                    pass(ax, bhh);
+                }
+            } else
 #pragma unroll
             for (int tl = 0; tl < TAPG; ++tl) {
                 const int tap = g * TAPG + tl;
@@ -353,6 +454,12 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
 
     // ---- epilogue: accumulator tile -> wave-private LDS patch -> 16-byte row-major stores (see conv_f16x3.hip)
     const int col = lane & 31, rbase = (lane >> 5) * 4;
+    // where accumulator register e of a 32 x 32 tile sits inside the tile: pixel (of the 32-pixel row), channel
+    const int pbase16 = pi16(4 * (lane >> 4));                     // (pi16(4 g + j) = pi16(4 g) + (j & 1) + 4 (j >> 1))
+    auto acc_row = [&](int e) __attribute__((always_inline)) -> int {
+        return M16 ? 16 * (e >> 3) + pbase16 + (e & 1) + 4 * ((e >> 1) & 1) : (e & 3) + 8 * (e >> 2) + rbase;
+    };
+    auto acc_col = [&](int e) __attribute__((always_inline)) -> int { return M16 ? 16 * ((e >> 2) & 1) + (lane & 15) : col; };
     __syncthreads();
 #if OTVM_PABL_NOEPI
     if (acc[0][0][0] == 12345.678f) p.out[0] = acc[0][0][1];
@@ -442,7 +549,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) rres[r4] = rnext[r4];
 #pragma unroll
-            for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
+            for (int e = 0; e < 16; ++e) patch[acc_row(e) * 36 + acc_col(e)] = acc[a][b][e];
             if (RES && t + 1 < TM * TN) load_res(t + 1, rnext);
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
@@ -483,7 +590,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                         rres[r4] = *reinterpret_cast<const f32x4*>(p.residual + ((int64_t)y * p.W + x) * p.res_ld + n4);
                 }
 #pragma unroll
-                for (int e = 0; e < 16; ++e) patch[((e & 3) + 8 * (e >> 2) + rbase) * 36 + col] = acc[a][b][e];
+                for (int e = 0; e < 16; ++e) patch[acc_row(e) * 36 + acc_col(e)] = acc[a][b][e];
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const int xi = r4 * 8 + prow;
@@ -529,6 +636,51 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
         const int seg = cg < 32 ? cg : 32;
         for (int i = tid; i < 2 * BN; i += NT) gred[i] = 0.0;
         __syncthreads();
+        if constexpr (M16) {
+            // a lane owns two channels of a 32-channel tile (sj = 0 / 1) and eight pixels of each of the wave's rows; the lanes
+            // that share a channel are lane ^ 16, lane ^ 32, lane ^ 48
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+#pragma unroll
+                for (int sj = 0; sj < 2; ++sj) {
+                    const int nl = (nt0 + b) * 32 + 16 * sj + (lane & 15);
+                    const int n = n0 + nl;
+                    float s = 0.f, ss = 0.f;
+                    if (n < p.Cout) {
+                        const float sc_ = p.wscale[n];
+                        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+                        for (int a = 0; a < TM; ++a) {
+                            const int y = ty0 + wave_m * TM + a;
+#pragma unroll
+                            for (int si = 0; si < 2; ++si)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) {
+                                    const int e = 4 * (2 * si + sj) + j;
+                                    const int x = tx0 + acc_row(e);
+                                    if (y < p.H && x < p.W) {
+                                        const float v = acc[a][b][e] * sc_ + bias;
+                                        s += v;
+                                        ss += v * v;
+                                    }
+                                }
+                        }
+                    }
+                    s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
+                    s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
+                    const int seg16 = seg < 16 ? seg : 16;
+                    for (int off = 1; off < seg16; off <<= 1) {
+                        s += __shfl_xor(s, off);
+                        ss += __shfl_xor(ss, off);
+                    }
+                    // (a group of 32 channels: its two 16-channel halves arrive as two atomics)
+                    if (lane < 16 && (lane & (seg16 - 1)) == 0 && n < p.Cout) {
+                        const int gl = nl / cg;
+                        atomicAdd(&gred[2 * gl], (double)s);
+                        atomicAdd(&gred[2 * gl + 1], (double)ss);
+                    }
+                }
+        } else
 #pragma unroll
         for (int b = 0; b < TN; ++b) {
             const int nl = (nt0 + b) * 32 + col;
@@ -610,12 +762,13 @@ __global__ __launch_bounds__(256) void pack_patch_weight_kernel(const float* __r
     }
 }
 
-template <int NPASS, int TH, int BN, int NW, int DIL, int TAPG = 9, bool INRES = false, bool HEAD = false, int NWN = 1, bool GLDS = false>
+template <int NPASS, int TH, int BN, int NW, int DIL, int TAPG = 9, bool INRES = false, bool HEAD = false, int NWN = 1, bool GLDS = false,
+          bool M16 = false>
 int launch_patch(PatchArgs& a, hipStream_t s) {
     a.tiles_x = otvm_ceil_div(a.W, 32);
     a.tiles_y = otvm_ceil_div(a.H, TH);
     a.tiles_n = otvm_ceil_div(a.Cout, BN);
-    hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL, TAPG, INRES, HEAD, NWN, GLDS, NPASS>), dim3(a.tiles_x * a.tiles_y * a.tiles_n, a.batch), dim3(NW * 64), 0, s, a);
+    hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL, TAPG, INRES, HEAD, NWN, GLDS, NPASS, M16>), dim3(a.tiles_x * a.tiles_y * a.tiles_n, a.batch), dim3(NW * 64), 0, s, a);
     OTVM_CHECK_LAUNCH("otvm_conv2d(patch f16x3)");
     return 0;
 }
@@ -698,6 +851,13 @@ int otvm_conv2d_patch_f16x3_forced(const otvm_conv_params* p, void* stream) { re
 // returns -1 when the layer is not eligible (caller falls back to the implicit-GEMM kernel)
 int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream) { return patch_run(p, stream, patch_choice(p)); }
 
+// round 5: the nine-tap 64-filter tiles on v_mfma_f32_16x16x32_f16 (the kernel's M16 comment); OTVM_PATCH_M16=0: the 32x32x16 form
+// (A/B runs).  One box, alternating (profiles/r05_patch_mfma16_ab.txt): 1080p 46.17 vs 45.54 frames/s, 832x480 151.6 vs 150.1
+static int patch_m16() {
+    static const int m = getenv("OTVM_PATCH_M16") ? atoi(getenv("OTVM_PATCH_M16")) : 1;
+    return m;
+}
+
 template <int NPASS>
 static int patch_run_t(const otvm_conv_params* p, void* stream, int choice, const otvm_head_params* hd) {
     if (choice == 0) return -1;
@@ -730,7 +890,9 @@ static int patch_run_t(const otvm_conv_params* p, void* stream, int choice, cons
     if (p->in_res) {
         OTVM_REQUIRE(otvm_conv2d_accepts_input_residual(p) && !is_wide && (p->in_res_ld & 3) == 0 && ((uintptr_t)p->in_res & 15) == 0,
                      "otvm_conv2d: in_res needs in_scale on a 3x3 stride-1 dilation-1 layer with <= 64 output channels");
-        return p->Cout <= 32 ? launch_patch<3, 8, 32, 4, 1, 3, true>(a, s) : launch_patch<3, 8, 64, 4, 1, 9, true>(a, s);
+        if (p->Cout <= 32) return launch_patch<3, 8, 32, 4, 1, 3, true>(a, s);
+        // (the matrix-core form of the plain 64-filter tile: the same products in the same order as the layer without in_res)
+        return patch_m16() ? launch_patch<3, 8, 64, 4, 1, 9, true, false, 1, false, true>(a, s) : launch_patch<3, 8, 64, 4, 1, 9, true>(a, s);
     }
     if (is_wide) {
         // the eight waves as 4 x 2 (two rows x four channel tiles each) instead of 8 x 1 (one row x eight tiles): a third less
@@ -771,6 +933,13 @@ static int patch_run_t(const otvm_conv_params* p, void* stream, int choice, cons
     static const int glds64 = getenv("OTVM_PATCH64_GLDS") ? atoi(getenv("OTVM_PATCH64_GLDS")) : 0;
     if (p->dil == 1 && p->Cout > 32 && glds64) return launch_patch<NPASS, 8, 64, 4, 1, 3, false, false, 1, true>(a, s);   // (both channel tiles have weights)
     if (p->dil == 1 && p->Cout <= 32 && glds32) return launch_patch<NPASS, 8, 32, 4, 1, 3, false, false, 1, true>(a, s);
+    if constexpr (NPASS == 3) {
+        if (patch_m16() && p->Cout > 32) {
+            if (p->dil == 1) return launch_patch<3, 8, 64, 4, 1, 9, false, false, 1, false, true>(a, s);
+            if (p->dil == 2) return launch_patch<3, 8, 64, 4, 2, 9, false, false, 1, false, true>(a, s);
+            return launch_patch<3, 8, 64, 4, 4, 9, false, false, 1, false, true>(a, s);
+        }
+    }
     if (p->dil == 1) return p->Cout <= 32 ? launch_patch<NPASS, 8, 32, 4, 1, 3>(a, s) : launch_patch<NPASS, 8, 64, 4, 1>(a, s);
     if (p->dil == 2) return launch_patch<NPASS, 8, 64, 4, 2>(a, s);
     return launch_patch<NPASS, 8, 64, 4, 4>(a, s);

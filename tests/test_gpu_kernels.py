@@ -149,6 +149,20 @@ def test_conv_fuzz_all_routes(G):
     assert r.returncode == 0 and "conv_fuzz: 80 cases" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("m16", ["1", "0"], ids=["mfma16x16x32", "mfma32x32x16"])
+def test_nine_tap_patch_tiles_in_either_matrix_core_form(G, m16):
+    """The 64-filter patch tiles run on v_mfma_f32_16x16x32_f16 by default (round 5; planar LDS patch, tap pairs in the K = 32 of
+    one instruction, permuted accumulator rows, its own fused GroupNorm sums); OTVM_PATCH_M16=0 keeps the 32x32x16 form (A/B
+    runs).  The switch is read once per process: both forms are checked in processes of their own on ragged blocks, every
+    dilation, 16-channel stages that do not fill a 32-channel block, bias / residual / activation / fused statistics."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_fuzz.py"), "--n", "40", "--seed", "9", "--patch64"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, OTVM_PATCH_M16=m16))
+    assert r.returncode == 0 and "conv_fuzz: 40 cases" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_gn_table_tail_stress_short(G):
     """tools/gn_tail_stress.py, short form: the GroupNorm table written by a conv's LAST workgroup (common.h::
     otvm_gn_table_tail -- device-scope statistics atomics, a workgroup-scope fence, a ticket) against otvm_gn_table over the
@@ -942,7 +956,8 @@ def test_conv_every_tunable_configuration(G, Cin, Cout, k, stride, dil, H, W, us
     assert n >= 3 and len(set(codes[:n])) == n
     if Cin % 32 == 0 and Cout > 32:
         assert any(c // 16 - 1 == 9 for c in codes[:n]), "the one-wave 64x64 tile must be a candidate of a whole-chunk layer"
-        assert any(c // 16 - 1 in (10, 42) for c in codes[:n]) and any(c // 16 - 1 in (11, 43) for c in codes[:n]), "pipelined small tiles (32 + t: LDS-DMA form)"
+        assert any(c // 16 - 1 in (10, 42, 74) for c in codes[:n]) and any(c // 16 - 1 in (11, 43, 75) for c in codes[:n]), \
+            "pipelined small tiles (32 + t: LDS-DMA form, 64 + t: on v_mfma_f32_16x16x32_f16)"
     seen_split = False
     for c in list(codes[:n]) + [0]:
         out.t.fill_(float("nan"))
@@ -1106,7 +1121,8 @@ def test_igemm_lds_dma_weight_stages_are_race_free(G, tile, Cin, Cout, k, H, W, 
     p = conv_params(xa, cw, out, None, 1, pad, 1, 0, 0, None, L.PREC_F16X3, None, None)
     codes = (C.c_int * 128)()
     n = int(lib.otvm_conv2d_candidates(C.byref(p), codes, 128))
-    assert (fam + tile + 1) * 16 + 1 in list(codes[:n]), "the LDS-DMA tile (both matrix-core forms) must be a candidate of a whole-chunk layer"
+    # (OTVM_IGEMM_M16 = 2, the default: the 16x16x32 form replaces the 32x32x16 form in the list; that one stays legal when forced)
+    assert (64 + tile + 1) * 16 + 1 in list(codes[:n]), "the LDS-DMA tile (16x16x32 form) must be a candidate of a whole-chunk layer"
     assert (tile + 1) * 16 + 1 not in list(codes[:n]), "... in place of the register-staged form"
     p.tune = (tile + 1) * 16 + 1                            # the register-staged tile of the same shape (still legal when forced)
     L.check(lib.otvm_conv2d(C.byref(p), G.stream()), "register-staged tile")

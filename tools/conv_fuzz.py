@@ -22,6 +22,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--n", type=int, default=200)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--patch64", action="store_true", help="only 3x3 stride-1 layers with 33 ... 64 filters: the nine-tap patch tiles "
+                                                          "(either matrix-core form, OTVM_PATCH_M16)")
     ap.add_argument("--verbose", action="store_true", help="print every case BEFORE it is launched (to find a case that faults)")
     args = ap.parse_args()
     rng = random.Random(args.seed)
@@ -35,6 +37,9 @@ def main():
         if k == 7:
             Cin = rng.choice([3, 11, 22, 24])
         Cout = rng.choice([3, 16, 32, 48, 64, 128, 192, 256, 384, 512, 1024])
+        if args.patch64:
+            k, stride, dil = 3, 1, rng.choice([1, 1, 1, 2, 4])
+            Cin, Cout = rng.choice([16, 32, 48, 64, 80, 128, 320]), rng.choice([40, 48, 64, 64, 64])
         # keep the CPU reference cheap: bound M * K * Cout
         budget = 6e9
         maxM = int(budget / (Cin * k * k * Cout * 2))
@@ -48,7 +53,7 @@ def main():
         use_res = rng.random() < 0.3 and not gn
         if gn:
             act = 0
-        prec = rng.choice([0, 1, 1, 1])
+        prec = 1 if args.patch64 else rng.choice([0, 1, 1, 1])
         g = torch.Generator().manual_seed(1000 + it)
         x = torch.randn(1, Cin, H, W, generator=g)
         w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
