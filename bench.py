@@ -37,7 +37,8 @@ POWER_LIMITED_PEAK = {"f16x3": 1650.0 / 3.0, "f16": 1650.0}       # tools/probes
 KERNEL_NAME = {"f32": "all otvm_conv2d launches: conv_igemm_f32_kernel (v_mfma_f32_32x32x2_f32)",
                "f16x3": "all convolution launches of the plan: conv_igemm_f16x3_kernel + conv_patch_f16x3_kernel + conv_stem_f16x3_kernel "
                         "(+ split-K finish) + stm_bottleneck_f16x3_kernel (three / four fused convolutions of an STM res2 block); "
-                        "3x v_mfma_f32_32x32x16_f16 per fp32-equivalent MAC",
+                        "three f16 MFMA passes per fp32-equivalent MAC (v_mfma_f32_16x16x32_f16 in the LDS-DMA implicit-GEMM and nine-tap patch tiles, "
+                        "v_mfma_f32_32x32x16_f16 elsewhere)",
                "f16": "the same launches in the single-pass mode: conv_igemm_f16x3_kernel<..., NPASS = 1> and conv_patch_f16x3_kernel<..., "
                       "NPASS = 1> issue ONE v_mfma_f32_32x32x16_f16 per MAC on fp16-rounded operands; the stem, 16-wide head, fused STM "
                       "bottleneck and memory-read kernels keep three passes (priced as if single-pass: frac is a lower bound)"}
