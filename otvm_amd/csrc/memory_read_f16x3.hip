@@ -82,27 +82,6 @@ __global__ __launch_bounds__(256) void bank_pack_vals_kernel(const float* __rest
     }
 }
 
-// M16 layout of the values (round 5): Vf[kvb = hw_pad/32][nb = 16][sj = 2][hi|lo][lane][8]: lane l <- V[32 kvb + 8 (l>>4) + 0..7]
-// [32 nb + 16 sj + (l&15)] = the B operand of one v_mfma_f32_16x16x32_f16 (32 memory rows deep, 16 value channels wide)
-__global__ __launch_bounds__(256) void bank_pack_vals_m16_kernel(const float* __restrict__ v, int hw, _Float16* __restrict__ vf) {
-    const int kvb = blockIdx.x;
-    for (int i = threadIdx.x; i < 16 * 2 * 64; i += 256) {
-        const int nb = i >> 7, sj = (i >> 6) & 1, l = i & 63;
-        const int dv = nb * 32 + 16 * sj + (l & 15), r0 = kvb * 32 + 8 * (l >> 4);
-        f16x8 hi, lo;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float x = (r0 + j) < hw ? v[(int64_t)(r0 + j) * DV + dv] : 0.f;
-            _Float16 h, lw;
-            split1(x, h, lw);
-            hi[j] = h; lo[j] = lw;
-        }
-        _Float16* base = vf + ((((int64_t)kvb * 16 + nb) * 2 + sj) * 2) * 512;
-        *reinterpret_cast<f16x8*>(base + l * 8) = hi;
-        *reinterpret_cast<f16x8*>(base + 512 + l * 8) = lo;
-    }
-}
-
 struct Mem3Args {
     const float* q; int q_ld;
     const _Float16* kf[8]; const _Float16* vf[8];
@@ -113,14 +92,6 @@ struct Mem3Args {
     float* part_ml;    // [partials][hw][2]
 };
 
-// M16 (round 5): P.V -- four fifths of the kernel's matrix work -- on v_mfma_f32_16x16x32_f16 (~10 % more work per joule than the
-// 32x32x16 instruction under this chip's power limit, profiles/r05_igemm_mfma16_ab.txt).  A 32 x 32 accumulator tile is four 16 x 16
-// sub-tiles (registers 4 q ... 4 q + 3 of quad q = 2 si + sj: query 16 si + 4 (lane >> 4) + j, channel 16 sj + (lane & 15)); one
-// instruction takes 32 memory rows: the A operand is P[16 si + (lane & 15)][32 kc + 8 (lane >> 4) ...] out of LDS (octet o of
-// row r stored at o ^ f(r), f = bit 2 ^ bit 3 of r: without it every ds_read_b128 lane group is a 2-way bank conflict), the B
-// operand one 1-KiB block of the bank's M16 layout (bank_pack_vals_m16_kernel).  K.Q^T keeps the 32x32x16 instruction (its
-// accumulator layout is what the in-register softmax is written for).
-template <bool M16>
 __global__ __launch_bounds__(256, 2) void memory_read_f16x3_kernel(const Mem3Args p) {
     __shared__ __attribute__((aligned(16))) _Float16 Qh[BQ * LDQH];
     __shared__ __attribute__((aligned(16))) _Float16 Ql[BQ * LDQH];
@@ -200,19 +171,7 @@ __global__ __launch_bounds__(256, 2) void memory_read_f16x3_kernel(const Mem3Arg
         // vector-memory path, so a 128-query workgroup that halves the bank traffic was not built)
         // the first value fragments of the tile travel under the softmax
         f16x8 vh[2][4], vl[2][4];
-        // M16: a step = 32 memory rows x 64 of the wave's 128 channels (step s: rows 32 (s >> 1) ..., channel tiles 2 (s & 1), + 1);
-        // fragment index inside a step = 2 b + sj
-        auto v_step = [&](int st, int buf) __attribute__((always_inline)) {
-            const _Float16* vblk = Vf + ((((int64_t)(2 * t + (st >> 1)) * 16 + wave * 4 + 2 * (st & 1)) * 2) * 2) * 512 + lane * 8;
-#pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                vh[buf][f] = *reinterpret_cast<const f16x8*>(vblk + (f * 2) * 512);
-                vl[buf][f] = *reinterpret_cast<const f16x8*>(vblk + (f * 2 + 1) * 512);
-            }
-        };
-        if constexpr (M16) {
-            v_step(0, 0);
-        } else {
+        {
             const _Float16* vblk = Vf + (((int64_t)(4 * t) * 16 + wave * 4) * 2) * 512 + lane * 8;
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
@@ -255,8 +214,7 @@ __global__ __launch_bounds__(256, 2) void memory_read_f16x3_kernel(const Mem3Arg
                     split1(e, h, lw);
                     hi[j] = h; lo[j] = lw;
                 }
-                int kvl = sa * 32 + 8 * g + 4 * fh;
-                if (M16) kvl ^= ((((qq >> 2) ^ (qq >> 3)) & 1) << 3);      // octet o of row r at o ^ f(r)
+                const int kvl = sa * 32 + 8 * g + 4 * fh;
                 *reinterpret_cast<f16x4*>(&Ph[qq * LDPH + kvl]) = hi;
                 *reinterpret_cast<f16x4*>(&Pl[qq * LDPH + kvl]) = lo;
             }
@@ -279,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void memory_read_f16x3_kernel(const Mem3Arg
             for (int a = 0; a < 2; ++a)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
-                    alr[a][e] = alpha_l[a * 32 + (M16 ? 16 * (e >> 3) + 4 * (lane >> 4) + (e & 3) : (e & 3) + 8 * (e >> 2) + 4 * fh)];
+                    alr[a][e] = alpha_l[a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh];
                     moved |= alr[a][e] != 1.f;
                 }
             if (__any(moved)) {                          // the running maxima settle after the first tiles
@@ -291,44 +249,6 @@ __global__ __launch_bounds__(256, 2) void memory_read_f16x3_kernel(const Mem3Arg
                         for (int b = 0; b < 4; ++b) acc[a][b][e] *= alr[a][e];
             }
         }
-        if constexpr (M16) {
-            const int l15 = lane & 15, osw = (lane >> 4) ^ (((l15 >> 2) ^ (l15 >> 3)) & 1);
-            auto quad = [](const f32x16& c, int q) __attribute__((always_inline)) { return f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]}; };
-            auto put = [](f32x16& c, int q, const f32x4 x) __attribute__((always_inline)) { c[4 * q] = x.x; c[4 * q + 1] = x.y; c[4 * q + 2] = x.z; c[4 * q + 3] = x.w; };
-#pragma unroll
-            for (int st = 0; st < 4; ++st) {
-                const int kc = st >> 1, bh = st & 1, vb = st & 1;
-                if (st + 1 < 4) {                        // the next step's value fragments, a step ahead
-                    v_step(st + 1, (st + 1) & 1);
-                    asm volatile("" ::: "memory");
-                }
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    // (the P fragments of one 32-query block at a time: 16 registers; holding both blocks across the two steps
-                    // of a chunk spilled 56 bytes)
-                    f16x8 ph[2], pl[2];
-#pragma unroll
-                    for (int si = 0; si < 2; ++si) {
-                        ph[si] = *reinterpret_cast<const f16x8*>(&Ph[(a * 32 + 16 * si + l15) * LDPH + 32 * kc + 8 * osw]);
-                        pl[si] = *reinterpret_cast<const f16x8*>(&Pl[(a * 32 + 16 * si + l15) * LDPH + 32 * kc + 8 * osw]);
-                    }
-                    // three passes over the block's eight accumulator quads: consecutive MFMAs never share an accumulator
-#pragma unroll
-                    for (int pass = 0; pass < 3; ++pass)
-#pragma unroll
-                        for (int b = 0; b < 2; ++b)
-#pragma unroll
-                            for (int sj = 0; sj < 2; ++sj)
-#pragma unroll
-                                for (int si = 0; si < 2; ++si) {
-                                    f32x16& c = acc[a][2 * bh + b];
-                                    const f16x8 A = pass == 0 ? pl[si] : ph[si];
-                                    const f16x8 B = pass == 1 ? vl[vb][2 * b + sj] : vh[vb][2 * b + sj];
-                                    put(c, 2 * si + sj, __builtin_amdgcn_mfma_f32_16x16x32_f16(A, B, quad(c, 2 * si + sj), 0, 0, 0));
-                                }
-                }
-            }
-        } else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             f16x8 ph[2], pl[2];
@@ -374,11 +294,10 @@ __global__ __launch_bounds__(256, 2) void memory_read_f16x3_kernel(const Mem3Arg
     for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            const int qq = q0 + a * 32 + (M16 ? 16 * (e >> 3) + 4 * (lane >> 4) + (e & 3) : (e & 3) + 8 * (e >> 2) + 4 * fh);
-            const int cc = M16 ? 16 * ((e >> 2) & 1) + (lane & 15) : frow;
+            const int qq = q0 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
             if (qq < hw) {
 #pragma unroll
-                for (int b = 0; b < 4; ++b) po[(int64_t)qq * DV + dv0 + 32 * b + cc] = acc[a][b][e];
+                for (int b = 0; b < 4; ++b) po[(int64_t)qq * DV + dv0 + 32 * b + frow] = acc[a][b][e];
             }
         }
     if (sa == 0 && fh == 0 && q0 + sb * 32 + frow < hw) {
@@ -639,22 +558,13 @@ extern "C" int64_t otvm_bank_slot_bytes_f16x3(int hw) {
     return (int64_t)hw_pad64(hw) * (DK + DV) * 2 * sizeof(_Float16);
 }
 
-// round 5: P.V on v_mfma_f32_16x16x32_f16 over the M16 value layout (the kernel's comment).  OTVM_MEMREAD_M16=0 keeps the 32x32x16
-// form and its layout (A/B runs); so does OTVM_MEMREAD_ALT=1 (that kernel reads the old layout).  Pack and read consult the same switch.
-static int mr_m16() {
-    static const int m = (getenv("OTVM_MEMREAD_M16") ? atoi(getenv("OTVM_MEMREAD_M16")) : 1) &&
-                         !(getenv("OTVM_MEMREAD_ALT") && atoi(getenv("OTVM_MEMREAD_ALT")));
-    return m;
-}
-
 extern "C" int otvm_bank_pack_f16x3(const float* key, const float* val, int hw, void* slot, void* stream) {
     OTVM_REQUIRE(key && val && slot && hw > 0, "otvm_bank_pack_f16x3: bad arguments");
     const int hp = hw_pad64(hw);
     _Float16* kf = (_Float16*)slot;
     _Float16* vf = kf + (int64_t)hp * DK * 2;
     hipLaunchKernelGGL(bank_pack_keys_kernel, dim3(hp / 32), dim3(256), 0, (hipStream_t)stream, key, hw, kf);
-    if (mr_m16()) hipLaunchKernelGGL(bank_pack_vals_m16_kernel, dim3(hp / 32), dim3(256), 0, (hipStream_t)stream, val, hw, vf);
-    else hipLaunchKernelGGL(bank_pack_vals_kernel, dim3(hp / 16), dim3(256), 0, (hipStream_t)stream, val, hw, vf);
+    hipLaunchKernelGGL(bank_pack_vals_kernel, dim3(hp / 16), dim3(256), 0, (hipStream_t)stream, val, hw, vf);
     OTVM_CHECK_LAUNCH("otvm_bank_pack_f16x3");
     return 0;
 }
@@ -686,8 +596,7 @@ static int mr_launch_partials(const float* q_key, int q_ld, const void* const* s
         // workgroup.  The chunk count stays what fills 512 four-wave slots, i.e. 256 of these workgroups.
         static const int alt = getenv("OTVM_MEMREAD_ALT") ? atoi(getenv("OTVM_MEMREAD_ALT")) : 0;
         if (alt) hipLaunchKernelGGL(memory_read_f16x3_alt_kernel, dim3(otvm_ceil_div(hw, BQ), (used + 1) / 2), dim3(512), 0, stream, a);
-        else if (mr_m16()) hipLaunchKernelGGL(memory_read_f16x3_kernel<true>, dim3(otvm_ceil_div(hw, BQ), used), dim3(256), 0, stream, a);
-        else hipLaunchKernelGGL(memory_read_f16x3_kernel<false>, dim3(otvm_ceil_div(hw, BQ), used), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(memory_read_f16x3_kernel, dim3(otvm_ceil_div(hw, BQ), used), dim3(256), 0, stream, a);
         part0 += used;
     }
     return part0;
