@@ -57,7 +57,8 @@ const char* otvm_last_error(void);
                                  17: otvm_gram_f16 / otvm_gn_predict (GroupNorm statistics of a 1x1 convolution's output predicted
                                      from its input's Gram matrix: the normalisation moves into that convolution's epilogue);
                                  18: otvm_gram_params.diag / otvm_gn_predict_params.diag (conditioning + saturation diagnostics of the
-                                     predicted statistics); implicit-GEMM tiles 32 + t with LDS-DMA weight stages (tune codes) */
+                                     predicted statistics); implicit-GEMM tiles 32 + t with LDS-DMA weight stages and 64 + t = the same on
+                                     v_mfma_f32_16x16x32_f16 (tune codes; no new entry points) */
 int otvm_abi_version(void);
 
 /* ---------------------------------------------------------------- weights (load time) ----------
