@@ -43,8 +43,8 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #define OTVM_PABL_NOEPI 0      // no output stores / residual loads
 #endif
 #ifndef OTVM_PABL_MFMA16
-#define OTVM_PABL_MFMA16 0     // every 32x32x16 MFMA of the 32x32x16 forms replaced by two 16x16x32 on the same fragments (the instruction's
-#endif                         // effect on a tile before its real 16x16x32 form exists: profiles/r05_patch_mfma16_ab.txt)
+#define OTVM_PABL_MFMA16 0     // every MFMA of the 32x32x16 forms replaced by two 16x16x32 on the same fragments (what the instruction
+#endif                         // alone is worth on a tile before a real 16x16x32 form exists: profiles/r05_patch_wide_mfma16_ab.txt)
 #ifndef OTVM_PM16_NOKXP
 #define OTVM_PM16_NOKXP 0      // (A/B build, results right) M16 tiles: taps paired (t, t + 1) on every dilation
 #endif
@@ -152,20 +152,12 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     constexpr int TM = TH / NWM, TN = TNW / NWN;
     static_assert(NW % NWN == 0 && TH % NWM == 0 && TNW % NWN == 0, "bad wave grid");
     constexpr int PW = 32 + 2 * DIL, PH = TH + 2 * DIL, NPIX = PH * PW;
-    // M16W: the 16x16x32 form of the LDS-DMA tiles.  Its weight stages hold an EVEN number of taps so that the taps pair up inside
-    // the instruction's K = 32: per 16 input channels the stages are the filter-column pairs {0, 3}, {1, 4}, {2, 5} ((kx 0, ky) +
-    // (kx 1, ky) of tap row ky), {6, 7} ((kx 2, ky 0) + (kx 2, ky 1)) and {8}: five stages of 32 / 16 KiB instead of three of 48
-    // (14 instructions' worth of K for 13.5).  [Stages {0,3,1,4}, {2,5,6,7}, {8} -- three, as before -- measured 48 - 67 % SLOWER
-    // than the 32x32x16 form: a 64-KiB copy has to land under the one-tap stage's 1000 matrix-core cycles.]
-    constexpr bool M16W = M16 && GLDS;
-    constexpr int NG = M16W ? 5 : 9 / TAPG;
-    constexpr int STAPS = M16W ? 2 : TAPG;                             // taps of the largest weight stage
+    constexpr int NG = 9 / TAPG;
     static_assert(BN % 32 == 0 && 9 % TAPG == 0, "bad tile");
-    static_assert(!M16 || (NPASS == 3 && !HEAD && ((TAPG == 9 && NWN == 1 && !GLDS) || (TAPG == 3 && GLDS && DIL == 1))),
-                  "the 16x16x32 form: nine-tap f16x3 tiles, or the LDS-DMA tiles with their even-tap stages");
+    static_assert(!M16 || (TAPG == 9 && NPASS == 3 && !HEAD && NWN == 1 && !GLDS), "the 16x16x32 form: nine-tap f16x3 tiles");
     constexpr int PLANE = ((NPIX + 11) / 16) * 16 + 4;                 // M16: pixels per octet plane, = 4 mod 16 (>= NPIX)
     constexpr int PATCH_HALFS = M16 ? 2 * 2 * PLANE * 8 : 2 * NPIX * LDP;   // hi + lo
-    constexpr int B_PIECES = STAPS * TNW * 2 * 64;                     // 16-byte pieces of one (the largest) weight stage
+    constexpr int B_PIECES = TAPG * TNW * 2 * 64;                      // 16-byte pieces of one weight stage
     constexpr int B_HALFS = B_PIECES * 8;
     constexpr int EPI_HALFS = NW * 32 * 36 * 2 * (HEAD ? 2 : 1);       // epilogue patches (fp32) expressed in halfs
     // GLDS (round 4, the 256-channel tiles): the weight stage is copied global -> LDS by the LDS-DMA path (global_load_lds_dwordx4:
@@ -227,10 +219,9 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
             const int i = tid + k * NT;
-            if (i < (M16W ? (g < 4 ? 2 : 1) * TNW * 2 * 64 : B_PIECES)) {
+            if (i < B_PIECES) {
                 const int l = i & 63, blk = i >> 6;                     // blk = (tapl*TN + b)*2 + hl
-                const int hl = blk & 1, tb = blk >> 1, b = tb % TNW, tl = tb / TNW;
-                const int tap = !M16W ? g * TAPG + tl : (g < 3 ? g + 3 * tl : (g == 3 ? 6 + tl : 8));
+                const int hl = blk & 1, tb = blk >> 1, b = tb % TNW, tap = g * TAPG + tb / TNW;
                 if (NPASS == 1 && hl) continue;                         // (wave-uniform: a wave copies whole 1-KiB blocks)
                 const int64_t src = (((((int64_t)cb32 * 9 + tap) * nbs + nb0 + b) * 2 + ks) * 2 + hl) * 512 + l * 8;
                 if constexpr (GLDS) {
@@ -353,24 +344,32 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                 const int bbase = (l15 + 32 * oct) * 8;
                 auto quad = [](const f32x16& c, int q) __attribute__((always_inline)) { return f32x4{c[4 * q], c[4 * q + 1], c[4 * q + 2], c[4 * q + 3]}; };
                 auto put = [](f32x16& c, int q, const f32x4 v) __attribute__((always_inline)) { c[4 * q] = v.x; c[4 * q + 1] = v.y; c[4 * q + 2] = v.z; c[4 * q + 3] = v.w; };
-                constexpr int TAPB = TNW * 2 * 512;                         // halfs of one tap's weight blocks
-                constexpr int GBM = TN >= 4 ? 1 : (TN < 2 ? TN : 2);        // B fragments of GBM channel tiles at a time (registers: 128 accumulators at TN = 4)
-                // one K = 32 pass over TM x GBM tiles: 4 TM GBM instructions on as many accumulator quads
-                auto pass = [&](int b0, const f16x8 (&A)[TM][2], const f16x8 (&B)[GBM][2]) __attribute__((always_inline)) {
+                // one K = 32 pass over the wave's TM x TN tiles: 4 TM TN instructions on as many accumulator quads
+                auto pass = [&](const f16x8 (&A)[TM][2], const f16x8 (&B)[TN][2]) __attribute__((always_inline)) {
 #pragma unroll
                     for (int a = 0; a < TM; ++a)
 #pragma unroll
-                        for (int b = 0; b < GBM; ++b)
+                        for (int b = 0; b < TN; ++b)
 #pragma unroll
                             for (int si = 0; si < 2; ++si)
 #pragma unroll
                                 for (int sj = 0; sj < 2; ++sj)
-                                    put(acc[a][b0 + b], 2 * si + sj, __builtin_amdgcn_mfma_f32_16x16x32_f16(A[a][si], B[b][sj], quad(acc[a][b0 + b], 2 * si + sj), 0, 0, 0));
+                                    put(acc[a][b], 2 * si + sj, __builtin_amdgcn_mfma_f32_16x16x32_f16(A[a][si], B[b][sj], quad(acc[a][b], 2 * si + sj), 0, 0, 0));
                 };
-                // two taps x {lo.hi, hi.lo, hi.hi}: lanes 0-31 read tap tl1 (A at lane offset ao), lanes 32-63 tap tl2
-                auto pair_units = [&](int ao, int tl1, int tl2) __attribute__((always_inline)) {
-                    const int bo = bbase + (hs ? tl2 : tl1) * TAPB;
-                    f16x8 ah[TM][2], al[TM][2];
+                constexpr int TAPB = TNW * 2 * 512;                         // halfs of one tap's weight blocks
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    // pairs (kx 0, ky) + (kx 1, ky) for ky = 0, 1, 2 (taps ky and 3 + ky: with DIL = 1 the A fragment of output row
+                    // a, tap row ky is the one of row a + 1, tap row ky - 1 -- read once), then (kx 2, ky 0) + (kx 2, ky 1)
+                    // (dilated tiles share nothing and pair (t, t + 1): the kx-pairs cost them 40 registers)
+                    constexpr bool KXP = DIL == 1 && !OTVM_PM16_NOKXP;
+                    const int t1 = !KXP ? 2 * pr : (pr < 3 ? pr : 6), t2 = !KXP ? 2 * pr + 1 : (pr < 3 ? 3 + pr : 7);
+                    // (the lane-dependent part is the same for the three kx-pairs: equal addresses are equal expressions)
+                    const int o1 = ((t1 % 3) * DIL * PW + (t1 / 3) * DIL) * 8, o2 = ((t2 % 3) * DIL * PW + (t2 / 3) * DIL) * 8;
+                    const int ao = !KXP ? abase + (hs ? o2 : o1)
+                                        : (pr < 3 ? abase + hs * (DIL * 8) + pr * DIL * PW * 8 : abase + 2 * DIL * 8 + hs * (DIL * PW * 8));
+                    const int bo = bbase + (hs ? t2 : t1) * TAPB;
+                    f16x8 ah[TM][2], al[TM][2], bh[TN][2], bl[TN][2];
 #pragma unroll
                     for (int a = 0; a < TM; ++a)
 #pragma unroll
@@ -379,68 +378,35 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                             al[a][si] = *reinterpret_cast<const f16x8*>(&Pl[ao + (a * PW + 16 * si) * 8]);
                         }
 #pragma unroll
-                    for (int b0 = 0; b0 < TN; b0 += GBM) {
-                        f16x8 bh[GBM][2], bl[GBM][2];
+                    for (int b = 0; b < TN; ++b)
 #pragma unroll
-                        for (int b = 0; b < GBM; ++b)
-#pragma unroll
-                            for (int sj = 0; sj < 2; ++sj) {
-                                bh[b][sj] = *reinterpret_cast<const f16x8*>(&Bcur[bo + ((nt0 + b0 + b) * 2) * 512 + 16 * sj * 8]);
-                                bl[b][sj] = *reinterpret_cast<const f16x8*>(&Bcur[bo + ((nt0 + b0 + b) * 2 + 1) * 512 + 16 * sj * 8]);
-                            }
-                        pass(b0, al, bh);
-                        pass(b0, ah, bl);
-                        pass(b0, ah, bh);
-                    }
-                };
-                // the odd tap (local index tl, patch offset o8): [hi | lo] x [lo | 0], then [hi | lo] x [hi | hi]
-                auto single_units = [&](int o8, int tl) __attribute__((always_inline)) {
+                        for (int sj = 0; sj < 2; ++sj) {
+                            bh[b][sj] = *reinterpret_cast<const f16x8*>(&Bcur[bo + ((nt0 + b) * 2) * 512 + 16 * sj * 8]);
+                            bl[b][sj] = *reinterpret_cast<const f16x8*>(&Bcur[bo + ((nt0 + b) * 2 + 1) * 512 + 16 * sj * 8]);
+                        }
+                    pass(al, bh);
+                    pass(ah, bl);
+                    pass(ah, bh);
+                }
+                {   // tap 8: [hi | lo] x [hi | hi], then [hi | lo] x [lo | 0]
+                    constexpr int o8 = (2 * DIL * PW + 2 * DIL) * 8;
                     const _Float16* Ahl = hs ? Pl : Ph;
-                    f16x8 ax[TM][2];
+                    f16x8 ax[TM][2], bhh[TN][2], bl0[TN][2];
 #pragma unroll
                     for (int a = 0; a < TM; ++a)
 #pragma unroll
                         for (int si = 0; si < 2; ++si) ax[a][si] = *reinterpret_cast<const f16x8*>(&Ahl[abase + o8 + (a * PW + 16 * si) * 8]);
                     const f16x8 zero8 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
 #pragma unroll
-                    for (int b0 = 0; b0 < TN; b0 += GBM) {
-                        f16x8 bhh[GBM][2], bl0[GBM][2];
+                    for (int b = 0; b < TN; ++b)
 #pragma unroll
-                        for (int b = 0; b < GBM; ++b)
-#pragma unroll
-                            for (int sj = 0; sj < 2; ++sj) {
-                                bhh[b][sj] = *reinterpret_cast<const f16x8*>(&Bcur[bbase + tl * TAPB + ((nt0 + b0 + b) * 2) * 512 + 16 * sj * 8]);
-                                const f16x8 l = *reinterpret_cast<const f16x8*>(&Bcur[bbase + tl * TAPB + ((nt0 + b0 + b) * 2 + 1) * 512 + 16 * sj * 8]);
-                                bl0[b][sj] = hs ? zero8 : l;
-                            }
-                        pass(b0, ax, bl0);
-                        pass(b0, ax, bhh);
-                    }
-                };
-                // pairs (kx 0, ky) + (kx 1, ky) for ky = 0, 1, 2 (taps ky and 3 + ky: with DIL = 1 the A fragment of output row a, tap
-                // row ky is the one of row a + 1, tap row ky - 1 -- read once; the lane-dependent part of the address is the same for
-                // the three: equal addresses are equal expressions), then (kx 2, ky 0) + (kx 2, ky 1), then tap 8
-                // (dilated tiles share nothing and pair (t, t + 1): the kx-pairs cost them 40 registers)
-                constexpr bool KXP = DIL == 1 && !OTVM_PM16_NOKXP;
-                constexpr int o8 = (2 * DIL * PW + 2 * DIL) * 8;
-                const int akx = abase + hs * (DIL * 8);                      // lanes 32-63: one filter column to the right
-                const int a67 = abase + 2 * DIL * 8 + hs * (DIL * PW * 8);   // (kx 2, ky 0) | (kx 2, ky 1)
-                if constexpr (M16W) {
-                    if (g < 3) {
-                        pair_units(akx + g * DIL * PW * 8, 0, 1);
-                    } else if (g == 3) {
-                        pair_units(a67, 0, 1);
-                    } else {
-                        single_units(o8, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int pr = 0; pr < 4; ++pr) {
-                        const int t1 = !KXP ? 2 * pr : (pr < 3 ? pr : 6), t2 = !KXP ? 2 * pr + 1 : (pr < 3 ? 3 + pr : 7);
-                        const int o1 = ((t1 % 3) * DIL * PW + (t1 / 3) * DIL) * 8, o2 = ((t2 % 3) * DIL * PW + (t2 / 3) * DIL) * 8;
-                        pair_units(!KXP ? abase + (hs ? o2 : o1) : (pr < 3 ? akx + pr * DIL * PW * 8 : a67), t1, t2);
-                    }
-                    single_units(o8, 8);
+                        for (int sj = 0; sj < 2; ++sj) {
+                            bhh[b][sj] = *reinterpret_cast<const f16x8*>(&Bcur[bbase + 8 * TAPB + ((nt0 + b) * 2) * 512 + 16 * sj * 8]);
+                            const f16x8 l = *reinterpret_cast<const f16x8*>(&Bcur[bbase + 8 * TAPB + ((nt0 + b) * 2 + 1) * 512 + 16 * sj * 8]);
+                            bl0[b][sj] = hs ? zero8 : l;
+                        }
+                    pass(ax, bl0);
+                    pass(ax, bhh);
                 }
             } else
 #pragma unroll
@@ -950,12 +916,6 @@ static int patch_run_t(const otvm_conv_params* p, void* stream, int choice, cons
         // rows x two tiles) spills 108 B
         static const int nwn = getenv("OTVM_PATCH_WIDE_NWN") ? atoi(getenv("OTVM_PATCH_WIDE_NWN")) : 2;
         static const int glds = getenv("OTVM_PATCH_WIDE_GLDS") ? atoi(getenv("OTVM_PATCH_WIDE_GLDS")) : 1;
-        if constexpr (NPASS == 3) {
-            // round 5: ... on v_mfma_f32_16x16x32_f16 with even-tap weight stages (the kernel's M16W comment); OTVM_PATCH_WIDE_M16=0:
-            // the 32x32x16 form with its three-tap stages (A/B runs)
-            static const int wm16 = getenv("OTVM_PATCH_WIDE_M16") ? atoi(getenv("OTVM_PATCH_WIDE_M16")) : 1;
-            if (nwn == 2 && p->dil == 1 && glds && wm16) return launch_patch<3, 8, 256, 8, 1, 3, false, false, 2, true, true>(a, s);
-        }
         if (nwn == 2 && p->dil == 1 && glds) return launch_patch<NPASS, 8, 256, 8, 1, 3, false, false, 2, true>(a, s);
         if (nwn == 2 && p->dil == 1) return launch_patch<NPASS, 8, 256, 8, 1, 3, false, false, 2>(a, s);   // (dilated: 52 / 92 B of scratch)
         if (p->dil == 1) return launch_patch<NPASS, 8, 256, 8, 1, 3>(a, s);
