@@ -50,7 +50,7 @@ struct BnkArgs {
     const _Float16* w1f; const _Float16* w2f; const _Float16* w3f;      // fragment-major split weights
     const float* s1; const float* s2; const float* s3;                  // per-filter scales (undo the power-of-two scaling)
     const float* b1; const float* b2; const float* b3;                  // folded BatchNorm biases (b3 includes bd with a projection)
-    int H, W, x_ld, y_ld, tiles_x, tiles_y;
+    int H, W, x_ld, y_ld, tiles_x, tiles_y; OtvmTileWalk walk;
     int64_t x_bs, y_bs;                                                 // batch: image blockIdx.y
 };
 
@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256) void stm_bottleneck_f16x3_kernel(const BnkArgs
     _Float16* STG = smem + STG_OFF;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 31, fh = lane >> 5;
-    const int tile_x = blockIdx.x % p.tiles_x, tile_y = blockIdx.x / p.tiles_x;
+    int tile_n_, tile_x, tile_y;
+    otvm_tile_decode(p.walk, blockIdx.x, gridDim.x, 1, p.tiles_x, p.tiles_y, tile_n_, tile_x, tile_y);
     const int ty0 = tile_y * TH, tx0 = tile_x * TW;
 #ifdef OTVM_BNK_TIMING
     unsigned long long t_prev = wall_clock64();
@@ -481,6 +482,7 @@ extern "C" int otvm_stm_bottleneck_f16x3(const otvm_stm_bottleneck_params* q, vo
     a.s1 = q->s1; a.s2 = q->s2; a.s3 = q->s3; a.b1 = q->b1; a.b2 = q->b2; a.b3 = q->b3;
     a.H = q->H; a.W = q->W; a.x_ld = q->x_ld; a.y_ld = q->y_ld;
     a.tiles_x = otvm_ceil_div(q->W, TW); a.tiles_y = otvm_ceil_div(q->H, TH);
+    a.walk = otvm_tile_walk_of(8);
     const int batch = q->batch > 1 ? q->batch : 1;
     a.x_bs = batch > 1 ? q->x_bs : 0; a.y_bs = batch > 1 ? q->y_bs : 0;
     {

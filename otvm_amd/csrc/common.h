@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include "../../include/otvm_hip.h"
 
 void otvm_set_error(const char* fmt, ...);
@@ -44,6 +45,43 @@ static inline hipError_t otvm_reserve_lds_once(std::atomic<bool> (&done)[OTVM_MA
     e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e == hipSuccess && track) done[dev].store(true, std::memory_order_release);
     return e;
+}
+
+// ---- tile walk of the spatially tiled kernels (patch / head / stem convs, fused bottleneck; round 5).  The hardware deals
+// consecutive workgroup ids round-robin to the eight XCDs, each with an L2 of its own, so with a row-major tile order the
+// neighbours that share halo columns / rows never meet in one L2 and every shared line is fetched by several XCDs
+// (profiles/r05_tile_walk_traffic.md: the full-resolution patch tiles fetched 1.3-1.9 x their input).  walk = 1: XCD x owns a
+// contiguous range of a re-ordered tile list -- bands of `band` tile rows, column-major inside a band -- so the 64-96 workgroups
+// resident on an XCD cover a compact rectangle of tiles whose halos are fetched once.  walk = 0: row-major (A/B runs).
+// Which tile a workgroup computes changes, the arithmetic of a tile does not: results are bit-identical in either walk.
+struct OtvmTileWalk { int walk, band; };
+// family: 1 patch convs, 2 stems, 4 head conv, 8 fused bottleneck (OTVM_TILE_WALK = bit mask of the families that use walk 1).
+// Default 11: whole frame at 1080p 35.86 -> 33.31 GB of conv traffic (1.26 -> 1.17 x algorithmic), +0.2 ... 0.4 % frames/s; the
+// head conv keeps the row-major walk -- it fetches 13 % less with walk 1 but runs 1 - 5 % slower alone on the device
+static inline OtvmTileWalk otvm_tile_walk_of(int family) {
+    static const int mask = getenv("OTVM_TILE_WALK") ? atoi(getenv("OTVM_TILE_WALK")) : 11;
+    static const int band = getenv("OTVM_TILE_BAND") ? atoi(getenv("OTVM_TILE_BAND")) : 8;
+    return OtvmTileWalk{(mask & family) ? 1 : 0, band < 1 ? 1 : band};
+}
+// workgroup `bid` of `nwg` -> (tile_n, tile_x, tile_y) of a tiles_x x tiles_y map with tiles_n channel tiles per position
+// (channel tile fastest: the workgroups of one position run side by side on one XCD and share its patch in L2)
+__device__ __forceinline__ void otvm_tile_decode(OtvmTileWalk w, int bid, int nwg, int tiles_n, int tiles_x, int tiles_y, int& tile_n,
+                                                 int& tile_x, int& tile_y) {
+    if (w.walk == 0) {
+        tile_n = bid % tiles_n; bid /= tiles_n;
+        tile_x = bid % tiles_x;
+        tile_y = bid / tiles_x;
+        return;
+    }
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);     // XCD x owns a contiguous range of t
+    tile_n = t % tiles_n; t /= tiles_n;
+    const int per_band = w.band * tiles_x;
+    const int bnd = t / per_band, rem = t - bnd * per_band;
+    const int y0 = bnd * w.band;
+    const int rows = tiles_y - y0 < w.band ? tiles_y - y0 : w.band;
+    tile_x = rem / rows;
+    tile_y = y0 + (rem - tile_x * rows);
 }
 
 // compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}).  `#pragma unroll` is a

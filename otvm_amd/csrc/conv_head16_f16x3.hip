@@ -27,7 +27,7 @@ struct Head16Args {
     const float* in; const _Float16* wf; const float* wscale; const float* bias; float* out;
     int H, W, in_ld, out_ld, act;
     unsigned in_bytes;                   // size of one image's input view (buffer-resource range)
-    int tiles_x, tiles_y;
+    int tiles_x, tiles_y; OtvmTileWalk walk;
     int64_t in_bs, out_bs;
     OtvmHeadArgs head; int64_t head_img_bs, head_alpha_bs, head_tri_bs, head_sm_bs;
 };
@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256, OTVM_HEAD16_WGS) void conv_head16_f16x3_kernel
     _Float16* Pl = smem + NPIX * LDP;
     static_assert(EPI_HALFS + 2 * (N_OUT * 17 + 3) <= PATCH_HALFS, "the head's weights live behind the epilogue rows");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile_x = blockIdx.x % p.tiles_x, tile_y = blockIdx.x / p.tiles_x;
+    int tile_n_, tile_x, tile_y;
+    otvm_tile_decode(p.walk, blockIdx.x, gridDim.x, 1, p.tiles_x, p.tiles_y, tile_n_, tile_x, tile_y);
     const int ty0 = tile_y * TH, tx0 = tile_x * TW;
     // ---- what the epilogue needs from global memory, requested first: one value of the head's [N_OUT][16] weights + [N_OUT] bias
     // per thread, and the RGB of the pixel this lane finishes (lanes 0-31: the wave's first image row, 32-63: the second)
@@ -286,6 +287,7 @@ int otvm_conv2d_head16_impl(const otvm_conv_params* p, const otvm_head_params* h
     OTVM_REQUIRE((int64_t)p->H * p->W * p->in_ld * 4 < 0xFFFFFFF0ll, "otvm_conv2d_head (16-wide tile): input view beyond 32-bit offsets");
     a.in_bytes = (unsigned)((int64_t)p->H * p->W * p->in_ld * 4);
     a.tiles_x = otvm_ceil_div(p->W, TW); a.tiles_y = otvm_ceil_div(p->H, TH);
+    a.walk = otvm_tile_walk_of(4);
     const int batch = p->batch > 1 ? p->batch : 1;
     a.in_bs = batch > 1 ? p->in_bs : 0; a.out_bs = batch > 1 ? p->out_bs : 0;
     a.head.w = hd->w; a.head.b = hd->b; a.head.n_out = hd->n_out; a.head.img = hd->img; a.head.img_ld = hd->img_ld;

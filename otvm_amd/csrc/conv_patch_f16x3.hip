@@ -56,6 +56,7 @@ struct PatchArgs {
     double* gn_stats;
     int H, W, Cin, in_ld, res_ld, Cout, out_ld, n_pad32, in_relu, act;
     int tiles_x, tiles_y, tiles_n;
+    OtvmTileWalk walk;           // tile walk of the grid (common.h)
     // fused input normalisation (GroupNorm apply of the producer folded into the staging): x' = in_act(x * in_scale[c]
     // + in_shift[c]) for pixels inside the image, 0 for the conv's zero padding; nullptr = plain input
     const float* in_scale; const float* in_shift; int in_act;
@@ -181,11 +182,9 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     if (blockIdx.x >= 256 && blockIdx.x < 512)
         for (int i = 0; i < OTVM_PATCH_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
 #endif
-    // tile decode: channel tile fastest, then x, then y (neighbouring tiles share halo rows in L2)
-    int bid = blockIdx.x;
-    const int tile_n = bid % p.tiles_n; bid /= p.tiles_n;
-    const int tile_x = bid % p.tiles_x;
-    const int tile_y = bid / p.tiles_x;
+    // tile decode: channel tile fastest, then the map's tiles in the walk of common.h (XCD-aware bands by default)
+    int tile_n, tile_x, tile_y;
+    otvm_tile_decode(p.walk, blockIdx.x, gridDim.x, p.tiles_n, p.tiles_x, p.tiles_y, tile_n, tile_x, tile_y);
     const int ty0 = tile_y * TH, tx0 = tile_x * 32, n0 = tile_n * BN;
 
     f32x16 acc[TM][TN];
@@ -784,6 +783,7 @@ int launch_patch(PatchArgs& a, hipStream_t s) {
     a.tiles_x = otvm_ceil_div(a.W, 32);
     a.tiles_y = otvm_ceil_div(a.H, TH);
     a.tiles_n = otvm_ceil_div(a.Cout, BN);
+    a.walk = otvm_tile_walk_of(1);
     hipLaunchKernelGGL((conv_patch_f16x3_kernel<TH, BN, NW, DIL, TAPG, INRES, HEAD, NWN, GLDS, NPASS, M16>), dim3(a.tiles_x * a.tiles_y * a.tiles_n, a.batch), dim3(NW * 64), 0, s, a);
     OTVM_CHECK_LAUNCH("otvm_conv2d(patch f16x3)");
     return 0;

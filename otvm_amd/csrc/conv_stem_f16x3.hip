@@ -27,7 +27,7 @@ namespace {
 struct StemArgs {
     const float* in; const _Float16* wf; const float* wscale; const float* bias; float* out; double* gn_stats;
     int H, W, Cin, in_ld, Ho, Wo, Cout, out_ld, act, groups;
-    int tiles_x, tiles_y;
+    int tiles_x, tiles_y; OtvmTileWalk walk;
     int64_t in_bs, out_bs; int gn_bs;     // batch: image blockIdx.y lives *_bs elements behind image 0
     OtvmGnTail tail;                      // ABI 16: the output's GroupNorm table, written by the last workgroup (common.h)
 };
@@ -64,7 +64,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     _Float16* Pl = smem + NPIX * 8;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tile_x = blockIdx.x % p.tiles_x, tile_y = blockIdx.x / p.tiles_x;
+    int tile_n_, tile_x, tile_y;
+    otvm_tile_decode(p.walk, blockIdx.x, gridDim.x, 1, p.tiles_x, p.tiles_y, tile_n_, tile_x, tile_y);
     const int ty0 = tile_y * TH, tx0 = tile_x * TW;
     const int iy00 = 2 * ty0 - 3, ix00 = 2 * tx0 - 3;                    // input pixel of patch position (0, 0)
 
@@ -369,6 +370,7 @@ int otvm_conv2d_stem_f16x3(const otvm_conv_params* p, void* stream) {
     a.out_ld = p->out_ld; a.act = p->act; a.groups = (p->Cin + 7) / 8;
     a.tiles_x = otvm_ceil_div(p->Wo, TW);
     a.tiles_y = otvm_ceil_div(p->Ho, TH);
+    a.walk = otvm_tile_walk_of(2);
     const int batch = p->batch > 1 ? p->batch : 1;
     a.in_bs = batch > 1 ? p->in_bs : 0; a.out_bs = batch > 1 ? p->out_bs : 0; a.gn_bs = batch > 1 ? p->gn_bs : 0;
     hipLaunchKernelGGL(conv_stem_f16x3_kernel, dim3(a.tiles_x * a.tiles_y, batch), dim3(NT), 0, (hipStream_t)stream, a);

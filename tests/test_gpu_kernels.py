@@ -163,6 +163,24 @@ def test_nine_tap_patch_tiles_in_either_matrix_core_form(G, m16):
     assert r.returncode == 0 and "conv_fuzz: 40 cases" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_tile_walk_is_bit_identical(G):
+    """csrc/common.h: the spatially tiled kernels (patch convs, stems, head conv, fused bottleneck) walk their tiles in XCD-aware
+    bands by default (round 5: halo lines are fetched once per XCD L2 instead of once per neighbour).  The walk decides which
+    workgroup computes which tile, never a tile's arithmetic: row-major (OTVM_TILE_WALK=0), every family in bands of 8 and bands of
+    3 tile rows (short last bands, one and two channel tiles per position) give bit-identical outputs.  The switch is read once
+    per process, so every walk runs in a process of its own (tools/tile_walk_check.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for env in ({"OTVM_TILE_WALK": "0"}, {"OTVM_TILE_WALK": "15"}, {"OTVM_TILE_WALK": "15", "OTVM_TILE_BAND": "3"}, {}):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "tile_walk_check.py")], capture_output=True, text=True,
+                           timeout=900, env=dict(os.environ, **env))
+        assert r.returncode == 0 and "tile_walk_check: 11 outputs" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+        digests.append(r.stdout.strip().split()[-1])
+    assert len(set(digests)) == 1, digests
+
+
 def test_gn_table_tail_stress_short(G):
     """tools/gn_tail_stress.py, short form: the GroupNorm table written by a conv's LAST workgroup (common.h::
     otvm_gn_table_tail -- device-scope statistics atomics, a workgroup-scope fence, a ticket) against otvm_gn_table over the
