@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void upsample2x_bilinear_kernel(const float* _
                                                                   const float* __restrict__ in_shift, int in_act,
                                                                   const float* __restrict__ add, int add_ld,
                                                                   float* __restrict__ out, int out_ld, int64_t in_bs,
-                                                                  int64_t add_bs, int64_t out_bs, int norm_bs, int rows) {
+                                                                  int64_t add_bs, int64_t out_bs, int norm_bs) {
     {   // image blockIdx.z
         const int zb = blockIdx.z;
         in += zb * in_bs;
@@ -116,53 +116,48 @@ __global__ __launch_bounds__(256) void upsample2x_bilinear_kernel(const float* _
         if (add) add += zb * add_bs;
         if (in_scale) { in_scale += zb * norm_bs; in_shift += zb * norm_bs; }
     }
-    // A workgroup walks `rows` consecutive input rows of its columns and keeps the lower row of a cell in registers as the next
-    // cell's upper row (round 5): with one input row per workgroup every row was fetched by two workgroups on two XCDs -- the
-    // launch read 2.3 x its input (profiles/r05_kernel_traffic_gbps_1080p.md) at 6 TB/s of total traffic
     const int Q = C >> 2, Ho = 2 * Hi, Wo = 2 * Wi;
-    const int ya = blockIdx.y * rows, yb = ya + rows < Hi ? ya + rows : Hi;
+    const int y = blockIdx.y;
+    const int y1 = y + (y < Hi - 1 ? 1 : 0);
+    const float* r0 = in + (int64_t)y * Wi * in_ld;
+    const float* r1 = in + (int64_t)y1 * Wi * in_ld;
     const unsigned total = (unsigned)Wi * (unsigned)Q;
     for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const int x = (int)(i / (unsigned)Q);
         const int c = (int)(i - (unsigned)x * (unsigned)Q) * 4;
         const int x1 = x + (x < Wi - 1 ? 1 : 0);
-        f32x4 sa = {1.f, 1.f, 1.f, 1.f}, sb = {0.f, 0.f, 0.f, 0.f};
-        if (in_scale) { sa = *reinterpret_cast<const f32x4*>(in_scale + c); sb = *reinterpret_cast<const f32x4*>(in_shift + c); }
-        auto load_row = [&](int yy, f32x4& a, f32x4& b) __attribute__((always_inline)) {
-            const float* r = in + (int64_t)yy * Wi * in_ld;
-            a = *reinterpret_cast<const f32x4*>(r + (int64_t)x * in_ld + c);
-            b = *reinterpret_cast<const f32x4*>(r + (int64_t)x1 * in_ld + c);
-            if (in_scale) {
-                a = a * sa + sb; b = b * sa + sb;
+        f32x4 v00 = *reinterpret_cast<const f32x4*>(r0 + (int64_t)x * in_ld + c);
+        f32x4 v01 = *reinterpret_cast<const f32x4*>(r0 + (int64_t)x1 * in_ld + c);
+        f32x4 v10 = *reinterpret_cast<const f32x4*>(r1 + (int64_t)x * in_ld + c);
+        f32x4 v11 = *reinterpret_cast<const f32x4*>(r1 + (int64_t)x1 * in_ld + c);
+        if (in_scale) {
+            const f32x4 sa = *reinterpret_cast<const f32x4*>(in_scale + c), sb = *reinterpret_cast<const f32x4*>(in_shift + c);
+            v00 = v00 * sa + sb; v01 = v01 * sa + sb; v10 = v10 * sa + sb; v11 = v11 * sa + sb;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { a[j] = otvm_act(a[j], in_act); b[j] = otvm_act(b[j], in_act); }
+            for (int j = 0; j < 4; ++j) {
+                v00[j] = otvm_act(v00[j], in_act); v01[j] = otvm_act(v01[j], in_act);
+                v10[j] = otvm_act(v10[j], in_act); v11[j] = otvm_act(v11[j], in_act);
             }
-        };
-        f32x4 v00, v01, v10, v11;
-        load_row(ya, v10, v11);
-        for (int y = ya; y < yb; ++y) {
-            v00 = v10; v01 = v11;
-            if (y < Hi - 1) load_row(y + 1, v10, v11);
-            // output rows fed by this cell: 2y+1, 2y+2 (and 0 from the first cell), columns likewise
+        }
+        // output rows fed by this cell: 2y+1, 2y+2 (and 0 from the first cell), columns likewise
 #pragma unroll
-            for (int ry = 0; ry < 3; ++ry) {
-                const int oy = ry == 2 ? 0 : 2 * y + 1 + ry;
-                if ((ry == 2 && y != 0) || oy >= Ho) continue;
-                float fy = ((float)oy + 0.5f) * 0.5f - 0.5f;
-                fy = fy < 0.f ? 0.f : fy;
-                const float ly = fy - (float)(int)fy, hy = 1.f - ly;
+        for (int ry = 0; ry < 3; ++ry) {
+            const int oy = ry == 2 ? 0 : 2 * y + 1 + ry;
+            if ((ry == 2 && y != 0) || oy >= Ho) continue;
+            float fy = ((float)oy + 0.5f) * 0.5f - 0.5f;
+            fy = fy < 0.f ? 0.f : fy;
+            const float ly = fy - (float)(int)fy, hy = 1.f - ly;
 #pragma unroll
-                for (int rx = 0; rx < 3; ++rx) {
-                    const int ox = rx == 2 ? 0 : 2 * x + 1 + rx;
-                    if ((rx == 2 && x != 0) || ox >= Wo) continue;
-                    float fx = ((float)ox + 0.5f) * 0.5f - 0.5f;
-                    fx = fx < 0.f ? 0.f : fx;
-                    const float lx = fx - (float)(int)fx, hx = 1.f - lx;
-                    f32x4 v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
-                    const int64_t pix = (int64_t)oy * Wo + ox;
-                    if (add) v += *reinterpret_cast<const f32x4*>(add + pix * add_ld + c);
-                    *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = v;
-                }
+            for (int rx = 0; rx < 3; ++rx) {
+                const int ox = rx == 2 ? 0 : 2 * x + 1 + rx;
+                if ((rx == 2 && x != 0) || ox >= Wo) continue;
+                float fx = ((float)ox + 0.5f) * 0.5f - 0.5f;
+                fx = fx < 0.f ? 0.f : fx;
+                const float lx = fx - (float)(int)fx, hx = 1.f - lx;
+                f32x4 v = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+                const int64_t pix = (int64_t)oy * Wo + ox;
+                if (add) v += *reinterpret_cast<const f32x4*>(add + pix * add_ld + c);
+                *reinterpret_cast<f32x4*>(out + pix * out_ld + c) = v;
             }
         }
     }
@@ -286,12 +281,8 @@ extern "C" int otvm_upsample_bilinear_b(const float* in, int Hi, int Wi, int C, 
     if (x2_on && Ho == 2 * Hi && Wo == 2 * Wi && Hi >= 2 && Wi >= 2) {
         int bx2 = otvm_ceil_div(Wi * (C / 4), 256);
         if (bx2 > 64) bx2 = 64;
-        // input rows per workgroup: 4 on maps that still fill the chip with a quarter of the workgroups (OTVM_UPSAMPLE2X_ROWS: A/B runs)
-        static const int rows_env = getenv("OTVM_UPSAMPLE2X_ROWS") ? atoi(getenv("OTVM_UPSAMPLE2X_ROWS")) : 0;
-        const int64_t wgs = (int64_t)bx2 * Hi * batch;
-        const int rows = rows_env > 0 ? rows_env : (wgs >= 4096 ? 4 : (wgs >= 2048 ? 2 : 1));
-        hipLaunchKernelGGL(upsample2x_bilinear_kernel, dim3(bx2, otvm_ceil_div(Hi, rows), batch), dim3(256), 0, (hipStream_t)stream, in, Hi, Wi, C, in_ld,
-                           in_scale, in_shift, in_act, add, add_ld, out, out_ld, in_bs, add_bs, out_bs, norm_bs, rows);
+        hipLaunchKernelGGL(upsample2x_bilinear_kernel, dim3(bx2, Hi, batch), dim3(256), 0, (hipStream_t)stream, in, Hi, Wi, C, in_ld,
+                           in_scale, in_shift, in_act, add, add_ld, out, out_ld, in_bs, add_bs, out_bs, norm_bs);
         OTVM_CHECK_LAUNCH("otvm_upsample_bilinear(x2)");
         return 0;
     }
