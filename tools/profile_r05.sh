@@ -33,7 +33,7 @@ python bench.py --precision f16 --no-cpu-baseline --layer-report $O/layers_f16_1
 python bench.py --batch 2 --steps 40 --warmup 5 --no-cpu-baseline > $O/bench_1080p_batch2.json 2> $O/bench_b2.err
 python bench.py --height 480 --width 832 --batch 4 --steps 47 --warmup 3 --no-cpu-baseline > $O/bench_480p_batch4.json 2> $O/bench_480b4.err
 rm -f $O/ab_1080p.txt
-for v in "OTVM_IGEMM_GLDS=1" "OTVM_IGEMM_GLDS=0" "OTVM_IGEMM_M16=0" "OTVM_PATCH_M16=0" "OTVM_GN_PREDICT=0" "OTVM_FUSE_HEAD=0" "OTVM_IGEMM_GLDS=1"; do
+for v in "OTVM_IGEMM_GLDS=1" "OTVM_TILE_WALK=0" "OTVM_IGEMM_GLDS=0" "OTVM_IGEMM_M16=0" "OTVM_PATCH_M16=0" "OTVM_GN_PREDICT=0" "OTVM_FUSE_HEAD=0" "OTVM_TILE_WALK=0" "OTVM_IGEMM_GLDS=1"; do
   env $v python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v', round(d['value'],2), 'frames/s')" >> $O/ab_1080p.txt
 done
 (cd _old 2>/dev/null && unset OTVM_TUNE_FILE && python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('round-4 tree (2b1ccb9), same box', round(d['value'],2), 'frames/s')" >> $O/ab_1080p.txt)
