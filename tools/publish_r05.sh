@@ -14,3 +14,15 @@ cp $O/layer_roofline_1080p.md $P/${T}_layer_roofline_1080p.md; cp $O/layer_roofl
 cp $O/ab_1080p.txt $P/${T}_ab_1080p.txt
 [ -s $O/bench_4k_T200_growing.json ] && cp $O/bench_4k_T200_growing.json $P/${T}_bench_4k_T200_growing.json
 git -C $R status --short profiles | head -40
+# bench.py divides the COMMITTED conv-traffic file of the latest round into roofline.traffic; the bench line of this lease was
+# printed before this lease's own PMC passes were published, i.e. against the previous file: re-divide it from the passes of the
+# same lease (same tree, same box, same command) so the published line and the published passes agree
+python - <<'PY'
+import json, os
+P = "profiles"
+b = json.load(open(P + "/r05_bench_1gpu.json")); t = json.load(open(P + "/r05_conv_traffic_f16x3_1920x1080.json"))
+b["roofline"]["traffic"] = t["traffic_bytes_per_frame"] / b["roofline"]["launches_per_frame"]
+b["roofline"]["traffic_source"] = "profiles/r05_conv_traffic_f16x3_1920x1080.json of the same lease (tools/publish_r05.sh)"
+json.dump(b, open(P + "/r05_bench_1gpu.json", "w"))
+print("roofline.traffic = %.1f MB per launch (%.3f x algorithmic)" % (b["roofline"]["traffic"] / 1e6, b["roofline"]["traffic"] / b["roofline"]["algorithmic_bytes_per_launch"]))
+PY
