@@ -20,8 +20,6 @@
 #include <stdlib.h>
 
 #include "conv_f16x3_kernel.h"
-#include <map>
-#include <mutex>
 
 namespace {
 
@@ -505,26 +503,6 @@ static bool config_ok(const otvm_conv_params* p, int tile, int S) {
     return true;
 }
 
-// OTVM_SPLITK_FUSED=1 (experiment): the ticket words of the fused split-K finish, one zeroed array per workspace (streams that may
-// run side by side own separate workspaces, so they never share a word).  nullptr: not available -- the finish kernel runs
-constexpr int SPLITK_MAX_TICKETS = 16384;
-static unsigned* splitk_tickets_for(const void* ws, hipStream_t s) {
-    static const int on = getenv("OTVM_SPLITK_FUSED") ? atoi(getenv("OTVM_SPLITK_FUSED")) : 0;
-    if (!on) return nullptr;
-    static std::mutex mu;
-    static std::map<const void*, unsigned*> tickets;
-    std::lock_guard<std::mutex> lock(mu);
-    auto it = tickets.find(ws);
-    if (it != tickets.end()) return it->second;
-    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-    if (hipStreamIsCapturing(s, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return nullptr;   // (no allocation under capture)
-    unsigned* t = nullptr;
-    if (hipMalloc(&t, SPLITK_MAX_TICKETS * sizeof(unsigned)) != hipSuccess) return nullptr;
-    if (hipMemset(t, 0, SPLITK_MAX_TICKETS * sizeof(unsigned)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
-    tickets[ws] = t;
-    return t;
-}
-
 static int run_config(const otvm_conv_params* p, Conv3Args& a, int tile, int S, hipStream_t s) {
     if (S <= 1) return launch_tile(tile, a, s, 1);
     const int64_t M = a.M;
@@ -532,26 +510,15 @@ static int run_config(const otvm_conv_params* p, Conv3Args& a, int tile, int S, 
     Conv3Args b = a;
     b.out = (float*)p->splitk_ws; b.out_ld = ldp; b.split_stride = M * ldp; b.out_bs = (int64_t)S * M * ldp;
     b.bias = nullptr; b.residual = nullptr; b.res_scale = nullptr; b.act = OTVM_ACT_NONE; b.gn_stats = nullptr; b.tail.scale = nullptr;
-    const int g_batch = a.batch;
-    bool fused = false;
-    if (tile != T64x64W1 && (int64_t)otvm_ceil_div(M, TILE_BM(tile)) * otvm_ceil_div(p->Cout, TILE_BN(tile)) * g_batch <= SPLITK_MAX_TICKETS) {
-        if (unsigned* tk = splitk_tickets_for(p->splitk_ws, s)) {
-            b.fuse.counter = tk; b.fuse.bias = p->bias; b.fuse.residual = p->residual; b.fuse.res_scale = a.res_scale; b.fuse.out = p->out;
-            b.fuse.res_ld = p->res_ld; b.fuse.out_ld = p->out_ld; b.fuse.ldp = ldp; b.fuse.act = p->act; b.fuse.ws_bs = a.ws_bs;
-            b.fuse.rs_bs = a.rs_bs; b.fuse.out_bs = a.out_bs; b.fuse.res_bs = a.res_bs;
-            fused = true;
-        }
-    }
     const int rc = launch_tile(tile, b, s, S);
     if (rc) return rc;
-    if (!fused) {
-        int64_t blocks = (M * (ldp / 4) + 255) / 256;
-        if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)blocks, g_batch), dim3(256), 0, s, (const float*)p->splitk_ws, S,
-                           (int64_t)M * ldp, M, p->Cout, ldp, p->bias, p->residual, p->res_ld, p->act, p->out,
-                           p->out_ld, a.out_bs, a.res_bs, a.ws_bs, a.res_scale, a.rs_bs);
-        OTVM_CHECK_LAUNCH("otvm_conv2d(split-K finish)");
-    }
+    int64_t blocks = (M * (ldp / 4) + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    const int g_batch = a.batch;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((int)blocks, g_batch), dim3(256), 0, s, (const float*)p->splitk_ws, S,
+                       (int64_t)M * ldp, M, p->Cout, ldp, p->bias, p->residual, p->res_ld, p->act, p->out,
+                       p->out_ld, a.out_bs, a.res_bs, a.ws_bs, a.res_scale, a.rs_bs);
+    OTVM_CHECK_LAUNCH("otvm_conv2d(split-K finish)");
     if (p->gn_stats) {
         const int rc2 = otvm_gn_stats_b(p->out, M, p->Cout, p->out_ld, p->gn_stats, g_batch, a.out_bs, a.gn_bs, (void*)s);
         if (rc2 || !a.tail.scale) return rc2;
@@ -654,7 +621,6 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     a.in_relu = p->in_relu; a.act = p->act;
     a.M = p->Ho * p->Wo; a.taps = p->kh * p->kw; a.nchunks = p->K_pad / 32;
     a.split_stride = 0;
-    a.fuse = Conv3Args::Fuse{};                            // (counter == nullptr: no fused split-K finish)
     a.wf = (const _Float16*)p->w_wfrag;
     a.npass = p->precision == OTVM_PREC_F16 ? 1 : 3;
     a.tail = otvm_gn_tail_of(p);

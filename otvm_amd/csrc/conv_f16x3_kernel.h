@@ -75,14 +75,6 @@ struct Conv3Args {
     unsigned in_bytes;           // GLDS tiles: size of one image's input view (the buffer resource's range; < 2^31, launch3)
     int batch;                   // images of the launch (gridDim.z)
     int npass;                   // 3 = f16x3, 1 = precision "f16" (one MFMA pass on fp16-rounded operands; conv_f16x3_p1.hip)
-    // split-K with the finish inside this launch (experiment, OTVM_SPLITK_FUSED=1): counter != nullptr -> every workgroup takes a
-    // ticket for its output tile after its partial tile is written; the one that draws the last ticket adds the gridDim.y partials
-    // in the fixed order 0 .. S - 1 (the arithmetic of splitk_finish_kernel, bit for bit) and writes the finished tile
-    struct Fuse {
-        unsigned* counter;       // [batch][tiles_m * tiles_n], zero between launches (the last workgroup resets its word)
-        const float* bias; const float* residual; const float* res_scale; float* out;
-        int res_ld, out_ld, ldp, act, ws_bs, rs_bs; int64_t out_bs, res_bs;
-    } fuse;
 };
 
 // conv_f16x3_glds.hip: the LDS-DMA form of implicit-GEMM tile `base` (the enum of conv_f16x3.hip), K split over S workgroups
@@ -921,46 +913,6 @@ void conv_igemm_f16x3_kernel(const Conv3Args pa) {
         }
         __syncthreads();                                    // gred is free again: scratch of the table tail
         otvm_gn_table_tail(p.gn_stats, p.M, p.Cout, p.tail, blockIdx.z, gridDim.x * gridDim.y, reinterpret_cast<float*>(gred));
-    }
-    // ---- split-K, finish fused (see Conv3Args::Fuse).  Release: the partial tile's stores, an agent-scope fence, the ticket;
-    // acquire: the last ticket, an agent-scope fence, the loads of all S partial tiles (HIP memory model: fence-fence
-    // synchronisation through the relaxed device-scope atomic)
-    if (p.fuse.counter) {                                   // (uniform)
-        __threadfence();
-        __syncthreads();                                    // every wave's partial rows are stored and fenced; the LDS patches are free
-        unsigned* const flag = reinterpret_cast<unsigned*>(smem);
-        if (threadIdx.x == 0) {
-            unsigned* cnt = p.fuse.counter + (int64_t)blockIdx.z * gridDim.x + blockIdx.x;
-            const unsigned last = atomicAdd(cnt, 1u) == gridDim.y - 1 ? 1u : 0u;
-            if (last) atomicExch(cnt, 0u);                  // the next launch on this workspace finds zeros
-            *flag = last;
-        }
-        __syncthreads();
-        if (*flag) {
-            __threadfence();
-            const int zb = blockIdx.z, S = gridDim.y, ldp = p.fuse.ldp;
-            const float* part = p.out;                      // image zb's S partial maps (p.out was advanced by zb * out_bs)
-            const float* bias = p.fuse.bias ? p.fuse.bias + zb * p.fuse.ws_bs : nullptr;
-            const float* residual = p.fuse.residual ? p.fuse.residual + zb * p.fuse.res_bs : nullptr;
-            const float* res_scale = p.fuse.res_scale ? p.fuse.res_scale + zb * p.fuse.rs_bs : nullptr;
-            float* out = p.fuse.out + zb * p.fuse.out_bs;
-            constexpr int QN = BN / 4;
-            for (int i = threadIdx.x; i < BM * QN; i += NT) {
-                const int64_t m = m0 + i / QN;
-                const int c = n0 + (i % QN) * 4;
-                if (m >= p.M || c >= ldp) continue;
-                f32x4 v = *reinterpret_cast<const f32x4*>(part + m * ldp + c);
-                for (int z = 1; z < S; ++z) v += *reinterpret_cast<const f32x4*>(part + z * p.split_stride + m * ldp + c);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if (c + j < p.Cout) {
-                        float x = v[j] + (bias ? bias[c + j] : 0.f);
-                        if (residual) x += residual[m * p.fuse.res_ld + c + j] * (res_scale ? res_scale[c + j] : 1.f);
-                        out[m * p.fuse.out_ld + c + j] = otvm_act(x, p.fuse.act);
-                    }
-                }
-            }
-        }
     }
 }
 
