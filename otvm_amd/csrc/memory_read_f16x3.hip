@@ -88,7 +88,6 @@ struct Mem3Args {
     int hw;
     int tiles_per_slot, total_tiles, chunk_tiles;   // memory axis of this launch in 64-row tiles; tiles per workgroup
     int part0;         // index of this launch's first partial
-    int walk;          // 1: XCD-aware (query tile, chunk) walk of the grid (see the kernel)
     float* part_o;     // [partials][hw][512]
     float* part_ml;    // [partials][hw][2]
 };
@@ -101,19 +100,8 @@ __global__ __launch_bounds__(256, 2) void memory_read_f16x3_kernel(const Mem3Arg
     __shared__ float red_m[2 * BQ], red_s[2 * BQ], alpha_l[BQ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // (query tile, chunk of the memory axis) of this workgroup.  walk == 1 (round 5): the workgroups that stream one chunk sit on as
-    // few XCDs as possible -- consecutive workgroup ids go round-robin to the eight XCDs, so with the plain (query tile, chunk) grid
-    // every XCD's L2 fetched every chunk, i.e. the whole bank; here XCD x owns a contiguous range of the chunk-major list, so with
-    // c chunks only 8 / c XCDs stream a chunk.  The partial a workgroup writes is that of its (query tile, chunk) in either walk.
-    int bx = blockIdx.x, by = blockIdx.y;
-    if (p.walk) {
-        const int nq = gridDim.x, nwg = nq * gridDim.y, L = blockIdx.x + nq * blockIdx.y;
-        const int q = nwg >> 3, r = nwg & 7, xcd = L & 7;
-        const int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
-        by = t / nq; bx = t - by * nq;
-    }
-    const int q0 = bx * BQ, part = p.part0 + by;
-    const int g0 = by * p.chunk_tiles;
+    const int q0 = blockIdx.x * BQ, part = p.part0 + blockIdx.y;
+    const int g0 = blockIdx.y * p.chunk_tiles;
     const int g1 = g0 + p.chunk_tiles < p.total_tiles ? g0 + p.chunk_tiles : p.total_tiles;
     const int hw = p.hw;
 
@@ -602,8 +590,6 @@ static int mr_launch_partials(const float* q_key, int q_ld, const void* const* s
         a.total_tiles = n * a.tiles_per_slot;
         a.chunk_tiles = otvm_ceil_div(a.total_tiles, chunks);
         a.part0 = part0;
-        static const int walk = getenv("OTVM_MEMREAD_WALK") ? atoi(getenv("OTVM_MEMREAD_WALK")) : 1;
-        a.walk = walk;
         // every chunk index < chunks owns at least one tile: chunks <= total_tiles and chunk_tiles = ceil(total/chunks)
         const int used = otvm_ceil_div(a.total_tiles, a.chunk_tiles);
         // OTVM_MEMREAD_ALT=1: one 512-thread workgroup per CU, its two wave groups a segment apart (see the kernel); two chunks per
