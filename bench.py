@@ -10,8 +10,9 @@ the timed region starts.  One process per GPU; with N>1 every rank mattes its ow
 are independent, frames inside a sequence are strictly sequential -- SURVEY.md 8e), no data-path
 collective; ranks meet in one all-reduce for the timing/metric sums.  value = total frames / max time.
 
-Extra legs (rank 0, N=1): `roofline` (fp32-MFMA implicit-GEMM conv kernel: algorithmic FLOPs / HIP-event
-time per launch, instrumented replay of the timed frames on the same stream) and `cpu_baseline`
+Extra legs (rank 0, N=1): `roofline` (all convolution launches of the plan: algorithmic FLOPs / HIP-event
+time per launch, instrumented replay of the timed frames on the same stream; `traffic` = HBM-side bytes per
+launch from two short child runs of this script under `rocprofv3 --pmc`, live_conv_traffic) and `cpu_baseline`
 (the CPU oracle timed on the host cores for one steady-state frame of the same clip).
 """
 import argparse
@@ -44,6 +45,65 @@ KERNEL_NAME = {"f32": "all otvm_conv2d launches: conv_igemm_f32_kernel (v_mfma_f
                       "bottleneck and memory-read kernels keep three passes (priced as if single-pass: frac is a lower bound)"}
 DTYPE_NAME = {"f32": "f32", "f16x3": "f16x3 (fp32 operands split into fp16 hi+lo, fp32 accumulate)",
               "f16": "f16 (fp32 accumulate) -- REDUCED PRECISION, labelled mode: not the parity-graded configuration"}
+
+
+CONV_KERNELS = ("conv_igemm", "conv_patch", "conv_stem", "conv_wave", "stm_bottleneck", "splitk_finish")   # what the plan counts as a conv launch
+
+
+def live_conv_traffic(H, W, launches_per_frame, steps=8, warmup=3, timeout_s=240):
+    """HBM-side bytes per otvm_conv2d call of THIS tree on THIS box: two child runs of this script (11 frames, the parent's
+    tuned configurations) under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` with --kernel-trace only, in separate passes as
+    MI355X_MICROARCH.md prescribes; KiB -> bytes, FETCH_SIZE x 2 (gfx950) -- the arithmetic of tools/pmc_traffic.py.
+    Returns (bytes per launch, description) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="otvm_pmc_", dir="/tmp")
+    try:
+        from otvm_amd import engine as E
+        tune = os.path.join(tmp, "tune.json")
+        keep = E.TUNE_FILE
+        E.TUNE_FILE = tune
+        try:
+            E._save_tune_file()                                  # the children run the configurations this process timed
+        finally:
+            E.TUNE_FILE = keep
+        env = dict(os.environ, TMPDIR="/tmp", OTVM_TUNE_FILE=tune)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", str(warmup), "--height", str(H),
+               "--width", str(W), "--no-cpu-baseline", "--no-roofline"]
+        kib = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            r = subprocess.run([rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + cmd,
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s: rc %d, %d counter files" % (counter, r.returncode, len(files))
+            tot, rows = 0.0, 0
+            with open(files[0]) as fh:
+                for row in csv.DictReader(fh):
+                    if row["Counter_Name"] == counter and any(t in row["Kernel_Name"] for t in CONV_KERNELS):
+                        tot += float(row["Counter_Value"])
+                        rows += 1
+            if rows == 0:
+                return None, "no %s rows for the conv kernels" % counter
+            kib[counter] = tot
+        frames = steps + warmup
+        per_frame = (2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024.0 / frames
+        return per_frame / launches_per_frame, ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child runs of this command, "
+                                                "%d frames each, --kernel-trace only; KiB -> bytes, FETCH_SIZE x 2 on gfx950), "
+                                                "%.2f GB per frame / %.1f conv launches" % (frames, per_frame / 1e9, launches_per_frame))
+    except Exception as e:                                       # (a timeout, a missing tool, an unreadable file: the committed value stays)
+        return None, repr(e)[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def device_clip(H, W, T, seed, dev):
@@ -299,10 +359,21 @@ def main():
         if tpaths and args.batch <= 1:                      # the most recent round's passes (collected with one sequence per step)
             tj = json.load(open(tpaths[-1]))                # bytes of all conv kernels per frame / otvm_conv2d calls per frame
             traffic = tj["traffic_bytes_per_frame"] / (n / nrep) if "traffic_bytes_per_frame" in tj else tj.get("traffic_bytes_per_launch")
+        traffic_source = None if traffic is None else "committed PMC passes of this command: profiles/" + os.path.basename(tpaths[-1])
+        default_cfg = (args.skip == 5 and args.max_num == 5 and not args.stress_bank and not args.per_frame_report)
+        if (world == 1 and args.batch <= 1 and eng.precision_name == "f16x3" and default_cfg
+                and os.environ.get("OTVM_BENCH_LIVE_PMC", "1") != "0"):
+            # live: this run's own FETCH_SIZE / WRITE_SIZE passes (two short child runs of this script under rocprofv3, after the
+            # timed region); any failure keeps the committed value above and says so
+            live, why = live_conv_traffic(H, W, n / nrep)
+            if live is not None:
+                traffic, traffic_source = live, why
+            else:
+                traffic_source = "%s (live PMC passes not available: %s)" % (traffic_source, why)
         result["roofline"] = {
             "bound": "mfma", "kernel": KERNEL_NAME[eng.precision_name],
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-            "traffic": traffic,
+            "traffic": traffic, "traffic_source": traffic_source,
             # what the matrix cores of this chip sustain under its power limit with realistic operand values and NO memory
             # traffic (tools/probes/mfma_probe.hip, profiles/r02_mfma_power_ceiling.txt): 1598 TFLOP/s f16 = 533 f16x3;
             # informative only, `frac` above is priced against the nominal peak
