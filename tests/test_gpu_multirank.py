@@ -116,6 +116,27 @@ def test_two_ranks_on_one_gpu_through_eval_cli(tmp_path):
             assert int(np.abs(a1.astype(np.int16) - a3.astype(np.int16)).max()) <= 1, rel
 
 
+def test_bench_measures_conv_traffic_live(tmp_path):
+    """bench.py's roofline leg measures `traffic` itself (round 5): two short child runs of the same command under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` after the timed region.  Where the profiler is usable the line says "live" and
+    the bytes per conv launch sit between the algorithmic bytes and twice that; where it is not, the line must say so (a labelled
+    fallback, never a crash, never a silent constant)."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "OTVM_BENCH_LIVE_PMC"):
+        env.pop(k, None)
+    env["OTVM_TUNE_FILE"] = os.path.join(str(tmp_path), "tune.json")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                        "--height", "480", "--width", "832"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    roof = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["roofline"]
+    src = roof["traffic_source"]
+    if src is not None and src.startswith("live"):
+        ratio = roof["traffic"] / roof["algorithmic_bytes_per_launch"]
+        assert 0.9 < ratio < 2.0, (ratio, src)
+    else:
+        assert src is not None and "not available" in src, src
+
+
 def test_rccl_with_one_rank_through_bench_and_eval_cli(tmp_path):
     """RCCL itself (backend "nccl", the default) EXECUTED: a one-rank torch.distributed launch is legal on one GPU.  bench.py
     and eval_cli then initialise the process group on RCCL with the rank's device, broadcast the tuned configurations
