@@ -50,12 +50,23 @@ DTYPE_NAME = {"f32": "f32", "f16x3": "f16x3 (fp32 operands split into fp16 hi+lo
 CONV_KERNELS = ("conv_igemm", "conv_patch", "conv_stem", "conv_wave", "stm_bottleneck", "splitk_finish")   # what the plan counts as a conv launch
 
 
+def sum_conv_counter(csv_path, counter):
+    """(sum of Counter_Value, rows) over the convolution kernels' rows of one rocprofv3 counter_collection.csv"""
+    import csv
+    tot, rows = 0.0, 0
+    with open(csv_path) as fh:
+        for row in csv.DictReader(fh):
+            if row["Counter_Name"] == counter and any(t in row["Kernel_Name"] for t in CONV_KERNELS):
+                tot += float(row["Counter_Value"])
+                rows += 1
+    return tot, rows
+
+
 def live_conv_traffic(H, W, launches_per_frame, steps=8, warmup=3, timeout_s=240):
     """HBM-side bytes per otvm_conv2d call of THIS tree on THIS box: two child runs of this script (11 frames, the parent's
     tuned configurations) under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` with --kernel-trace only, in separate passes as
     MI355X_MICROARCH.md prescribes; KiB -> bytes, FETCH_SIZE x 2 (gfx950) -- the arithmetic of tools/pmc_traffic.py.
     Returns (bytes per launch, description) or (None, reason)."""
-    import csv
     import glob
     import shutil
     import subprocess
@@ -86,12 +97,7 @@ def live_conv_traffic(H, W, launches_per_frame, steps=8, warmup=3, timeout_s=240
             files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
             if r.returncode != 0 or not files:
                 return None, "rocprofv3 --pmc %s: rc %d, %d counter files" % (counter, r.returncode, len(files))
-            tot, rows = 0.0, 0
-            with open(files[0]) as fh:
-                for row in csv.DictReader(fh):
-                    if row["Counter_Name"] == counter and any(t in row["Kernel_Name"] for t in CONV_KERNELS):
-                        tot += float(row["Counter_Value"])
-                        rows += 1
+            tot, rows = sum_conv_counter(files[0], counter)
             if rows == 0:
                 return None, "no %s rows for the conv kernels" % counter
             kib[counter] = tot

@@ -419,3 +419,23 @@ def test_batch_groups_and_sharded_runner_with_batches():
     s = run_sharded(seqs, single, batch=2, matte_batch_fn=batched, key_fn=lambda sq: sq["res"])
     assert s["frames"] == 32 and sorted(s["outputs"]) == [0, 1, 2, 3, 4]
     assert sorted(calls, key=str) == sorted([("batch", [9, 7]), ("single", 5), ("batch", [8, 3])], key=str)
+
+
+def test_bench_sums_the_conv_rows_of_a_counter_file(tmp_path):
+    """bench.py::sum_conv_counter (the parser behind the live `roofline.traffic`): only the named counter, only the kernels the
+    plan counts as convolution launches; one row per (dispatch, counter) as rocprofv3 writes them."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    p = tmp_path / "f_counter_collection.csv"
+    p.write_text("Correlation_Id,Dispatch_Id,Kernel_Name,Counter_Name,Counter_Value\n"
+                 '1,1,"void (anonymous namespace)::conv_igemm_f16x3_kernel<256, 256>(Conv3Args)",FETCH_SIZE,1000\n'
+                 '2,2,"void (anonymous namespace)::conv_patch_f16x3_kernel<8, 64>(PatchArgs)",FETCH_SIZE,500.5\n'
+                 '3,3,"gn_apply_kernel(float const*)",FETCH_SIZE,77\n'
+                 '4,4,"splitk_finish_kernel(float const*)",WRITE_SIZE,9\n'
+                 '5,5,"void stm_bottleneck_f16x3_kernel<256>(BnkArgs)",FETCH_SIZE,10\n')
+    assert bench.sum_conv_counter(str(p), "FETCH_SIZE") == (1510.5, 3)
+    assert bench.sum_conv_counter(str(p), "WRITE_SIZE") == (9.0, 1)
+    assert bench.sum_conv_counter(str(p), "SQ_WAVES") == (0.0, 0)
