@@ -5,6 +5,9 @@
 
 A step = one frame of the hot path (EvalModel.forward: trimap propagation + alpha prediction + memorize)
 on a synthetic 1920x1080 clip (BASELINE.json configs[2]: T=100, memory every 5 frames, max 5 slots).
+The clip is ALWAYS BASELINE's length (100 frames at 1080p, 50 at 832x480, 200 at 4K; --clip-frames overrides): when
+warmup + steps is shorter, the clip's first frames run as an untimed lead-in and the LAST `steps` frames are timed, so the timed
+frames read a full bank (5 slots) whatever --steps says (eval.py:157-189: the loop and its memorize schedule).
 Frames are resident in HBM as fp32 BGR [1,1,3,H,W] tensors (the reference DataLoader's format) before
 the timed region starts.  One process per GPU; with N>1 every rank mattes its own sequence (sequences
 are independent, frames inside a sequence are strictly sequential -- SURVEY.md 8e), no data-path
@@ -12,7 +15,7 @@ collective; ranks meet in one all-reduce for the timing/metric sums.  value = to
 
 Extra legs (rank 0, N=1): `roofline` (all convolution launches of the plan: algorithmic FLOPs / HIP-event
 time per launch, instrumented replay of the timed frames on the same stream; `traffic` = HBM-side bytes per
-launch from two short child runs of this script under `rocprofv3 --pmc`, live_conv_traffic) and `cpu_baseline`
+launch from two short child runs of this script under `rocprofv3 --pmc`, live_traffic) and `cpu_baseline`
 (the CPU oracle timed on the host cores for one steady-state frame of the same clip).
 """
 import argparse
@@ -47,33 +50,47 @@ DTYPE_NAME = {"f32": "f32", "f16x3": "f16x3 (fp32 operands split into fp16 hi+lo
               "f16": "f16 (fp32 accumulate) -- REDUCED PRECISION, labelled mode: not the parity-graded configuration"}
 
 
-CONV_KERNELS = ("conv_igemm", "conv_patch", "conv_stem", "conv_wave", "stm_bottleneck", "splitk_finish")   # what the plan counts as a conv launch
+CONV_KERNELS = ("conv_igemm", "conv_patch", "conv_stem", "conv_head", "conv_wave", "stm_bottleneck", "splitk_finish")   # what the plan counts as a conv launch
+MEMREAD_KERNELS = ("memory_read_f16x3_kernel", "memory_read_combine", "memory_read_kernel")
+BASELINE_CLIP = {(1080, 1920): 100, (480, 832): 50, (2160, 3840): 200}      # BASELINE.json configs[2], [1], [4]: frames per clip
 
 
-def sum_conv_counter(csv_path, counter):
-    """(sum of Counter_Value, rows) over the convolution kernels' rows of one rocprofv3 counter_collection.csv"""
+def sum_conv_counter(csv_path, counter, kernels=CONV_KERNELS):
+    """(sum of Counter_Value, rows) over the rows of the kernels named in `kernels` (default: the convolution kernels) of one
+    rocprofv3 counter_collection.csv"""
     import csv
     tot, rows = 0.0, 0
     with open(csv_path) as fh:
         for row in csv.DictReader(fh):
-            if row["Counter_Name"] == counter and any(t in row["Kernel_Name"] for t in CONV_KERNELS):
+            if row["Counter_Name"] == counter and any(t in row["Kernel_Name"] for t in kernels):
                 tot += float(row["Counter_Value"])
                 rows += 1
     return tot, rows
 
 
-def live_conv_traffic(H, W, launches_per_frame, steps=8, warmup=3, timeout_s=240):
-    """HBM-side bytes per otvm_conv2d call of THIS tree on THIS box: two child runs of this script (11 frames, the parent's
-    tuned configurations) under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` with --kernel-trace only, in separate passes as
+def child_line(stdout):
+    """The JSON line a child run of this script printed (rocprofv3 writes around it)."""
+    for ln in reversed(stdout.splitlines()):
+        ln = ln.strip()
+        if ln.startswith('{"metric"'):
+            return json.loads(ln)
+    return None
+
+
+def live_traffic(H, W, extra_args=(), kernels=CONV_KERNELS, calls_key="conv_calls_total", clip=11, steps=8, warmup=3, timeout_s=100):
+    """HBM-side bytes per launch of THIS tree on THIS box: two child runs of this script (a `clip`-frame clip, the parent's tuned
+    configurations) under `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` with --kernel-trace only, in separate passes as
     MI355X_MICROARCH.md prescribes; KiB -> bytes, FETCH_SIZE x 2 (gfx950) -- the arithmetic of tools/pmc_traffic.py.
-    Returns (bytes per launch, description) or (None, reason)."""
+    The divisor is the CHILD's own count of launches (its JSON line's `calls_key`: every otvm_conv2d / fused-bottleneck / head-conv
+    call of that process, first frame and tuner launches included), so bytes and launches cover the same frames.
+    Returns (bytes per launch, description, child line) or (None, reason, None)."""
     import glob
     import shutil
     import subprocess
     import tempfile
     rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rp):
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", None
     tmp = tempfile.mkdtemp(prefix="otvm_pmc_", dir="/tmp")
     try:
         from otvm_amd import engine as E
@@ -87,27 +104,32 @@ def live_conv_traffic(H, W, launches_per_frame, steps=8, warmup=3, timeout_s=240
         env = dict(os.environ, TMPDIR="/tmp", OTVM_TUNE_FILE=tune)
         for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
             env.pop(k, None)
-        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", str(warmup), "--height", str(H),
-               "--width", str(W), "--no-cpu-baseline", "--no-roofline"]
-        kib = {}
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", str(steps), "--warmup", str(warmup), "--clip-frames", str(clip),
+               "--height", str(H), "--width", str(W), "--no-cpu-baseline", "--no-roofline"] + list(extra_args)
+        kib, calls, line = {}, None, None
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
             d = os.path.join(tmp, counter)
             r = subprocess.run([rp, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + cmd,
                                cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
             files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
             if r.returncode != 0 or not files:
-                return None, "rocprofv3 --pmc %s: rc %d, %d counter files" % (counter, r.returncode, len(files))
-            tot, rows = sum_conv_counter(files[0], counter)
+                return None, "rocprofv3 --pmc %s: rc %d, %d counter files" % (counter, r.returncode, len(files)), None
+            tot, rows = sum_conv_counter(files[0], counter, kernels)
             if rows == 0:
-                return None, "no %s rows for the conv kernels" % counter
+                return None, "no %s rows for the kernels %s" % (counter, "/".join(kernels)), None
             kib[counter] = tot
-        frames = steps + warmup
-        per_frame = (2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024.0 / frames
-        return per_frame / launches_per_frame, ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child runs of this command, "
-                                                "%d frames each, --kernel-trace only; KiB -> bytes, FETCH_SIZE x 2 on gfx950), "
-                                                "%.2f GB per frame / %.1f conv launches" % (frames, per_frame / 1e9, launches_per_frame))
+            line = child_line(r.stdout)
+            if line is None or not line.get(calls_key):
+                return None, "the child run printed no %s" % calls_key, None
+            if calls is not None and calls != line[calls_key]:
+                return None, "the two child runs issued different launch counts (%s vs %s)" % (calls, line[calls_key]), None
+            calls = line[calls_key]
+        total = (2.0 * kib["FETCH_SIZE"] + kib["WRITE_SIZE"]) * 1024.0
+        return total / calls, ("live: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate child runs of this command on a %d-frame "
+                               "clip, --kernel-trace only; KiB -> bytes, FETCH_SIZE x 2 on gfx950), %.2f GB over the %d launches the "
+                               "child itself issued (its first frame included on both sides)" % (clip, total / 1e9, calls)), line
     except Exception as e:                                       # (a timeout, a missing tool, an unreadable file: the committed value stays)
-        return None, repr(e)[:200]
+        return None, repr(e)[:200], None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -159,6 +181,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--clip-frames", type=int, default=0,
+                    help="frames of the clip (default: BASELINE's -- 100 at 1920x1080, 50 at 832x480, 200 at 3840x2160 -- and never "
+                         "fewer than warmup + steps); the LAST `steps` frames are timed, the frames in front of warmup are an untimed lead-in")
     ap.add_argument("--skip", type=int, default=5)
     ap.add_argument("--max-num", type=int, default=5)
     ap.add_argument("--precision", default=None, choices=["f32", "f16x3", "f16"],
@@ -203,7 +228,9 @@ def main():
         affinity = pin_rank_affinity(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
 
     H, W, K, Wm = args.height, args.width, args.steps, args.warmup
-    T = Wm + K                                              # frames of the clip: warm-up then timed
+    # frames of the clip: BASELINE's length; [0, lead_in) untimed lead-in, [lead_in, lead_in + Wm) warm-up, the last K timed
+    T = max(args.clip_frames if args.clip_frames > 0 else BASELINE_CLIP.get((H, W), 0), Wm + K)
+    lead_in = T - Wm - K
     from otvm_amd.synth_data import disc_trimap
     model, sd = build_model(dev, precision=args.precision)
     if dist is not None:
@@ -254,12 +281,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize(dev)
 
-    # ---- warm-up (first frame: plan build, allocations; then W-1 steady frames)
-    run_frames(0, Wm)
+    # ---- lead-in + warm-up (first frame: plan build, allocations; then steady frames): untimed
+    run_frames(0, lead_in + Wm)
     sync_all()
     host_issue[0], host_issue[1] = 0.0, 0
     t_start = time.perf_counter()
-    out = run_frames(Wm, T)
+    out = run_frames(lead_in + Wm, T)
     sync_all()
     elapsed = time.perf_counter() - t_start
     alpha_last = out[3]
@@ -292,7 +319,7 @@ def main():
     peak = PEAK_TFLOPS[eng.precision_name]
     # algorithmic FLOPs of the timed frames: convs 2.6195 MFLOP per padded pixel + the memory read
     # with the number of slots each frame ACTUALLY read (short clips spend their first 16 frames below 5 slots)
-    timed_T = [t_read[t] for t in range(Wm, T)]
+    timed_T = [t_read[t] for t in range(lead_in + Wm, T)]
     flops_frame = (2.6195e6 * Hp * Wp + 1280.0 * (sum(timed_T) / float(K)) * hw * hw) * NB     # per STEP (NB frames)
     hist = {}
     for n_ in timed_T:
@@ -302,9 +329,10 @@ def main():
         "steps": K, "warmup": Wm, "ms_per_step": 1000.0 * elapsed / K, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": DTYPE_NAME[eng.precision_name],
         "data": "synthetic",
-        "config": {"workload": ("synthetic %dx%d clip, T=%d frames (warmup %d + timed %d), %s, "
+        "lead_in_frames": lead_in,
+        "config": {"workload": ("synthetic %dx%d clip, T=%d frames (untimed lead-in %d + warmup %d + timed: the last %d), %s, "
                                 "trimap propagation + alpha + memorize per frame, one sequence per GPU" %
-                                (W, H, T, Wm, K, "EVERY frame memorised, no eviction (growing bank: build stress knob, "
+                                (W, H, T, lead_in, Wm, K, "EVERY frame memorised, no eviction (growing bank: build stress knob, "
                                  "BASELINE configs[4])" if args.stress_bank else
                                  "memory every %d, max %d slots" % (args.skip, args.max_num))),
                    "padded": [Hp, Wp], "weights": "synthetic (otvm_amd.synth_weights seed 0)",
@@ -322,6 +350,11 @@ def main():
         "algorithmic_tflop_per_frame": flops_frame / 1e12,
         "achieved_tflops_whole_frame": flops_frame / 1e12 / (elapsed / K),
         "alpha_checksum": float(alpha_last.double().mean()),
+        # launches this process issued so far (lead-in, warm-up and timed frames, tuner launches): what a parent run divides this
+        # run's PMC byte counts by (live_traffic)
+        "conv_calls_total": int(model._engine.conv_calls),
+        "memory_read_calls_total": int(sum(1 for t in t_read.values() if t > 0) * NB),
+        "memory_read_slots_total": int(sum(t_read.values()) * NB),
     }
 
     if per_rank is not None:
@@ -330,7 +363,7 @@ def main():
     if args.per_frame_report and rank == 0:
         ts = sorted(frame_ev)
         rows = [dict(frame=t, slots_read=t_read[t], ms=frame_ev[ts[i - 1]].elapsed_time(frame_ev[t]))
-                for i, t in enumerate(ts) if i > 0 and t >= Wm]
+                for i, t in enumerate(ts) if i > 0 and t >= lead_in + Wm]
         json.dump(dict(workload=result["config"]["workload"], padded=[Hp, Wp], hw=hw, frames=rows), open(args.per_frame_report, "w"), indent=0)
 
     if rank == 0 and not args.no_roofline:          # (N > 1: the other ranks wait in the final barrier)
@@ -366,17 +399,20 @@ def main():
             tj = json.load(open(tpaths[-1]))                # bytes of all conv kernels per frame / otvm_conv2d calls per frame
             traffic = tj["traffic_bytes_per_frame"] / (n / nrep) if "traffic_bytes_per_frame" in tj else tj.get("traffic_bytes_per_launch")
         traffic_source = None if traffic is None else "committed PMC passes of this command: profiles/" + os.path.basename(tpaths[-1])
+        mr_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1, _ in mr)
+        mr_dominant = bool(mr) and mr_ms > tot_ms           # (the growing bank of configs[4]: the frame IS the memory read)
         default_cfg = (args.skip == 5 and args.max_num == 5 and not args.stress_bank and not args.per_frame_report)
-        if (world == 1 and args.batch <= 1 and eng.precision_name == "f16x3" and default_cfg
-                and os.environ.get("OTVM_BENCH_LIVE_PMC", "1") != "0"):
+        live_env = os.environ.get("OTVM_BENCH_LIVE_PMC")
+        if (world == 1 and args.batch <= 1 and eng.precision_name == "f16x3" and default_cfg and not mr_dominant
+                and (live_env or "1") != "0"):
             # live: this run's own FETCH_SIZE / WRITE_SIZE passes (two short child runs of this script under rocprofv3, after the
             # timed region); any failure keeps the committed value above and says so
-            live, why = live_conv_traffic(H, W, n / nrep)
+            live, why, _ = live_traffic(H, W)
             if live is not None:
                 traffic, traffic_source = live, why
             else:
                 traffic_source = "%s (live PMC passes not available: %s)" % (traffic_source, why)
-        result["roofline"] = {
+        conv_block = {
             "bound": "mfma", "kernel": KERNEL_NAME[eng.precision_name],
             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
             "traffic": traffic, "traffic_source": traffic_source,
@@ -393,17 +429,40 @@ def main():
             "method": "torch.cuda.Event pairs on the launch stream around every otvm_conv2d launch, replay of the last "
                       "%d timed frames; FLOPs = 2*Ho*Wo*Cout*kh*kw*Cin (un-padded)" % nrep,
         }
+        mr_block = None
         if mr:
             # the memory-read contraction (north_star: >= 40 % MFMA utilisation): algorithmic FLOPs 1280*T*hw^2 over the
-            # HIP-event time of otvm_memory_read_f16x3 (kernel + combine), same replay
-            mr_ms = sum(e0.elapsed_time(e1) for _, _, e0, e1, _ in mr)
+            # HIP-event time of otvm_memory_read_f16x3 (kernel + combine), same replay.  Algorithmic bytes of one read:
+            # the bank's keys and values once (640 fp32-equivalent values per position and slot: the packed split-fp16 copy has the
+            # same size), the query key in, the 512-channel readout out
             mr_fl = float(sum(f for _, f, _, _, _ in mr))
             mr_t = mr_fl / (mr_ms * 1e-3) / 1e12
-            result["memory_read"] = {"ms_per_launch": mr_ms / len(mr), "launches": len(mr), "achieved": mr_t, "peak": peak,
-                                     "unit": "TFLOP/s", "frac": mr_t / peak,
-                                     "T_read": [int(b) for _, _, _, _, b in mr],
-                                     "note": "frac = share of the MFMA peak spent on ALGORITHMIC flops; the kernel also "
-                                             "issues the softmax rescale and padded tiles, see profiles/ for MFMA-busy"}
+            mr_T = [int(b) for _, _, _, _, b in mr]
+            mr_block = {"bound": "mfma", "kernel": "memory_read_f16x3_kernel + memory_read_combine_kernel (STM.py:140-163: softmax(K^T q / sqrt(128)) "
+                                                   "over the memory axis and the value readout, flash-style over the packed bank)",
+                        "ms_per_launch": mr_ms / len(mr), "launches": len(mr), "achieved": mr_t, "peak": peak,
+                        "unit": "TFLOP/s", "frac": mr_t / peak, "T_read": mr_T,
+                        "algorithmic_bytes_per_launch": (640.0 * sum(mr_T) / len(mr_T) + 640.0) * hw * 4.0,
+                        "traffic": None, "traffic_source": None,
+                        "note": "frac = share of the MFMA peak spent on ALGORITHMIC flops (1280 * T * hw^2 per read); the kernel also "
+                                "issues the softmax rescale and padded tiles, see profiles/ for MFMA-busy"}
+            if mr_dominant and world == 1 and args.batch <= 1 and eng.precision_name == "f16x3" and live_env == "1":
+                # opt-in (two more passes over the whole growing-bank clip under rocprofv3): HBM-side bytes per memory read
+                xa = ["--skip", str(args.skip), "--max-num", str(args.max_num)] + (["--stress-bank"] if args.stress_bank else [])
+                live, why, cl = live_traffic(H, W, extra_args=xa, kernels=MEMREAD_KERNELS, calls_key="memory_read_calls_total",
+                                             clip=T, steps=K, warmup=Wm, timeout_s=900)
+                mr_block["traffic"], mr_block["traffic_source"] = live, why
+                if cl is not None:                            # the child's population: every read of the clip (T_read = 1 .. T - 1)
+                    mr_block["traffic_population"] = {"reads": cl["memory_read_calls_total"], "mean_T_read": cl["memory_read_slots_total"] / float(cl["memory_read_calls_total"]),
+                                                      "algorithmic_bytes_per_read": (640.0 * cl["memory_read_slots_total"] / cl["memory_read_calls_total"] + 640.0) * hw * 4.0}
+        if mr_dominant:
+            # the dominant kernel of this run is the memory read: `roofline` names it, the convolutions keep their block
+            result["roofline"] = mr_block
+            result["conv_roofline"] = conv_block
+        else:
+            result["roofline"] = conv_block
+            if mr_block is not None:
+                result["memory_read"] = mr_block
 
     if rank == 0 and world == 1 and NB == 1 and eng.precision_name == "f16":
         # the labelled single-pass mode reports what it costs in accuracy: the first frames of the same clip through an f16x3 model

@@ -28,6 +28,18 @@ void otvm_set_error(const char* fmt, ...);
     } while (0)
 
 static inline int otvm_ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+// Ablation switches (tile thresholds, kernel-variant selectors, tile walks: OTVM_* names).  The shipping build compiles every one
+// of them to its default -- the library reads NO environment variable; `python otvm_amd/csrc/build.py --probes` builds
+// libotvm_hip_probes.so with -DOTVM_PROBES, where each is read from the environment once per process (A/B runs and the two tests
+// that compare kernel forms, selected with OTVM_HIP_LIB).
+#ifdef OTVM_PROBES
+static inline int64_t otvm_probe_int(const char* name, int64_t dflt) {
+    const char* v = getenv(name);
+    return v ? atoll(v) : dflt;
+}
+#else
+static constexpr inline int64_t otvm_probe_int(const char*, int64_t dflt) { return dflt; }
+#endif
 // f16x3 and its single-pass sibling "f16" share kernels, weight formats and dispatch; they differ in the MFMA passes per product
 static inline bool otvm_prec_is_split(int precision) { return precision == OTVM_PREC_F16X3 || precision == OTVM_PREC_F16; }
 
@@ -59,8 +71,8 @@ struct OtvmTileWalk { int walk, band; };
 // Default 11: whole frame at 1080p 35.86 -> 33.31 GB of conv traffic (1.26 -> 1.17 x algorithmic), +0.2 ... 0.4 % frames/s; the
 // head conv keeps the row-major walk -- it fetches 13 % less with walk 1 but runs 1 - 5 % slower alone on the device
 static inline OtvmTileWalk otvm_tile_walk_of(int family) {
-    static const int mask = getenv("OTVM_TILE_WALK") ? atoi(getenv("OTVM_TILE_WALK")) : 11;
-    static const int band = getenv("OTVM_TILE_BAND") ? atoi(getenv("OTVM_TILE_BAND")) : 8;
+    static const int mask = otvm_probe_int("OTVM_TILE_WALK", 11);
+    static const int band = otvm_probe_int("OTVM_TILE_BAND", 8);
     return OtvmTileWalk{(mask & family) ? 1 : 0, band < 1 ? 1 : band};
 }
 // workgroup `bid` of `nwg` -> (tile_n, tile_x, tile_y) of a tiles_x x tiles_y map with tiles_n channel tiles per position

@@ -535,7 +535,7 @@ int otvm_conv2d_stem_eligible(const otvm_conv_params* p);                   // c
 int otvm_conv2d_stem_f16x3(const otvm_conv_params* p, void* stream);
 
 static int glds_mode() {
-    static const int m = getenv("OTVM_IGEMM_GLDS") ? atoi(getenv("OTVM_IGEMM_GLDS")) : 1;
+    static const int m = otvm_probe_int("OTVM_IGEMM_GLDS", 1);
     return m;
 }
 // the 16x16x32 form of the LDS-DMA tiles: 2 (default) = instead of the 32x32x16 form everywhere; 1 = offered to the tuner next to
@@ -543,11 +543,11 @@ static int glds_mode() {
 // Whole frame, one box, alternating (profiles/r05_igemm_mfma16_ab.txt): 1080p 47.51 (2) / 47.36 (1) / 46.51 (0) frames/s,
 // 832x480 153.2 / 153.2 / 153.3
 static int m16_mode() {
-    static const int m = getenv("OTVM_IGEMM_M16") ? atoi(getenv("OTVM_IGEMM_M16")) : 2;
+    static const int m = otvm_probe_int("OTVM_IGEMM_M16", 2);
     return m;
 }
 static int64_t m16_min_pixels() {
-    static const int64_t v = getenv("OTVM_IGEMM_M16_MIN_PIXELS") ? atoll(getenv("OTVM_IGEMM_M16_MIN_PIXELS")) : 16384;
+    static const int64_t v = otvm_probe_int("OTVM_IGEMM_M16_MIN_PIXELS", 16384);
     return v;
 }
 
@@ -645,8 +645,8 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     }
     // ---- heuristic.  Split-K for layers that cannot fill the chip with output tiles alone (OS16/OS32 maps, the whole
     // 480p frame): 128-row tiles, the K chunks of a tile shared by up to 8 workgroups
-    static const int splitk = getenv("OTVM_SPLITK") ? atoi(getenv("OTVM_SPLITK")) : 1;
-    static const int min_total = getenv("OTVM_SPLITK_MINTOTAL") ? atoi(getenv("OTVM_SPLITK_MINTOTAL")) : 32;
+    static const int splitk = otvm_probe_int("OTVM_SPLITK", 1);
+    static const int min_total = otvm_probe_int("OTVM_SPLITK_MINTOTAL", 32);
     if (splitk && p->splitk_ws && a.nchunks >= min_total) {
         const bool wide = p->Cout > 64;
         const int64_t tiles = (int64_t)otvm_ceil_div(M, 128) * otvm_ceil_div(p->Cout, wide ? 128 : 64);
@@ -655,7 +655,7 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
         // layer at 480p / 1080p: 1024->128 3x3 at OS16 0.186 -> 0.058 ms, 1024->256 1x1 + GN 0.035 -> 0.074 ms)
         int S = (int)(384 / (tiles > 0 ? tiles : 1));
         if (S > 8) S = 8;
-        static const int min_chunks = getenv("OTVM_SPLITK_MINCHUNKS") ? atoi(getenv("OTVM_SPLITK_MINCHUNKS")) : 8;
+        static const int min_chunks = otvm_probe_int("OTVM_SPLITK_MINCHUNKS", 8);
         if (S > a.nchunks / min_chunks) S = a.nchunks / min_chunks;
         if (p->gn_stats && a.nchunks < 256 && tiles > 8) S = 1;
         const int tk = wide ? T128x128 : T128x64;
@@ -673,17 +673,17 @@ int otvm_conv2d_f16x3_impl(const otvm_conv_params* p, void* stream) {
     // OTVM_T_* override them for sweeps).
     if (config_ok(p, T256x256, 1)) {
         const int64_t huge = (int64_t)otvm_ceil_div(M, 256) * otvm_ceil_div(p->Cout, 256);
-        static const int t_huge = getenv("OTVM_T_HUGE") ? atoi(getenv("OTVM_T_HUGE")) : 256;
+        static const int t_huge = otvm_probe_int("OTVM_T_HUGE", 256);
         if (huge >= t_huge) return launch_tile(pick(T256x256), a, s, 1);
     }
     const int64_t big = (int64_t)otvm_ceil_div(M, 256) * otvm_ceil_div(p->Cout, 128);
-    static const int t_big = getenv("OTVM_T_BIG") ? atoi(getenv("OTVM_T_BIG")) : 128;
+    static const int t_big = otvm_probe_int("OTVM_T_BIG", 128);
     if (big >= t_big) return launch_tile(pick(T256x128), a, s, 1);
     const int64_t mid = (int64_t)otvm_ceil_div(M, 128) * otvm_ceil_div(p->Cout, 128);
-    static const int t_mid = getenv("OTVM_T_MID") ? atoi(getenv("OTVM_T_MID")) : 384;
+    static const int t_mid = otvm_probe_int("OTVM_T_MID", 384);
     if (mid >= t_mid) return launch_tile(pick(T128x128), a, s, 1);
     const int64_t sm = (int64_t)otvm_ceil_div(M, 128) * otvm_ceil_div(p->Cout, 64);
-    static const int t_sm = getenv("OTVM_T_SM") ? atoi(getenv("OTVM_T_SM")) : 384;
+    static const int t_sm = otvm_probe_int("OTVM_T_SM", 384);
     if (sm >= t_sm) return launch_tile(pick(T128x64), a, s, 1);
     return launch_tile(pick(T64x64), a, s, 1);
 }

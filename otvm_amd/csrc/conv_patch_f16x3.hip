@@ -811,14 +811,14 @@ extern "C" int otvm_pack_patch_weight_f16x3(const float* w_packed, int O, int K_
 static int patch_choice(const otvm_conv_params* p, bool forced = false) {
     if (!p->w_frag || p->kh != 3 || p->kw != 3 || p->stride != 1 || p->pad != p->dil || p->Cin % 16 != 0) return 0;
     if (p->dil != 1 && p->dil != 2 && p->dil != 4) return 0;
-    static const int wide = getenv("OTVM_PATCH_WIDE") ? atoi(getenv("OTVM_PATCH_WIDE")) : 1;
+    static const int wide = otvm_probe_int("OTVM_PATCH_WIDE", 1);
     if (p->Cout <= 64) return 1;
     if (!wide || p->Cout % 256 != 0) return 0;                     // wide path: 256-channel tiles, 8 waves, 3-tap weight stages
     if (forced) return 2;
     // needs enough 8x32 x 256-channel tiles to fill 256 CUs (OS4 maps at 1080p): 327 vs 285 TFLOP/s (256->256) and
     // 390 vs 348 (512->256) against the implicit-GEMM kernel.  On smaller maps the implicit-GEMM tiles win
     // (a 4x32-tile variant of this kernel measured 160-230 TFLOP/s vs 290-315 and was dropped).
-    static const int t_patch = getenv("OTVM_T_PATCH") ? atoi(getenv("OTVM_T_PATCH")) : 400;
+    static const int t_patch = otvm_probe_int("OTVM_T_PATCH", 400);
     const int64_t t8 = (int64_t)otvm_ceil_div(p->H, 8) * otvm_ceil_div(p->W, 32) * (p->Cout / 256);
     return t8 >= t_patch ? 2 : 0;
 }
@@ -870,7 +870,7 @@ int otvm_conv2d_patch_f16x3_impl(const otvm_conv_params* p, void* stream) { retu
 // round 5: the nine-tap 64-filter tiles on v_mfma_f32_16x16x32_f16 (the kernel's M16 comment); OTVM_PATCH_M16=0: the 32x32x16 form
 // (A/B runs).  One box, alternating (profiles/r05_patch_mfma16_ab.txt): 1080p 46.17 vs 45.54 frames/s, 832x480 151.6 vs 150.1
 static int patch_m16() {
-    static const int m = getenv("OTVM_PATCH_M16") ? atoi(getenv("OTVM_PATCH_M16")) : 1;
+    static const int m = otvm_probe_int("OTVM_PATCH_M16", 1);
     return m;
 }
 
@@ -914,15 +914,15 @@ static int patch_run_t(const otvm_conv_params* p, void* stream, int choice, cons
         // the eight waves as 4 x 2 (two rows x four channel tiles each) instead of 8 x 1 (one row x eight tiles): a third less
         // LDS fragment traffic per MFMA; OTVM_PATCH_WIDE_NWN=1 keeps the round-2 arrangement (same-box A/B); 2 x 4 waves (four
         // rows x two tiles) spills 108 B
-        static const int nwn = getenv("OTVM_PATCH_WIDE_NWN") ? atoi(getenv("OTVM_PATCH_WIDE_NWN")) : 2;
-        static const int glds = getenv("OTVM_PATCH_WIDE_GLDS") ? atoi(getenv("OTVM_PATCH_WIDE_GLDS")) : 1;
+        static const int nwn = otvm_probe_int("OTVM_PATCH_WIDE_NWN", 2);
+        static const int glds = otvm_probe_int("OTVM_PATCH_WIDE_GLDS", 1);
         if (nwn == 2 && p->dil == 1 && glds) return launch_patch<NPASS, 8, 256, 8, 1, 3, false, false, 2, true>(a, s);
         if (nwn == 2 && p->dil == 1) return launch_patch<NPASS, 8, 256, 8, 1, 3, false, false, 2>(a, s);   // (dilated: 52 / 92 B of scratch)
         if (p->dil == 1) return launch_patch<NPASS, 8, 256, 8, 1, 3>(a, s);
         if (p->dil == 2) return launch_patch<NPASS, 8, 256, 8, 2, 3>(a, s);
         return launch_patch<NPASS, 8, 256, 8, 4, 3>(a, s);
     }
-    static const int th16 = getenv("OTVM_PATCH_TH16") ? atoi(getenv("OTVM_PATCH_TH16")) : 0;
+    static const int th16 = otvm_probe_int("OTVM_PATCH_TH16", 0);
     if (p->dil == 1 && th16 && (int64_t)p->H * p->W >= (1 << 18))      // 16x32 pixel blocks, 8 waves: half the weight stream per pixel
         return p->Cout <= 32 ? launch_patch<NPASS, 16, 32, 8, 1>(a, s) : launch_patch<NPASS, 16, 64, 8, 1>(a, s);
     // (measured and rejected, round 2: 16x32-pixel blocks with 8 waves -- half the weight stream and less halo per pixel --
@@ -938,15 +938,15 @@ static int patch_run_t(const otvm_conv_params* p, void* stream, int choice, cons
     // LDS fragment reads per 36 MFMAs (a wave's six patch rows serve its four output rows and three taps of a filter column;
     // the compiler already shares equal fragment loads between taps): 80->32 at 1088x1920 0.429 -> 0.415 ms, 64->32 0.310 ->
     // 0.301; no gain at 480x832 (two workgroups per CU instead of three).  Two waves x four rows on 8 x 32 blocks: 0.447 / 0.320.
-    static const int rows4 = getenv("OTVM_PATCH32_ROWS4") ? atoi(getenv("OTVM_PATCH32_ROWS4")) : 1;
-    static const int glds32 = getenv("OTVM_PATCH32_GLDS") ? atoi(getenv("OTVM_PATCH32_GLDS")) : 0;   // (LDS-DMA weight stages: neutral, see below)
+    static const int rows4 = otvm_probe_int("OTVM_PATCH32_ROWS4", 1);
+    static const int glds32 = otvm_probe_int("OTVM_PATCH32_GLDS", 0);   // (LDS-DMA weight stages: neutral, see below)
     if (p->dil == 1 && p->Cout <= 32 && rows4 && (int64_t)p->H * p->W >= (1 << 20))
         return glds32 ? launch_patch<NPASS, 16, 32, 4, 1, 3, false, false, 1, true>(a, s) : launch_patch<NPASS, 16, 32, 4, 1, 3>(a, s);
     // round 5: 64 output channels with 3-tap weight stages copied by LDS-DMA into alternating buffers (as the 256-channel tiles):
     // the nine-tap stage moved 36 KiB of weights per 16 input channels through registers (9 x 16 bytes per lane + 9 ds_write_b128)
     // Measured neutral (profiles/r05_patch_narrow_glds_ab.txt: 64->64 at 1088x1920 0.548 vs 0.550 ms, 320->64 0.516 vs 0.507, 64->32
     // 0.272 vs 0.275; whole frame 45.91 vs 45.92 frames/s): the tenth variant this tile does not respond to.  Off by default.
-    static const int glds64 = getenv("OTVM_PATCH64_GLDS") ? atoi(getenv("OTVM_PATCH64_GLDS")) : 0;
+    static const int glds64 = otvm_probe_int("OTVM_PATCH64_GLDS", 0);
     if (p->dil == 1 && p->Cout > 32 && glds64) return launch_patch<NPASS, 8, 64, 4, 1, 3, false, false, 1, true>(a, s);   // (both channel tiles have weights)
     if (p->dil == 1 && p->Cout <= 32 && glds32) return launch_patch<NPASS, 8, 32, 4, 1, 3, false, false, 1, true>(a, s);
     if constexpr (NPASS == 3) {

@@ -315,7 +315,7 @@ extern "C" int otvm_trimap_encode(const float* probs, int Hp, int Wp, const uint
     // timing probes (results WRONG when set) exist in -DOTVM_PROBES builds only (tools/build_variant.sh): a release library
     // does not read OTVM_EDT_DBG
 #ifdef OTVM_PROBES
-    static const int dbg = getenv("OTVM_EDT_DBG") ? atoi(getenv("OTVM_EDT_DBG")) : 0;
+    static const int dbg = otvm_probe_int("OTVM_EDT_DBG", 0);
 #else
     constexpr int dbg = 0;
 #endif

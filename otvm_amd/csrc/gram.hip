@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void gn_predict_kernel(const PredArgs pa) {
 
 // block size: the largest of 256 / 128 / 64 that divides C (OTVM_GRAM_BS caps it: experiments)
 extern "C" int otvm_gram_block(int C) {
-    static const int cap = getenv("OTVM_GRAM_BS") ? atoi(getenv("OTVM_GRAM_BS")) : 128;   // (256: measured slower, one 512-thread workgroup per CU)
+    static const int cap = otvm_probe_int("OTVM_GRAM_BS", 128);   // (256: measured slower, one 512-thread workgroup per CU)
     if (C % 256 == 0 && cap >= 256) return 256;
     return C % 128 == 0 && cap >= 128 ? 128 : 64;
 }
@@ -425,7 +425,7 @@ extern "C" int64_t otvm_gram_entries(int C) {
 // kernels, one for the 512-thread one), 256 .. 1024 pixels each, at most 128 chunks
 extern "C" int otvm_gram_chunks(int64_t P, int C, int* pch_out) {
     const int bs = otvm_gram_block(C), nb = C / bs, nblk = nb * (nb + 1) / 2;
-    static const int wgs = getenv("OTVM_GRAM_WGS") ? atoi(getenv("OTVM_GRAM_WGS")) : 0;
+    static const int wgs = otvm_probe_int("OTVM_GRAM_WGS", 0);
     int64_t nk = (wgs > 0 ? wgs : (bs == 256 ? 192 : 384)) / nblk;
     if (nk > 128) nk = 128;
     if (nk > P / 256) nk = P / 256;

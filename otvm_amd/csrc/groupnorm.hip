@@ -172,7 +172,7 @@ extern "C" int otvm_gn_stats_b(const float* x, int64_t P, int C, int ld, double*
     int64_t blocks = (P + rows - 1) / rows;
     // every block ends with 64 fp64 atomics on the same 64 addresses: 512 blocks instead of 2048 (480p, where this pass
     // follows the split-K layers three times per frame: 146.3 -> 148.6 frames/s; 1080p unchanged)
-    static const int cap = getenv("OTVM_GN_STATS_BLOCKS") ? atoi(getenv("OTVM_GN_STATS_BLOCKS")) : 512;
+    static const int cap = otvm_probe_int("OTVM_GN_STATS_BLOCKS", 512);
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(gn_stats_kernel, dim3((int)blocks, batch), dim3(threads), 0, (hipStream_t)stream, x, P, C, ld, stats, x_bs,
                        stats_bs);

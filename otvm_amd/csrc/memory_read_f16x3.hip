@@ -308,230 +308,6 @@ __global__ __launch_bounds__(256, 2) void memory_read_f16x3_kernel(const Mem3Arg
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Round 5: the same read with ONE 512-thread workgroup per CU whose two wave groups alternate EXPLICITLY.
-//
-// The kernel above runs two independent 4-wave workgroups per CU and leaves their interleaving to the hardware: both may sit in
-// their softmax (VALU + LDS + two barriers) at the same time while the matrix pipe idles, or both in their MFMA bursts.  Here the
-// two groups of a workgroup (waves 0-3 / 4-7: one wave of each group per SIMD) take two chunks of the memory axis for the SAME 64
-// queries (the query tile is staged once) and run one segment apart, every segment boundary being a workgroup barrier:
-//        interval A: group 0 softmax(i)    | group 1 S = K Q^T (i)      (VALU / LDS beside 24 MFMAs)
-//        interval B: group 0 P V (i)       | group 1 softmax(i)         (96 MFMAs beside VALU / LDS)
-//        interval C: group 0 S (i + 1)     | group 1 P V (i)            (matrix beside matrix: the pipe is simply full)
-// -- the regime MI355X_MICROARCH.md measures ("Two waves per SIMD"): a compute segment beside a load / softmax segment, priorities
-// left at 0.  The barriers (A) and (B) the softmax needs anyway are two of the three interval boundaries.  Same arithmetic per
-// (query, chunk) as the kernel above: the partials are bit-identical, the combine kernel does not change.
-__global__ __launch_bounds__(512, 1) void memory_read_f16x3_alt_kernel(const Mem3Args p) {
-    __shared__ __attribute__((aligned(16))) _Float16 Qh[BQ * LDQH];
-    __shared__ __attribute__((aligned(16))) _Float16 Ql[BQ * LDQH];
-    __shared__ __attribute__((aligned(16))) _Float16 Ph2[2][BQ * LDPH];
-    __shared__ __attribute__((aligned(16))) _Float16 Pl2[2][BQ * LDPH];
-    __shared__ float red_m2[2][2 * BQ], red_s2[2][2 * BQ], alpha_l2[2][BQ];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6, grp = wave8 >> 2, wave = wave8 & 3;
-    const int q0 = blockIdx.x * BQ;
-    const int chunk = 2 * blockIdx.y + grp, part = p.part0 + chunk;
-    const int g0 = chunk * p.chunk_tiles;
-    const int g1 = g0 + p.chunk_tiles < p.total_tiles ? g0 + p.chunk_tiles : p.total_tiles;     // (g0 >= g1: this group has no chunk)
-    const int hw = p.hw;
-    _Float16* Ph = Ph2[grp]; _Float16* Pl = Pl2[grp];
-    float* red_m = red_m2[grp]; float* red_s = red_s2[grp]; float* alpha_l = alpha_l2[grp];
-
-    for (int i = tid; i < BQ * (DK / 4); i += 512) {
-        const int r = i / (DK / 4), c = (i - r * (DK / 4)) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (q0 + r < hw) v = *reinterpret_cast<const f32x4*>(p.q + (int64_t)(q0 + r) * p.q_ld + c);
-        f16x4 hi, lo;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { _Float16 h, lw; split1(v[j], h, lw); hi[j] = h; lo[j] = lw; }
-        *reinterpret_cast<f16x4*>(&Qh[r * LDQH + c]) = hi;
-        *reinterpret_cast<f16x4*>(&Ql[r * LDQH + c]) = lo;
-    }
-    __syncthreads();
-    float m_run = -__builtin_huge_valf(), l_run = 0.f;
-
-    f32x16 acc[2][4];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-    const int sa = wave >> 1, sb = wave & 1;
-    const int frow = lane & 31, fh = lane >> 5;
-    const float scale = 1.0f / sqrtf((float)DK);
-    const _Float16* qhp = &Qh[(sb * 32 + frow) * LDQH + 8 * fh];
-    const _Float16* qlp = &Ql[(sb * 32 + frow) * LDQH + 8 * fh];
-    const int qq = sb * 32 + frow;
-
-    // state handed from segment to segment of one tile
-    int si = g0 / p.tiles_per_slot, t = g0 - si * p.tiles_per_slot - 1;       // (seg_S pre-increments)
-    const _Float16* Vf = nullptr;
-    int kv0 = 0;
-    float v[16];
-    f16x8 vh[2][4], vl[2][4];
-
-    auto seg_S = [&]() __attribute__((always_inline)) {
-        if (++t == p.tiles_per_slot) { t = 0; ++si; }
-        const _Float16* __restrict__ Kf = p.kf[si];
-        Vf = p.vf[si];
-        kv0 = t * BKV;
-        f32x16 s, s2;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { s[e] = 0.f; s2[e] = 0.f; }
-        const _Float16* kblk = Kf + ((int64_t)(2 * t + sa) * 8 * 2) * 512 + lane * 8;
-        f16x8 kh[8], kl[8];
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            kh[ks] = *reinterpret_cast<const f16x8*>(kblk + (ks * 2) * 512);
-            kl[ks] = *reinterpret_cast<const f16x8*>(kblk + (ks * 2 + 1) * 512);
-        }
-        asm volatile("" ::: "memory");
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            const f16x8 qh = *reinterpret_cast<const f16x8*>(qhp + 16 * ks);
-            const f16x8 ql = *reinterpret_cast<const f16x8*>(qlp + 16 * ks);
-            s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[ks], qh, s2, 0, 0, 0);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[ks], qh, s, 0, 0, 0);
-            s2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[ks], ql, s2, 0, 0, 0);
-        }
-        {   // the first value fragments of the tile travel under the softmax segment
-            const _Float16* vblk = Vf + (((int64_t)(4 * t) * 16 + wave * 4) * 2) * 512 + lane * 8;
-#pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                vh[0][b] = *reinterpret_cast<const f16x8*>(vblk + (b * 2) * 512);
-                vl[0][b] = *reinterpret_cast<const f16x8*>(vblk + (b * 2 + 1) * 512);
-            }
-        }
-        s += s2;
-        const float ninf = -__builtin_huge_valf();
-        float mx = ninf;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int kvl = sa * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-            v[e] = kv0 + kvl < hw ? s[e] * scale : ninf;
-            mx = fmaxf(mx, v[e]);
-        }
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        if (fh == 0) red_m[sa * BQ + qq] = mx;
-    };
-    auto seg_SM = [&]() __attribute__((always_inline)) {
-        const float m_new = fmaxf(m_run, fmaxf(red_m[qq], red_m[BQ + qq]));
-        const float al = fast_exp(m_run - m_new);
-        float sum = 0.f;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f16x4 hi, lo;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float e = fast_exp(v[4 * g + j] - m_new);
-                sum += e;
-                _Float16 h, lw;
-                split1(e, h, lw);
-                hi[j] = h; lo[j] = lw;
-            }
-            const int kvl = sa * 32 + 8 * g + 4 * fh;
-            *reinterpret_cast<f16x4*>(&Ph[qq * LDPH + kvl]) = hi;
-            *reinterpret_cast<f16x4*>(&Pl[qq * LDPH + kvl]) = lo;
-        }
-        sum += __shfl_xor(sum, 32);
-        if (fh == 0) {
-            red_s[sa * BQ + qq] = sum;
-            if (sa == 0) alpha_l[qq] = al;
-        }
-        m_run = m_new;
-        l_run *= al;
-    };
-    auto seg_PV = [&]() __attribute__((always_inline)) {
-        l_run += red_s[qq] + red_s[BQ + qq];
-        {
-            float alr[2][16];
-            bool moved = false;
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    alr[a][e] = alpha_l[a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh];
-                    moved |= alr[a][e] != 1.f;
-                }
-            if (__any(moved)) {
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int e = 0; e < 16; ++e)
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) acc[a][b][e] *= alr[a][e];
-            }
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            f16x8 ph[2], pl[2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                ph[a] = *reinterpret_cast<const f16x8*>(&Ph[(a * 32 + frow) * LDPH + 16 * ks + 8 * fh]);
-                pl[a] = *reinterpret_cast<const f16x8*>(&Pl[(a * 32 + frow) * LDPH + 16 * ks + 8 * fh]);
-            }
-            if (ks + 1 < 4) {
-                const _Float16* vblk = Vf + (((int64_t)(4 * t + ks + 1) * 16 + wave * 4) * 2) * 512 + lane * 8;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) {
-                    vh[(ks + 1) & 1][b] = *reinterpret_cast<const f16x8*>(vblk + (b * 2) * 512);
-                    vl[(ks + 1) & 1][b] = *reinterpret_cast<const f16x8*>(vblk + (b * 2 + 1) * 512);
-                }
-                asm volatile("" ::: "memory");
-            }
-            const int vb = ks & 1;
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl[a], vh[vb][b], acc[a][b], 0, 0, 0);
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[a], vl[vb][b], acc[a][b], 0, 0, 0);
-#pragma unroll
-            for (int b = 0; b < 4; ++b)
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph[a], vh[vb][b], acc[a][b], 0, 0, 0);
-        }
-    };
-
-    // tiles of this group: [g0, g1); both groups walk p.chunk_tiles iterations so that every wave meets every barrier
-    const int nmine = g1 > g0 ? g1 - g0 : 0;
-    if (grp == 0 && nmine > 0) seg_S();
-    __syncthreads();
-    for (int i = 0; i < p.chunk_tiles; ++i) {
-        const bool live = i < nmine;                               // (wave-uniform)
-        if (live) { if (grp == 0) seg_SM(); else seg_S(); }        // interval A
-        __syncthreads();
-        if (live) { if (grp == 0) seg_PV(); else seg_SM(); }       // interval B
-        __syncthreads();
-        if (grp == 0) { if (i + 1 < nmine) seg_S(); } else if (live) seg_PV();     // interval C
-        __syncthreads();
-    }
-    if (nmine == 0) return;
-    const int dv0 = wave * 128;
-    float* po = p.part_o + ((int64_t)part * hw) * DV;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int qo = q0 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * fh;
-            if (qo < hw) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b) po[(int64_t)qo * DV + dv0 + 32 * b + frow] = acc[a][b][e];
-            }
-        }
-    if (sa == 0 && fh == 0 && q0 + sb * 32 + frow < hw) {
-        float* ml = p.part_ml + ((int64_t)part * hw + q0 + sb * 32 + frow) * 2;
-        ml[0] = m_run;
-        ml[1] = l_run;
-    }
-}
 
 }  // namespace
 
@@ -592,11 +368,7 @@ static int mr_launch_partials(const float* q_key, int q_ld, const void* const* s
         a.part0 = part0;
         // every chunk index < chunks owns at least one tile: chunks <= total_tiles and chunk_tiles = ceil(total/chunks)
         const int used = otvm_ceil_div(a.total_tiles, a.chunk_tiles);
-        // OTVM_MEMREAD_ALT=1: one 512-thread workgroup per CU, its two wave groups a segment apart (see the kernel); two chunks per
-        // workgroup.  The chunk count stays what fills 512 four-wave slots, i.e. 256 of these workgroups.
-        static const int alt = getenv("OTVM_MEMREAD_ALT") ? atoi(getenv("OTVM_MEMREAD_ALT")) : 0;
-        if (alt) hipLaunchKernelGGL(memory_read_f16x3_alt_kernel, dim3(otvm_ceil_div(hw, BQ), (used + 1) / 2), dim3(512), 0, stream, a);
-        else hipLaunchKernelGGL(memory_read_f16x3_kernel, dim3(otvm_ceil_div(hw, BQ), used), dim3(256), 0, stream, a);
+        hipLaunchKernelGGL(memory_read_f16x3_kernel, dim3(otvm_ceil_div(hw, BQ), used), dim3(256), 0, stream, a);
         part0 += used;
     }
     return part0;

@@ -277,7 +277,7 @@ extern "C" int otvm_upsample_bilinear_b(const float* in, int Hi, int Wi, int C, 
                  "otvm_upsample_bilinear: bad batch arguments");
     const float sy = (float)Hi / (float)Ho, sx = (float)Wi / (float)Wo;
     OTVM_REQUIRE(Ho <= 65535 && (int64_t)Wo * (C / 4) < (1ll << 31), "otvm_upsample_bilinear: output %dx%d too large", Ho, Wo);
-    static const int x2_on = getenv("OTVM_UPSAMPLE2X") ? atoi(getenv("OTVM_UPSAMPLE2X")) : 1;
+    static const int x2_on = otvm_probe_int("OTVM_UPSAMPLE2X", 1);
     if (x2_on && Ho == 2 * Hi && Wo == 2 * Wi && Hi >= 2 && Wi >= 2) {
         int bx2 = otvm_ceil_div(Wi * (C / 4), 256);
         if (bx2 > 64) bx2 = 64;

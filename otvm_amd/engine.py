@@ -121,27 +121,38 @@ TUNE_FILE = os.environ.get("OTVM_TUNE_FILE")
 _TUNE_FILE_LOADED = False
 
 
+# OTVM_* variables that do NOT select kernels, tiles or launch routes (everything else with that prefix does)
+_NON_VARIANT_ENV = ("OTVM_TUNE_FILE", "OTVM_DIST_BACKEND", "OTVM_TEST_FULL_F64", "OTVM_TEST_4K_ORACLE", "OTVM_BENCH_LIVE_PMC",
+                    "OTVM_BENCH_FORCE_DIAG", "OTVM_CHECK_FINITE", "OTVM_GRAPHS")
+
+
+def variant_env():
+    """The OTVM_* switches of this process that select kernel variants (engine routes; with the -DOTVM_PROBES library also tile
+    thresholds / kernel forms / tile walks), sorted."""
+    return sorted((k, v) for k, v in os.environ.items() if k.startswith("OTVM_") and k not in _NON_VARIANT_ENV)
+
+
 def kernel_config_digest():
     """16 hex digits over everything that selects kernel variants in this process: the tuned configuration of every layer shape
     AND the OTVM_* environment switches the library and the engine read (tile thresholds, kernel-variant switches such as
     OTVM_PATCH_WIDE_NWN or OTVM_IGEMM_GLDS change fp32 summation orders without passing through the tuner).  Equal
-    digests on all ranks = identical launches on all ranks."""
+    digests on all ranks = identical launches on all ranks.  (A conditioning-guard trip -- HipEngine.gn_predict_log -- rebuilds
+    that rank's plans on another route and may time new layer signatures: digests of ranks can differ afterwards.)"""
     import hashlib
-    env = sorted((k, v) for k, v in os.environ.items()
-                 if k.startswith("OTVM_") and k not in ("OTVM_TUNE_FILE", "OTVM_DIST_BACKEND", "OTVM_TEST_FULL_F64"))
-    return hashlib.sha256(repr((sorted(_TUNE_CACHE.items()), env)).encode()).hexdigest()[:16]
+    return hashlib.sha256(repr((sorted(_TUNE_CACHE.items()), variant_env())).encode()).hexdigest()[:16]
 
 
 def _tune_file_tag():
-    """What a tune file is valid for: the chip and the library ABI (choices timed on another chip, or for another set of
-    kernels, must not be applied silently)."""
+    """What a tune file is valid for: the chip, the library ABI and the kernel-variant switches of the process that timed it (a
+    tune code of 0 resolves to different kernels under different switches: choices timed under one setting must not be applied
+    silently under another -- ADVICE r5)."""
     # (not the marketing name: it comes from an ids file that is missing on some boxes and was seen to differ between two
     # processes of one box -- the ISA name and the CU count identify the chip)
     name = "none"
     if torch.cuda.is_available():
         pr = torch.cuda.get_device_properties(torch.cuda.current_device())
         name = "%s/%dcu" % (getattr(pr, "gcnArchName", "?").split(":")[0], pr.multi_processor_count)
-    return {"device": name, "abi": L.ABI_VERSION}
+    return {"device": name, "abi": L.ABI_VERSION, "variant_env": [list(kv) for kv in variant_env()]}
 
 
 def _load_tune_file():
@@ -159,6 +170,8 @@ def _load_tune_file():
         if doc.get("abi") != tag["abi"] or (tag["device"] != "none" and doc.get("device") != tag["device"]):
             raise ValueError("tuned for %r / ABI %r, this process runs %r / ABI %r"
                              % (doc.get("device"), doc.get("abi"), tag["device"], tag["abi"]))
+        if doc.get("variant_env", []) != tag["variant_env"]:
+            raise ValueError("tuned under the switches %r, this process runs under %r" % (doc.get("variant_env", []), tag["variant_env"]))
         for k, v in doc["choices"].items():
             _TUNE_CACHE[tuple(json.loads(k))] = int(v)
     except Exception as e:                                       # noqa: BLE001 -- any defect of the file means "not usable"
@@ -385,6 +398,7 @@ class HipEngine:
         self.pending = None          # deferred memorize of the previous frame
         self.ev_dec = None           # fires when the last STM decoder has read the query encoder's buffers
         self.frame_counter = 0
+        self.conv_calls = 0          # convolution launches issued by this engine (plan steps labelled "conv ", tuner launches included)
         self.last_T_read = 0
         self.parity = 0
         self.side = None
@@ -409,6 +423,7 @@ class HipEngine:
         self.use_graphs = USE_GRAPHS
         self.gn_predict_off = False   # set by predict_check: the plans are (re)built without the predicted GroupNorm tails
         self.gn_predict_log = []      # (layer, kappa, action) of every intervention of the conditioning guard
+        self.gn_predict_suspect_from = None   # frame of the current clip from which a mid-clip 'off' verdict makes alpha suspect
         self._diag_host = None
         self._diag_ev = None
         self.keep_hid_d = False      # training forward (otvm_amd/train.py): the decoder's hidden state must exist in memory
@@ -595,6 +610,10 @@ class HipEngine:
                 self.gn_predict_log.append((name, kappa, "f16x3 Gram matrix"))
                 if verdict == "ok":
                     verdict = "p3"
+        if verdict == "p3":
+            # a captured hipGraph holds the Gram kernel chosen at CAPTURE time (1-pass or 3-pass): the lists are captured again
+            # from their next use on.  The old graphs may still be executing: retired, not destroyed
+            pl.retire_graphs()
         return verdict
 
     def predict_check(self, pl, sync):
@@ -737,6 +756,7 @@ class HipEngine:
             self.pending = None
             self.reset()
             self.frame_counter = 0
+            self.gn_predict_suspect_from = None
         if frame_id is None:                                  # position in the sequence since the last first_frame
             frame_id = self.frame_counter
         self.frame_counter += 1
@@ -946,6 +966,15 @@ class HipEngine:
             # before it is returned (one synchronisation per clip) and computed again if a layer had to change its route -- the
             # bank is empty there, so the frame call is repeatable; later frames are watched without synchronising
             verdict = self.predict_check(pl, sync=first_frame)
+            if verdict == "off" and not first_frame:
+                # detected in the middle of a clip (asynchronous words, up to two check periods old): the plans are rebuilt at the
+                # next first_frame; the frames of THIS clip from `suspect` on were normalised with statistics now known to be
+                # ill-conditioned -- flagged for the caller (gn_predict_suspect_from, reset at the next first_frame), not hidden
+                import warnings
+                self.gn_predict_suspect_from = max(0, self.frame_counter - 1 - 16)
+                warnings.warn("otvm_amd: predicted GroupNorm statistics went ill-conditioned in the middle of a clip: its frames "
+                              "from %d on are suspect (engine.gn_predict_suspect_from); the rest of the clip keeps the current "
+                              "plan, the next clip runs on the accumulated route" % self.gn_predict_suspect_from)
             if first_frame and verdict != "ok" and _recheck > 0:
                 if verdict == "off":
                     self._drop_plans()                        # (rebuilt below without the predicted tails)
@@ -1032,6 +1061,8 @@ class FramePlan:
         self._bufs = {}
         self._keep = []
         self.graphs, self._graph_warm = {}, {}
+        self._n_conv = {}
+        self._retired_graphs = []
         self._fused_stats = []
         self._convs = []
         self._predicted = []                                  # (layer, otvm_gram_params, slot in self.diag) of every predicted tail
@@ -1054,6 +1085,7 @@ class FramePlan:
     def _time_conv(self, p, code, stream, reps=3):
         p.tune = code
         fn = self.lib.otvm_conv2d
+        self.e.conv_calls += 1 + reps
         L.check(fn(C.byref(p), stream), "autotune warm-up")
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
@@ -1126,6 +1158,12 @@ class FramePlan:
             t.zero_()
         self.stats.zero_()
         torch.cuda.synchronize(self.dev)
+
+    def retire_graphs(self):
+        """Forget the captured hipGraphs (a launch parameter changed): every list runs directly once more and is captured again.
+        The retired graphs stay alive with the plan -- one of them may still be executing."""
+        self._retired_graphs.extend(self.graphs.values())
+        self.graphs, self._graph_warm = {}, {}
 
     def clear_stats(self, stream):
         """Zero the GroupNorm statistics arena for the coming frame (library call on ``stream``, no ATen launch)."""
@@ -1710,6 +1748,10 @@ class FramePlan:
         frame become a handful of graph launches (host time per frame 6.8 -> 0.9 ms at 480p; no throughput change, every
         measured configuration is GPU-bound).  Opt-in: OTVM_GRAPHS=1 or engine.use_graphs = True."""
         prof = self.e.prof
+        nc = self._n_conv.get(key)
+        if nc is None:
+            nc = self._n_conv[key] = sum(1 for st in self.steps[key] if not isinstance(st[0], str) and st[2].startswith("conv "))
+        self.e.conv_calls += nc
         if prof is None and self.e.check_level >= 3:
             # first run of a new checkpoint: scan the input and the output of every convolution
             for st in self.steps[key]:
@@ -1860,6 +1902,7 @@ class FramePlan:
             self.tune_convs(self._convs[n0:])                  # shapes timed at plan time (autotune): cache hits
             slot["kv_steps"] = S
         prof = self.e.prof
+        self.e.conv_calls += len(slot["kv_steps"])
         for st in slot["kv_steps"]:
             if prof is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -242,12 +242,42 @@ def c1080_fixture():
     print(name, "bank", res["bank"].tolist(), "alpha mean %.4f" % res["alpha"].mean(), "self-noise", noise, flips)
 
 
+# Round 6: the same geometry through the STEADY read -- five frames, memory every 3, at most 3 slots, so that frames
+# 2, 3 and 4 read 2, 2 and 3 slots (alpha/model.py:472-493 over 8160 positions per slot, STM.py:148-159) in the REFERENCE itself.
+# Alpha as float32 for the last two frames (the compared quantity), per-row sums for the others, class maps as uint8.
+C1080B = ("c1080_1920x1080_s3m3", 1080, 1920, 5, "demo", 3, 3, 12, 10)
+
+
+def c1080_steady_fixture():
+    name, H, W, T, style, skip, max_num, dk, cs = C1080B
+    res = run_sequence(H, W, T, style, skip, max_num, dk, cs)
+    alt = self_noise(H, W, T, style, skip, max_num, dk, cs)
+    noise = [float(np.abs(alt["alpha"][t] - res["alpha"][t]).max()) for t in range(T)]
+    flips = [int((alt["trimap"][t].argmax(0) != res["trimap"][t].argmax(0)).sum()) for t in range(T)]
+    tri = res["trimap"]
+    keep = [T - 2, T - 1]
+    np.savez_compressed(os.path.join(HERE, "seq_%s.npz" % name), alpha_frames=np.asarray(keep),
+                        alpha=np.stack([res["alpha"][t] for t in keep]).astype(np.float32),
+                        alpha_rowsum=res["alpha"].astype(np.float64).sum(2).astype(np.float32), bank=res["bank"],
+                        trimap_cls=tri.argmax(1).astype(np.uint8), key_probe=res["key_probe"])
+    meta = dict(H=H, W=W, T=T, style=style, skip=skip, max_num=max_num, dilate_kernel=dk, clip_seed=cs, weight_seed=0,
+                bank=res["bank"].tolist(), alpha_frames=keep, reference_self_noise_alpha_maxabs=noise,
+                reference_self_noise_trimap_flips=flips)
+    path = os.path.join(HERE, "fullsize.json")
+    doc = json.load(open(path)) if os.path.exists(path) else {}
+    doc[name] = meta
+    json.dump(doc, open(path, "w"), indent=1)
+    print(name, "bank", res["bank"].tolist(), "alpha mean %.4f" % res["alpha"].mean(), "self-noise", noise, flips)
+
+
 def main():
     torch.set_num_threads(8)
     if "--c480" in sys.argv:
         return fullsize_fixture()
     if "--c1080" in sys.argv:
         return c1080_fixture()
+    if "--c1080-steady" in sys.argv:
+        return c1080_steady_fixture()
     meta = {}
     for (name, H, W, T, style, skip, max_num, dk, cs) in SEQUENCES:
         res = run_sequence(H, W, T, style, skip, max_num, dk, cs)

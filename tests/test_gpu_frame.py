@@ -181,6 +181,81 @@ def test_sequence_with_predicted_groupnorm_on_small_maps(name, ds, synth_sd, mon
             assert float(np.abs(r["out"][3][0, 0, 0].cpu().numpy() - gold["alpha"][r["t"]]).max()) <= ALPHA_TOL
 
 
+def _ill_conditioned_sd(synth_sd, blk="NET.encoder.layer2.1"):
+    """The synthetic checkpoint with ONE FBA bottleneck whose conv3 output has a GroupNorm group with |mean| >> std (see
+    test_predicted_groupnorm_falls_back_when_ill_conditioned)."""
+    sd = {k: v.clone() for k, v in synth_sd.items()}
+    planes = sd[blk + ".conv3.weight"].shape[1]
+    g = torch.Generator().manual_seed(3)
+    sd[blk + ".bn2.weight"] = torch.full((planes,), 0.05)
+    beta = torch.zeros(planes)
+    beta[:planes // 2] = 1.0
+    sd[blk + ".bn2.bias"] = beta
+    w3 = sd[blk + ".conv3.weight"]
+    cg = w3.shape[0] // 32
+    det = torch.cat([torch.ones(planes // 2), -torch.ones(planes // 2)])[None, :, None, None]
+    w3[:cg] = det * 0.05 + 0.0005 * torch.randn(cg, planes, 1, 1, generator=g)
+    sd[blk + ".conv3.weight"] = w3
+    return sd, blk
+
+
+def test_conditioning_guard_reaches_captured_graphs(synth_sd, monkeypatch):
+    """the guard switches a layer to the f16x3 Gram matrix by setting q.passes = 3 -- but a captured hipGraph holds the
+    kernel chosen at CAPTURE time.  Model A replays graphs (engine.use_graphs) and runs a whole clip with the thresholds out of
+    reach, so that its launch lists are captured with the single-pass Gram kernel; then the thresholds come back and a second clip
+    trips the guard on its first frame.  Model B never uses graphs and trips on the very first frame.  Once both have switched the
+    same layers, the second clip must be bit-identical on A and B (the graphs were retired and captured again with the 3-pass
+    kernel) and meet the contract against the oracle."""
+    from oracle.otvm_oracle import OtvmOracle
+    from otvm_amd import engine
+    from otvm_amd.synth_data import synthetic_clip
+    monkeypatch.setattr(engine, "GN_PREDICT_MIN_PIXELS", 0)
+    monkeypatch.setattr(engine, "GN_PREDICT_KAPPA_OFF", 1e30)        # (stay on the predicted route: the graph path is what is tested)
+    sd, blk = _ill_conditioned_sd(synth_sd)
+    H, W, T = 64, 96, 5
+    frames, tri = synthetic_clip(H, W, T, seed=31)
+    a, tg = torch.ones(1, 1, 1, H, W), torch.from_numpy(tri)[None, None]
+
+    def clip(m, orc=None):
+        outs = []
+        for t in range(T):
+            fg = torch.from_numpy(frames[t].astype(np.float32)).permute(2, 0, 1)[None, None].contiguous()
+            kw = dict(first_frame=(t == 0), last_frame=(t == T - 1), memorize=(t % 2 == 0), max_memory_num=3)
+            out = m(a, fg, fg.clone(), tri_gt=tg, _frame_id=t, **kw)
+            torch.cuda.synchronize()
+            outs.append(out[3].cpu().clone())
+            if orc is not None:
+                ref = orc.frame(a, fg, fg.clone(), tri_gt=tg, frame_id=t, **kw)
+                d = float((outs[-1] - ref[3]).abs().max())
+                print("graphs + guard, second clip, frame %d: alpha max-abs vs oracle %.3e" % (t, d))
+                assert d <= ALPHA_TOL, (t, d)
+        return outs
+
+    mA = _fresh_model(sd, 12)
+    engA = mA.module._get_engine()
+    engA.use_graphs = True
+    monkeypatch.setattr(engine, "GN_PREDICT_KAPPA_P3", 1e30)
+    clip(mA)                                                     # lists captured with the single-pass Gram kernel
+    plA = engA.last_plan
+    assert plA.graphs and all(q.passes == 1 for _, q, _ in plA._predicted), (len(plA.graphs), engA.gn_predict_log)
+    old_graphs = list(plA.graphs.values())
+    monkeypatch.setattr(engine, "GN_PREDICT_KAPPA_P3", 4.0)
+    gotA = clip(mA, OtvmOracle(sd, dilate_kernel=12))
+    assert engA.last_plan is plA and any(n_ == blk and q.passes == 3 for n_, q, _ in plA._predicted), engA.gn_predict_log
+    assert plA._retired_graphs and all(any(g is r for r in plA._retired_graphs) for g in old_graphs)
+    assert plA.graphs and not any(any(g is r for r in plA._retired_graphs) for g in plA.graphs.values())   # captured again
+    mB = _fresh_model(sd, 12)
+    engB = mB.module._get_engine()
+    engB.use_graphs = False
+    clip(mB)
+    gotB = clip(mB)
+    sw = lambda e: sorted(n_ for n_, q, _ in e.last_plan._predicted if q.passes == 3)
+    print("layers on the f16x3 Gram matrix: with graphs %s, without %s" % (sw(engA), sw(engB)))
+    if sw(engA) == sw(engB):
+        for t in range(T):
+            assert torch.equal(gotA[t], gotB[t]), "frame %d: the replayed graph did not run the 3-pass Gram kernel" % t
+
+
 def test_predicted_groupnorm_falls_back_when_ill_conditioned(synth_sd, monkeypatch):
     """a checkpoint whose conv3 output has a GroupNorm group with |mean| >> std.  Built here: in one FBA
     bottleneck bn2 leaves half of conv3's input channels near 1 and the other half near 0, and the 16 filters of conv3's first
@@ -193,19 +268,7 @@ def test_predicted_groupnorm_falls_back_when_ill_conditioned(synth_sd, monkeypat
     from otvm_amd import engine
     from otvm_amd.synth_data import synthetic_clip
     monkeypatch.setattr(engine, "GN_PREDICT_MIN_PIXELS", 0)
-    sd = {k: v.clone() for k, v in synth_sd.items()}
-    blk = "NET.encoder.layer2.1"
-    planes = sd[blk + ".conv3.weight"].shape[1]
-    g = torch.Generator().manual_seed(3)
-    sd[blk + ".bn2.weight"] = torch.full((planes,), 0.05)
-    beta = torch.zeros(planes)
-    beta[:planes // 2] = 1.0
-    sd[blk + ".bn2.bias"] = beta
-    w3 = sd[blk + ".conv3.weight"]
-    cg = w3.shape[0] // 32
-    det = torch.cat([torch.ones(planes // 2), -torch.ones(planes // 2)])[None, :, None, None]
-    w3[:cg] = det * 0.05 + 0.0005 * torch.randn(cg, planes, 1, 1, generator=g)
-    sd[blk + ".conv3.weight"] = w3
+    sd, blk = _ill_conditioned_sd(synth_sd)
     H, W, T = 64, 96, 3
     frames, tri = synthetic_clip(H, W, T, seed=31)
     m = _fresh_model(sd, 12)

@@ -149,17 +149,30 @@ def test_conv_fuzz_all_routes(G):
     assert r.returncode == 0 and "conv_fuzz: 80 cases" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def _probes_lib():
+    """libotvm_hip_probes.so (python otvm_amd/csrc/build.py --probes): the same kernels with -DOTVM_PROBES, i.e. the OTVM_*
+    ablation switches readable from the environment; the shipping library has them compiled to their defaults (round 6)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "otvm_amd", "libotvm_hip_probes.so")
+    if not os.path.exists(path):
+        pytest.skip("libotvm_hip_probes.so is not built (python otvm_amd/csrc/build.py --probes)")
+    return path
+
+
 @pytest.mark.parametrize("m16", ["1", "0"], ids=["mfma16x16x32", "mfma32x32x16"])
 def test_nine_tap_patch_tiles_in_either_matrix_core_form(G, m16):
     """The 64-filter patch tiles run on v_mfma_f32_16x16x32_f16 by default (round 5; planar LDS patch, tap pairs in the K = 32 of
-    one instruction, permuted accumulator rows, its own fused GroupNorm sums); OTVM_PATCH_M16=0 keeps the 32x32x16 form (A/B
+    one instruction, permuted accumulator rows, its own fused GroupNorm sums); OTVM_PATCH_M16=0 (probes library) keeps the 32x32x16 form (A/B
     runs).  The switch is read once per process: both forms are checked in processes of their own on ragged blocks, every
     dilation, 16-channel stages that do not fill a 32-channel block, bias / residual / activation / fused statistics."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if m16 != "1":                                          # (the default form needs no switch: the shipping library)
+        env.update(OTVM_HIP_LIB=_probes_lib(), OTVM_PATCH_M16=m16)
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "conv_fuzz.py"), "--n", "40", "--seed", "9", "--patch64"],
-                       capture_output=True, text=True, timeout=900, env=dict(os.environ, OTVM_PATCH_M16=m16))
+                       capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "conv_fuzz: 40 cases" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
@@ -173,7 +186,10 @@ def test_tile_walk_is_bit_identical(G):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = []
+    probes = _probes_lib()
     for env in ({"OTVM_TILE_WALK": "0"}, {"OTVM_TILE_WALK": "15"}, {"OTVM_TILE_WALK": "15", "OTVM_TILE_BAND": "3"}, {}):
+        if env:                                             # ({}: the shipping library and its compiled-in walk)
+            env = dict(env, OTVM_HIP_LIB=probes)
         r = subprocess.run([sys.executable, os.path.join(root, "tools", "tile_walk_check.py")], capture_output=True, text=True,
                            timeout=900, env=dict(os.environ, **env))
         assert r.returncode == 0 and "tile_walk_check: 11 outputs" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

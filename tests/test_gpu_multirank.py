@@ -128,7 +128,13 @@ def test_bench_measures_conv_traffic_live(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
                         "--height", "480", "--width", "832"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    roof = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])["roofline"]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    # round 6: the clip is BASELINE's length whatever --steps says (50 frames at 832x480): an untimed lead-in in front, the LAST
+    # `steps` frames timed -- all of them read a full bank
+    assert line["lead_in_frames"] == 50 - 4 - 2 and "T=50" in line["config"]["workload"], line["config"]["workload"]
+    assert line["config"]["T_read_timed_frames"]["histogram"] == {"5": 4}, line["config"]["T_read_timed_frames"]
+    assert line["conv_calls_total"] > 0 and line["memory_read_calls_total"] == 49
+    roof = line["roofline"]
     src = roof["traffic_source"]
     if src is not None and src.startswith("live"):
         ratio = roof["traffic"] / roof["algorithmic_bytes_per_launch"]

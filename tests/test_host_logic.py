@@ -104,13 +104,19 @@ def test_shard_sequences_partitions():
     assert abs(loads[0] - loads[1]) <= 4 and sum(loads) == 30      # LPT greedy: 13 vs 17
 
 
-def _worker(rank, world, port, q):
+def _seq_lengths(n):
+    """Ragged clip lengths: 5 sequences = the original case; 48 = BASELINE configs[3] (VideoMatting108 val: 48 clips of unequal
+    length -- reference dataset.py:959-1017 -- sharded one sequence per GPU)."""
+    return [3 + i for i in range(n)] if n <= 5 else [3 + (7 * i) % 11 for i in range(n)]
+
+
+def _worker(rank, world, port, q, nseq=5):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from otvm_amd.dist import run_sharded
-    seqs = [dict(frames=list(range(3 + i)), id=i) for i in range(5)]
+    seqs = [dict(frames=list(range(n)), id=i) for i, n in enumerate(_seq_lengths(nseq))]
 
     def matte(seq):                         # stand-in for the GPU path: the sharding/reduction logic is what is tested
         n = len(seq["frames"])
@@ -125,29 +131,37 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sharded_runner_two_ranks_gloo():
+@pytest.mark.parametrize("world,nseq", [(2, 5), (2, 48), (8, 48)], ids=["2ranks-5seqs", "2ranks-48seqs", "8ranks-48seqs"])
+def test_sharded_runner_ranks_gloo(world, nseq):
+    """run_sharded over real process groups (gloo on CPU): 2 ranks on the small case, and BASELINE configs[3]'s shape -- 48 ragged
+    sequences -- over 2 and over 8 ranks (the 8-GPU node's rank count; reference eval.py:42,80 runs one device per process).  Every
+    rank ends with the same SUM / MAX-reduced totals, the shards partition the sequences, and the longest-first assignment
+    keeps the ranks' frame loads within one longest clip of each other."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29500 + (os.getpid() * 7 + world * 31 + nseq) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, nseq)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=120) for _ in range(2))
+    res = sorted(q.get(timeout=240) for _ in range(world))
     for p in procs:
         p.join(60)
-    total_frames = sum(3 + i for i in range(5))
+    lengths = _seq_lengths(nseq)
+    total_frames = sum(lengths)
     for rank, frames, sad, max_abs, mine, gm in res:
         assert frames == total_frames                               # SUM all-reduce
         assert abs(sad - 0.5 * 16 * total_frames / 1000.0) < 1e-9
         assert abs(max_abs - 0.5) < 1e-12                           # MAX all-reduce
         # ground-truth metrics: pooled ratios AND the reference's per-frame / per-pair means (utils/tmp/metric.py:184-189,
-        # 252-264), reduced over both ranks
+        # 252-264), reduced over all ranks
         assert gm["frames"] == total_frames and abs(gm["sad"] - 1.0) < 1e-12 and abs(gm["mse"] - 0.2) < 1e-12
-        want_mse = sum(0.25 * (i + 1) * (3 + i) for i in range(5)) / total_frames
-        assert abs(gm["mse_mean"] - want_mse) < 1e-12
+        want_mse = sum(0.25 * (i + 1) * n for i, n in enumerate(lengths)) / total_frames
+        assert abs(gm["mse_mean"] - want_mse) < 1e-9
         assert abs(gm["dtssd_mean"] - 0.125) < 1e-12 and abs(gm["dtssd_norm_mean"] - 0.0625) < 1e-12
-    assert sorted(res[0][4] + res[1][4]) == [0, 1, 2, 3, 4]
+    assert sorted(sum((r[4] for r in res), [])) == list(range(nseq))
+    loads = [sum(lengths[i] for i in r[4]) for r in res]
+    assert max(loads) - min(loads) <= max(lengths), loads
 
 
 def test_product_does_not_import_oracle():
