@@ -40,7 +40,7 @@ extern "C" {
 #define OTVM_PREC_F16 2
 
 const char* otvm_last_error(void);
-#define OTVM_ABI_VERSION 18   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
+#define OTVM_ABI_VERSION 19   /* 2: otvm_ppm_pool_ws_bytes(H, C); 3: otvm_conv_params.in_scale/in_shift/in_act;
                                  4: otvm_conv_params.splitk_ws; 5: otvm_preprocess_params.fg_u8/bg_u8/u8_rgb;
                                  6: otvm_conv_params.tune + otvm_conv2d_candidates;
                                  7: folded GroupNorm tables on otvm_gn_apply's residual and otvm_upsample_bilinear's input;
@@ -52,6 +52,7 @@ const char* otvm_last_error(void);
                                  13: otvm_conv_params.w_wfrag + otvm_pack_wave_weight_f16x3 (one-wave 64x64 tile);
                                  14: otvm_ppm_conv_z / otvm_ppm_conv_add (the PPM branches' share of conv_up1.0 without upsampling);
                                  15: otvm_stm_bottleneck_f16x3 (one kernel per 1/4-resolution bottleneck of the STM encoders);
+                                 19: ... and per 1/8-resolution identity bottleneck (Cin = 512, otvm_stm_bottleneck_params.tile);
                                  16: otvm_conv_params.gn_gamma ... gn_counter (the GroupNorm scale / shift table of the OUTPUT
                                      written by the conv's last workgroup instead of a separate otvm_gn_table launch);
                                  17: otvm_gram_f16 / otvm_gn_predict (GroupNorm statistics of a 1x1 convolution's output predicted
@@ -213,20 +214,25 @@ int otvm_split_conv_weight_f16x3(const float* w_packed, int O, int O_pad, int K_
 int64_t otvm_wave_weight_bytes_f16x3(int O_pad, int K_pad);
 int otvm_pack_wave_weight_f16x3(const void* w_hi, const void* w_lo, int O_pad, int K_pad, void* w_wfrag, void* stream);
 
-/* One torchvision Bottleneck of the STM encoders' 1/4-resolution stage (planes = 64, stride 1, eval-mode BatchNorm folded:
- * STM.py:43-51,79-87) as ONE launch: t1 = relu(W1 x + b1), t2 = relu(W2 * t1 + b2), y = relu(W3 t2 + b3 + identity); the
- * 64-channel intermediates stay in LDS, x is read once (with a one-pixel halo), y written once.
- *   Cin = 256: identity block (identity = x).   Cin = 64: the stage's first block -- the projection Wd x is folded into the
- *   last GEMM: w3f / s3 then belong to the concatenated filter [W3 | Wd] (K = 128) and b3 = b3 + bd.
+/* One torchvision Bottleneck of the STM encoders (stride 1, eval-mode BatchNorm folded: STM.py:43-51,79-87) as ONE launch:
+ * t1 = relu(W1 x + b1), t2 = relu(W2 * t1 + b2), y = relu(W3 t2 + b3 + identity); the intermediates stay in LDS, x is read once
+ * (with a one-pixel halo), y written once.
+ *   1/4-resolution stage (planes = 64, y has 256 channels; csrc/bottleneck_f16x3.hip):
+ *     Cin = 256: identity block (identity = x).   Cin = 64: the stage's first block -- the projection Wd x is folded into the
+ *     last GEMM: w3f / s3 then belong to the concatenated filter [W3 | Wd] (K = 128) and b3 = b3 + bd.
+ *   1/8-resolution stage (ABI 19; planes = 128, y has 512 channels; csrc/bottleneck128_f16x3.hip):
+ *     Cin = 512: identity block (res3.1 - res3.3).  `tile` picks the pixel block of a workgroup: 0 = from the map size,
+ *     1 = 8 x 16, 2 = 8 x 8, 3 = 4 x 8 (every tile computes the same values; fp32 summation orders are identical too).
  *   w1f / w2f / w3f: otvm_pack_wave_weight_f16x3 of the split weights (K-major [O_pad][K_pad] from otvm_split_conv_weight_f16x3);
  *   s*: their per-filter scales; b*: folded biases.  f16x3 arithmetic (OTVM_PREC_F16X3).                                  */
 typedef struct {
     const float* x; int H, W, Cin, x_ld;            /* [H*W, Cin] view                                       */
-    float* y; int y_ld;                             /* [H*W, 256] view                                       */
+    float* y; int y_ld;                             /* [H*W, 256 | 512] view                                 */
     const void* w1f; const void* w2f; const void* w3f;
     const float* s1; const float* s2; const float* s3;
     const float* b1; const float* b2; const float* b3;
     int batch; int64_t x_bs, y_bs;                  /* images per launch, floats between consecutive images  */
+    int tile;                                       /* ABI 19: planes-128 blocks only, see above             */
 } otvm_stm_bottleneck_params;
 int otvm_stm_bottleneck_f16x3(const otvm_stm_bottleneck_params* p, void* stream);
 

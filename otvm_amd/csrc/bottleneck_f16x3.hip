@@ -470,10 +470,14 @@ extern "C" int otvm_debug_bnk_times(unsigned long long* out8, int reset) {
 }
 #endif
 
+int otvm_stm_bottleneck128_launch(const otvm_stm_bottleneck_params* q, int tile, void* stream);
+
 extern "C" int otvm_stm_bottleneck_f16x3(const otvm_stm_bottleneck_params* q, void* stream) {
     OTVM_REQUIRE(q && q->x && q->y && q->w1f && q->w2f && q->w3f && q->s1 && q->s2 && q->s3 && q->b1 && q->b2 && q->b3,
                  "otvm_stm_bottleneck_f16x3: null pointer");
-    OTVM_REQUIRE(q->Cin == 64 || q->Cin == 256, "otvm_stm_bottleneck_f16x3: Cin must be 64 (projection block) or 256 (identity block), got %d", q->Cin);
+    if (q->Cin == 512) return otvm_stm_bottleneck128_launch(q, q->tile, stream);     // planes = 128 (bottleneck128_f16x3.hip)
+    OTVM_REQUIRE(q->Cin == 64 || q->Cin == 256, "otvm_stm_bottleneck_f16x3: Cin must be 64 (projection block), 256 (identity block, planes 64) "
+                 "or 512 (identity block, planes 128), got %d", q->Cin);
     OTVM_REQUIRE(q->x_ld % 4 == 0 && q->y_ld % 4 == 0 && ((uintptr_t)q->x & 15) == 0 && ((uintptr_t)q->y & 15) == 0 &&
                  q->x_ld >= q->Cin && q->y_ld >= 256, "otvm_stm_bottleneck_f16x3: views must be 16-byte aligned");
     OTVM_REQUIRE((int64_t)q->H * q->W * q->x_ld < (1ll << 31), "otvm_stm_bottleneck_f16x3: input view too large for 32-bit offsets");

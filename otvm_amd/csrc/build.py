@@ -23,6 +23,7 @@ SOURCES = [
     ("conv_stem_f16x3.hip", []),
     ("conv_head16_f16x3.hip", []),
     ("bottleneck_f16x3.hip", []),
+    ("bottleneck128_f16x3.hip", []),
     ("groupnorm.hip", []),
     ("gram.hip", []),
     ("resample.hip", ["-ffp-contract=off"]),

@@ -62,6 +62,11 @@ FUSE_GN_TABLE = os.environ.get("OTVM_FUSE_GN_TABLE", "1") != "0"
 # round 3: each 1/4-resolution bottleneck of the STM encoders (res2.0-2, planes 64) as ONE kernel, intermediates in LDS
 # (csrc/bottleneck_f16x3.hip); f16x3 only.  0 = the three (four) convolution launches of round 2
 FUSE_STM_BLOCK = os.environ.get("OTVM_FUSE_STM_BLOCK", "1") != "0"
+# round 6 (ABI 19): the identity bottlenecks of the STM encoders' 1/8-resolution stage (res3.1 - res3.3, planes 128) as ONE kernel
+# too (csrc/bottleneck128_f16x3.hip).  Whether a block runs fused -- and on which pixel tile -- or as its three convolution
+# launches is TIMED at plan time per map size (FramePlan._resolve_stm128; cached with the conv tuner's choices).
+# OTVM_FUSE_STM_BLOCK128: 0 = never, 1 = timed (default), 2 = always (tile from the map size)
+FUSE_STM_BLOCK128 = int(os.environ.get("OTVM_FUSE_STM_BLOCK128", "1"))
 FUSE_PPM_HEAD = os.environ.get("OTVM_PPM_HEAD", "1") != "0"
 # round 4 (ABI 17): the GroupNorm statistics of conv3's OUTPUT in the FBA bottlenecks predicted from its input (channel sums +
 # Gram matrix, csrc/gram.hip), so conv3's epilogue normalises, adds the identity, applies the ReLU and writes the block output:
@@ -1063,6 +1068,7 @@ class FramePlan:
         self.graphs, self._graph_warm = {}, {}
         self._n_conv = {}
         self._retired_graphs = []
+        self._stm128 = []                                     # launch lists holding an unresolved planes-128 STM block
         self._fused_stats = []
         self._convs = []
         self._predicted = []                                  # (layer, otvm_gram_params, slot in self.diag) of every predicted tail
@@ -1127,8 +1133,65 @@ class FramePlan:
         if timed_any:
             _save_tune_file()
 
+    def _resolve_stm128(self, timed):
+        """Every planes-128 STM identity block of the plan: fused (one launch, pixel tile 1 = 8x16 / 2 = 8x8 / 3 = 4x8) or its three
+        convolution launches (0), whichever is faster on this map -- timed once per (map, batch) with the buffers holding random
+        values (autotune), cached beside the conv tuner's choices; FUSE_STM_BLOCK128 = 2 or no tuner: fused, tile from the map."""
+        stream = torch.cuda.current_stream(self.dev).cuda_stream
+        timed_any = False
+        for S in self._stm128:
+            i = 0
+            while i < len(S):
+                st = S[i]
+                if not (isinstance(st[0], str) and st[0] == "stm128"):
+                    i += 1
+                    continue
+                _, fused, U, q, name = st
+                key = (-128, q.H, q.W, max(1, q.batch), q.x_ld, q.y_ld)
+                if FUSE_STM_BLOCK128 >= 2 or not timed:
+                    choice = _TUNE_CACHE.get(key, -1) if FUSE_STM_BLOCK128 < 2 else -1
+                elif key in _TUNE_CACHE:
+                    choice = _TUNE_CACHE[key]
+                else:
+                    def run(c, reps):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        for _ in range(reps):
+                            if c == 0:
+                                for u in U:
+                                    u[0](*u[1], stream)
+                            else:
+                                q.tile = c
+                                L.check(fused[0](*fused[1], stream), name)
+                        e1.record()
+                        return e0, e1, reps
+                    self.e.conv_calls += 3 * 7 + 3 * 7                  # (counted like the conv tuner's launches)
+                    run(0, 2)
+                    timed_ = [(c,) + run(c, 3) for c in (0, 1, 2, 3, 0, 1, 2, 3)]
+                    torch.cuda.synchronize(self.dev)
+                    ms = {}
+                    for c, e0, e1, r in timed_:
+                        t = e0.elapsed_time(e1) / r
+                        ms[c] = min(ms.get(c, t), t)
+                    choice = min(ms, key=ms.get)
+                    _TUNE_CACHE[key] = choice
+                    TUNE_LOG.append((name + " (fused bottleneck: 0 = three launches, 1 / 2 / 3 = fused on 8x16 / 8x8 / 4x8 pixels)",
+                                     (q.H, q.W, 512, q.x_ld, 512, q.y_ld, 3, 3, 1, 1, 1), choice, ms))
+                    timed_any = True
+                if choice == 0:
+                    S[i:i + 1] = U
+                    i += len(U)
+                else:
+                    q.tile = max(choice, 0)                              # (-1: the library picks from the map size)
+                    S[i] = fused
+                    i += 1
+        self._stm128 = []
+        if timed_any:
+            _save_tune_file()
+
     def autotune(self):
         if not (AUTOTUNE and self.e.precision == L.PREC_F16X3):
+            self._resolve_stm128(timed=False)
             return
         # realistic operand values while timing (zero-filled operands run the matrix cores at an unrepresentative power)
         filled = []
@@ -1152,6 +1215,7 @@ class FramePlan:
         self.conv([], self.r4m, "trimap.model.KV_M_r4.Key", tk, pad=1)
         self.conv([], self.r4m, "trimap.model.KV_M_r4.Value", tv, pad=1)
         self.tune_convs(self._convs)
+        self._resolve_stm128(timed=FUSE_STM_BLOCK128 == 1)
         torch.cuda.synchronize(self.dev)
         del self._convs[n0:], self._keep[k0:]                  # scratch-bound parameter blocks: not kept
         for t in filled:
@@ -1450,7 +1514,7 @@ class FramePlan:
             q = L.StmBottleneckParams(x.ptr, x.H, x.W, x.C, x.ld, out.ptr, out.ld,
                                       c1.w_wfrag.data_ptr(), c2.w_wfrag.data_ptr(), c3.w_wfrag.data_ptr(),
                                       c1.w_scale.data_ptr(), c2.w_scale.data_ptr(), c3.w_scale.data_ptr(),
-                                      c1.bias.data_ptr(), c2.bias.data_ptr(), c3.bias.data_ptr(), x.B, x.bs, out.bs)
+                                      c1.bias.data_ptr(), c2.bias.data_ptr(), c3.bias.data_ptr(), x.B, x.bs, out.bs, 0)
             self._keep.append(q)
             P = x.B * x.H * x.W
             flops = 2 * P * (x.C * 64 + 9 * 64 * 64 + 64 * 256 + (x.C * 256 if has_ds else 0))
@@ -1458,16 +1522,36 @@ class FramePlan:
             S.append((self.lib.otvm_stm_bottleneck_f16x3, (C.byref(q),), "conv " + p + " (fused bottleneck)", flops, abytes,
                       (x, out.ch(0, 256) if out.C > 256 else out)))
             return
+        c1, c2, c3 = W[p + ".conv1"], W[p + ".conv2"], W.get(p + ".conv3")
+        fuse128 = (FUSE_STM_BLOCK128 and self.e.precision == L.PREC_F16X3 and self.e.conv_precision == L.PREC_F16X3 and planes == 128
+                   and stride == 1 and not has_ds and x.C == 512 and c3 is not None
+                   and all(c.w_wfrag is not None and c.bias is not None for c in (c1, c2, c3))
+                   and x.H * x.W * x.ld * 4 < (1 << 31))
+        U = [] if fuse128 else S                                 # the three launches (the alternative of a fused block)
         t1 = self.buf(tag + "t1", x.H, x.W, planes)
-        self.conv(S, x, p + ".conv1", t1, act=RELU)
+        self.conv(U, x, p + ".conv1", t1, act=RELU)
         t2 = self.buf(tag + "t2", Ho, Wo, planes)
-        self.conv(S, t1, p + ".conv2", t2, stride=stride, pad=1, act=RELU)
+        self.conv(U, t1, p + ".conv2", t2, stride=stride, pad=1, act=RELU)
         if has_ds:
             idt = self.buf(tag + "td", Ho, Wo, planes * 4)
-            self.conv(S, x, p + ".downsample.0", idt, stride=stride)
+            self.conv(U, x, p + ".downsample.0", idt, stride=stride)
         else:
             idt = x
-        self.conv(S, t2, p + ".conv3", out, residual=idt, act=RELU)
+        self.conv(U, t2, p + ".conv3", out, residual=idt, act=RELU)
+        if fuse128:
+            q = L.StmBottleneckParams(x.ptr, x.H, x.W, x.C, x.ld, out.ptr, out.ld,
+                                      c1.w_wfrag.data_ptr(), c2.w_wfrag.data_ptr(), c3.w_wfrag.data_ptr(),
+                                      c1.w_scale.data_ptr(), c2.w_scale.data_ptr(), c3.w_scale.data_ptr(),
+                                      c1.bias.data_ptr(), c2.bias.data_ptr(), c3.bias.data_ptr(), x.B, x.bs, out.bs, 0)
+            self._keep.append(q)
+            P = x.B * x.H * x.W
+            flops = 2 * P * (512 * 128 + 9 * 128 * 128 + 128 * 512)
+            abytes = 4 * (P * 512 * 2 + 512 * 128 * 2 + 9 * 128 * 128)
+            fused = (self.lib.otvm_stm_bottleneck_f16x3, (C.byref(q),), "conv " + p + " (fused bottleneck)", flops, abytes,
+                     (x, out.ch(0, 512) if out.C > 512 else out))
+            # resolved by _resolve_stm128 (timed at plan time): either `fused` or the launches of `U` take this place
+            S.append(("stm128", fused, U, q, p))
+            self._stm128.append(S)
 
     def stm_trunk(self, S, stem_out, e, tag):
         """maxpool + res2/res3/res4 (BN folded) of an STM encoder.  Returns r4, r3, r2."""

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("OTVM_HIP_LIB") or os.path.join(_HERE, "libotvm_hip.so
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 PREC_F32, PREC_F16X3, PREC_F16 = 0, 1, 2
-ABI_VERSION = 18         # include/otvm_hip.h OTVM_ABI_VERSION
+ABI_VERSION = 19         # include/otvm_hip.h OTVM_ABI_VERSION
 
 
 class ConvParams(C.Structure):
@@ -37,7 +37,7 @@ class ConvParams(C.Structure):
 class StmBottleneckParams(C.Structure):
     _fields_ = [("x", vp), ("H", i32), ("W", i32), ("Cin", i32), ("x_ld", i32), ("y", vp), ("y_ld", i32),
                 ("w1f", vp), ("w2f", vp), ("w3f", vp), ("s1", vp), ("s2", vp), ("s3", vp), ("b1", vp), ("b2", vp), ("b3", vp),
-                ("batch", i32), ("x_bs", i64), ("y_bs", i64)]
+                ("batch", i32), ("x_bs", i64), ("y_bs", i64), ("tile", i32)]
 
 
 class GnApplyParams(C.Structure):

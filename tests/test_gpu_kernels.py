@@ -1617,7 +1617,7 @@ def test_stm_bottleneck_fused_kernel(G, Cin, H, W):
     ob = Act(torch.full((B * bs_o + 16,), float("nan"), device=G.DEV), H, W, 256, 256, 0, B=B, bs=bs_o)
     q = L.StmBottleneckParams(xb.ptr, H, W, Cin, xb.ld, ob.ptr, ob.ld, c1.w_wfrag.data_ptr(), c2.w_wfrag.data_ptr(),
                               c3.w_wfrag.data_ptr(), c1.w_scale.data_ptr(), c2.w_scale.data_ptr(), c3.w_scale.data_ptr(),
-                              b1.data_ptr(), b2.data_ptr(), b3.data_ptr(), B, xb.bs, ob.bs)
+                              b1.data_ptr(), b2.data_ptr(), b3.data_ptr(), B, xb.bs, ob.bs, 0)
     L.check(lib.otvm_stm_bottleneck_f16x3(C.byref(q), G.stream()), "fused bottleneck")
     torch.cuda.synchronize()
     for b in range(B):
@@ -1635,11 +1635,65 @@ def test_stm_bottleneck_fused_kernel(G, Cin, H, W):
         o1 = G.empty_act(H, W, 256)
         q1 = L.StmBottleneckParams(xb.img(b).ptr, H, W, Cin, xb.ld, o1.ptr, o1.ld, c1.w_wfrag.data_ptr(), c2.w_wfrag.data_ptr(),
                                    c3.w_wfrag.data_ptr(), c1.w_scale.data_ptr(), c2.w_scale.data_ptr(), c3.w_scale.data_ptr(),
-                                   b1.data_ptr(), b2.data_ptr(), b3.data_ptr(), 1, 0, 0)
+                                   b1.data_ptr(), b2.data_ptr(), b3.data_ptr(), 1, 0, 0, 0)
         L.check(lib.otvm_stm_bottleneck_f16x3(C.byref(q1), G.stream()), "fused bottleneck, one image")
         torch.cuda.synchronize()
         assert torch.equal(o1.torch(), ob.torch(b))
     q.Cin = 128
+    assert lib.otvm_stm_bottleneck_f16x3(C.byref(q), G.stream()) != 0          # loud refusal, no fallback
+
+
+@pytest.mark.parametrize("tile", [1, 2, 3, 0], ids=["8x16", "8x8", "4x8", "auto"])
+@pytest.mark.parametrize("H,W", [(8, 16), (19, 45), (34, 60), (68, 120)])
+def test_stm_bottleneck128_fused_kernel(G, H, W, tile):
+    """otvm_stm_bottleneck_f16x3 with Cin = 512 (ABI 19, csrc/bottleneck128_f16x3.hip): an identity bottleneck of the STM encoders'
+    1/8-resolution stage (planes 128: STM.py:43-51,79-87 with torchvision's Bottleneck, BatchNorm folded) as ONE launch ==
+    relu(conv3(relu(conv2(relu(conv1 x)))) + x) against fp64 torch, on every pixel tile; sizes that are not multiples of the tiles
+    exercise the halo and the edge masks; a batched launch is image-wise identical; all tiles give the same bits."""
+    from otvm_amd import lib as L
+    from otvm_amd.engine import Act
+    lib = L.load()
+    B = 2
+    xs = [rnd(1, 512, H, W, seed=60 + b).clamp_min(0) * 1.5 for b in range(B)]          # a ReLU output, as in the network
+    w1 = rnd(128, 512, 1, 1, seed=1, scale=1.0 / math.sqrt(512))
+    w2 = rnd(128, 128, 3, 3, seed=2, scale=1.0 / math.sqrt(128 * 9))
+    w3 = rnd(512, 128, 1, 1, seed=3, scale=1.0 / math.sqrt(128))
+    sc = [rnd(n, seed=40 + i).abs() + 0.5 for i, n in enumerate((128, 128, 512))]      # folded BatchNorm scales
+    bi = [rnd(n, seed=50 + i) * 0.3 for i, n in enumerate((128, 128, 512))]
+    c1, c2, c3 = G.pack_weight(w1, scale=sc[0]), G.pack_weight(w2, scale=sc[1]), G.pack_weight(w3, scale=sc[2])
+    assert all(c.w_wfrag is not None for c in (c1, c2, c3))
+    b1, b2, b3 = (b_.to(G.DEV) for b_ in bi)
+    xb = _batched_act(G, xs)
+    bs_o = H * W * 512 + 64
+    ob = Act(torch.full((B * bs_o + 16,), float("nan"), device=G.DEV), H, W, 512, 512, 0, B=B, bs=bs_o)
+
+    def params(x, o, nb):
+        return L.StmBottleneckParams(x.ptr, H, W, 512, x.ld, o.ptr, o.ld, c1.w_wfrag.data_ptr(), c2.w_wfrag.data_ptr(),
+                                     c3.w_wfrag.data_ptr(), c1.w_scale.data_ptr(), c2.w_scale.data_ptr(), c3.w_scale.data_ptr(),
+                                     b1.data_ptr(), b2.data_ptr(), b3.data_ptr(), nb, x.bs if nb > 1 else 0, o.bs if nb > 1 else 0, tile)
+    q = params(xb, ob, B)
+    L.check(lib.otvm_stm_bottleneck_f16x3(C.byref(q), G.stream()), "fused bottleneck (planes 128)")
+    torch.cuda.synchronize()
+    for b in range(B):
+        x = xs[b].double()
+        t = F.relu(F.conv2d(x, w1.double() * sc[0].double()[:, None, None, None], bi[0].double()))
+        t = F.relu(F.conv2d(t, w2.double() * sc[1].double()[:, None, None, None], bi[1].double(), padding=1))
+        want = F.relu(F.conv2d(t, w3.double() * sc[2].double()[:, None, None, None], bi[2].double()) + x)
+        got = ob.torch(b).permute(2, 0, 1)[None].cpu().double()
+        assert torch.isfinite(got).all()
+        d = float((got - want).abs().max())
+        print("planes-128 fused bottleneck %dx%d tile %d image %d: max-abs vs fp64 %.2e of %.2e" % (H, W, tile, b, d, float(want.abs().max())))
+        assert d <= 1e-5 * max(1.0, float(want.abs().max())), (b, d)
+        # a single-image launch gives the same bits -- on THIS tile and on the 8x8 tile (the tiles differ in who computes what,
+        # not in any summation order)
+        for t2_ in (tile, 2):
+            o1 = G.empty_act(H, W, 512)
+            q1 = params(xb.img(b), o1, 1)
+            q1.tile = t2_
+            L.check(lib.otvm_stm_bottleneck_f16x3(C.byref(q1), G.stream()), "fused bottleneck (planes 128), one image")
+            torch.cuda.synchronize()
+            assert torch.equal(o1.torch(), ob.torch(b)), (b, t2_)
+    q.tile = 9
     assert lib.otvm_stm_bottleneck_f16x3(C.byref(q), G.stream()) != 0          # loud refusal, no fallback
 
 

@@ -148,6 +148,31 @@ def test_oracle_1080p_frame_pair_vs_reference(synth_sd):
             assert d <= 1e-3 and flips <= 16, (d, flips)
 
 
+def test_oracle_1080p_steady_read_vs_reference(synth_sd):
+    """Round 6: the same geometry through the STEADY memory read -- five 1920x1080 frames matted by the REFERENCE
+    itself (tests/golden/make_golden.py --c1080-steady: memory every 3, at most 3 slots, so frames 2 / 3 / 4 read 2 / 2 / 3 slots
+    of 8160 positions each: alpha/model.py:472-493, STM.py:148-159) against the oracle: per-row alpha sums on every frame, the
+    full alpha of the last two.  ~5 min of CPU."""
+    import json
+    meta = json.load(open(os.path.join(GOLDEN, "fullsize.json")))["c1080_1920x1080_s3m3"]
+    gold = load_golden("c1080_1920x1080_s3m3")
+    keep = [int(t) for t in gold["alpha_frames"]]
+    assert [int(b) for b in gold["bank"]] == [1, 2, 2, 3, 3]                # slots resident AFTER each frame: frame 4 reads 3
+    orc = O.OtvmOracle(synth_sd, dilate_kernel=meta["dilate_kernel"])
+    for t, (a, fg, bg, tri_gt) in enumerate(clip_inputs(meta)):
+        out = orc.frame(a, fg, bg, tri_gt=tri_gt, frame_id=t, **frame_flags(meta, t))
+        assert len(orc.bank) == gold["bank"][t]
+        alpha = out[3][0, 0, 0].numpy()
+        flips = int((out[1][0, 0].numpy().argmax(0) != gold["trimap_cls"][t]).sum())
+        ds = float(np.abs(alpha.astype(np.float64).sum(1) - gold["alpha_rowsum"][t]).max())
+        assert ds <= 0.05 and flips <= 16, (t, ds, flips)
+        if t in keep:
+            d = float(np.abs(alpha - gold["alpha"][keep.index(t)]).max())
+            print("c1080 steady t=%d alpha %.2e row sums %.2e class flips %d (reference's own reorder noise: %.1e, %d flips)"
+                  % (t, d, ds, flips, meta["reference_self_noise_alpha_maxabs"][t], meta["reference_self_noise_trimap_flips"][t]))
+            assert d <= 1e-3, (t, d)
+
+
 def test_oracle_stages_vs_reference(synth_sd):
     """Per-stage tensors of two consecutive frames (reference forward hooks) against the oracle's captures."""
     from otvm_amd.synth_data import synthetic_clip
