@@ -45,6 +45,9 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #ifndef OTVM_PABL_MFMA16
 #define OTVM_PABL_MFMA16 0     // every MFMA of the 32x32x16 forms replaced by two 16x16x32 on the same fragments (what the instruction
 #endif                         // alone is worth on a tile before a real 16x16x32 form exists: profiles/r05_patch_wide_mfma16_ab.txt)
+#ifndef OTVM_PATCH_NO_LEAN
+#define OTVM_PATCH_NO_LEAN 0   // (A/B build, results right) M16 tiles on the generic staging code of round 5
+#endif
 #ifndef OTVM_PM16_NOKXP
 #define OTVM_PM16_NOKXP 0      // (A/B build, results right) M16 tiles: taps paired (t, t + 1) on every dilation
 #endif
@@ -212,7 +215,58 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     __amdgpu_buffer_rsrc_t in_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.in, 0, p.in_bytes, 0x00020000);
     __amdgpu_buffer_rsrc_t res_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(INRES ? p.in_res : p.in), 0, INRES ? p.in_res_bytes : 0, 0x00020000);
+    // ---- round 6: lean staging of the nine-tap 16x16x32 tiles (LEAN).  The generic staging below recomputes, per stage and per
+    // element, everything that does not depend on the stage -- patch coordinates (a division by PW), the image test, the LDS
+    // address, the weight piece's place -- and tests its run-time switches (in_scale, in_relu, in_act) per element: ~1200 non-MFMA
+    // instructions (525 VALU, 287 SALU, 183 branches) beside the 224 MFMAs of a stage in the 64-filter tile's ISA, i.e. more issue
+    // time than the MFMAs themselves (profiles/r05_patch64_sq_counters_m16.md: 51 % issue stalls).  Here the per-thread offsets
+    // are computed ONCE: a stage's loads are NP buffer loads (register offset + a scalar channel offset) and NB weight loads
+    // (scalar base + register offset), the normalisation is ONE uniform branch per stage around branch-free arithmetic
+    // (activation as max(v, 0) + slope min(v, 0): the same values as otvm_act), the LDS addresses are one register + immediates.
+    constexpr bool LEAN = M16 && !INRES && !OTVM_PATCH_NO_LEAN;
+    unsigned l_voff[LEAN ? NP : 1];                                    // byte offset of element k's quad in channel block 0; 0xFFFFFFFF = outside the image / patch
+                                                                       // (views reach 2^32 - 16 bytes: a 4K full-resolution layer is 2.7 GB -- no flag bit to spare)
+    unsigned l_woff[LEAN ? NB : 1];                                    // byte offset of weight piece k in channel stage 0
+    unsigned l_wok = 0;                                                // bit k: piece k exists (a 64-wide tile on a <= 32-filter layer has one column tile)
+    int l_o0 = 0;                                                      // LDS half-offset of element 0 (element k: + 512 k)
+    float l_slope = 1.f;                                               // input activation as a negative slope (1 none, 0 ReLU, 0.01 LeakyReLU)
+    if constexpr (LEAN) {
+        static_assert(NT % 4 == 0 && B_PIECES == NB * NT && TAPG == 9, "lean staging: whole weight pieces per thread, one stage per channel block");
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const int idx = tid + k * NT;
+            const int pix = idx >> 2, c4 = (idx & 3) * 4;
+            const int py = pix / PW, px = pix - py * PW;
+            const int iy = ty0 - DIL + py, ix = tx0 - DIL + px;
+            const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W) & (idx < NPIX * 4);
+            l_voff[k] = ok ? ((unsigned)(iy * p.W + ix) * (unsigned)p.in_ld + (unsigned)c4) << 2 : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            const int i = tid + k * NT;
+            const int l = i & 63, blk = i >> 6, hl = blk & 1, tb = blk >> 1, b = tb % TNW, tap = tb / TNW;
+            const bool ok = nb0 + b < nbs;                              // (wave-uniform: a wave copies whole 1-KiB blocks)
+            l_woff[k] = (unsigned)((((tap * nbs + nb0 + (ok ? b : 0)) * 2) * 2 + hl) * 512 + l * 8) * 2u;
+            l_wok |= ok ? (1u << k) : 0u;
+        }
+        l_o0 = (((tid >> 1) & 1) * PLANE + (tid >> 2)) * 8 + (tid & 1) * 4;
+        l_slope = p.in_relu ? 0.f : (p.in_scale ? (p.in_act == OTVM_ACT_RELU ? 0.f : (p.in_act == OTVM_ACT_LEAKY ? 0.01f : 1.f)) : 1.f);
+    }
     auto prefetch = [&](int cb, int g) __attribute__((always_inline)) {
+        if constexpr (LEAN) {
+            const unsigned soff = (unsigned)(cb * CB * 4);
+#pragma unroll
+            for (int k = 0; k < NP; ++k)
+                rp[k] = __builtin_bit_cast(f32x4, (u32x4)__builtin_amdgcn_raw_buffer_load_b128(in_rsrc, __builtin_elementwise_add_sat(l_voff[k], soff), 0, 0));   // (saturating: outside stays outside)
+            const char* wbase = reinterpret_cast<const char*>(p.wf) + (size_t)(((cb >> 1) * 9 * nbs * 2 + (cb & 1)) * 2) * 1024;   // uniform
+#pragma unroll
+            for (int k = 0; k < NB; ++k) rb[k] = *reinterpret_cast<const f16x8*>(wbase + l_woff[k]);
+            if (p.in_scale) {                                           // (uniform; NT % 4 == 0: the quad of element k is tid & 3 for every k)
+                rsc = *reinterpret_cast<const f32x4*>(p.in_scale + cb * CB + (tid & 3) * 4);
+                rsh = *reinterpret_cast<const f32x4*>(p.in_shift + cb * CB + (tid & 3) * 4);
+            }
+            return;
+        }
         const int cb32 = cb >> 1, ks = cb & 1;
         _Float16* bdst = Bs + (GLDS ? ((cb * NG + g) & 1) * B_HALFS : 0);
 #pragma unroll
@@ -263,6 +317,31 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
         }
     };
     auto commit = [&](int g) __attribute__((always_inline)) {
+        if constexpr (LEAN) {
+            const f16x8 zero8 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+            for (int k = 0; k < NB; ++k) *reinterpret_cast<f16x8*>(&Bs[(tid + k * NT) * 8]) = ((l_wok >> k) & 1u) ? rb[k] : zero8;
+            if (p.in_scale != nullptr || p.in_relu) {                   // ONE uniform branch per stage; rsc = 1, rsh = 0 without a table
+#pragma unroll
+                for (int k = 0; k < NP; ++k) {
+                    f32x4 v = rp[k] * rsc + rsh;
+                    v.x = fmaxf(v.x, 0.f) + l_slope * fminf(v.x, 0.f); v.y = fmaxf(v.y, 0.f) + l_slope * fminf(v.y, 0.f);
+                    v.z = fmaxf(v.z, 0.f) + l_slope * fminf(v.z, 0.f); v.w = fmaxf(v.w, 0.f) + l_slope * fminf(v.w, 0.f);
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    rp[k] = (l_voff[k] == 0xFFFFFFFFu) ? z : v;         // the conv's zero padding is not normalised
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < NP; ++k) {
+                if (k + 1 < NP || tid + k * NT < NPIX * 4) {            // (only the last element of a thread can lie behind the patch)
+                    f16x4 hi, lo;
+                    split4p(rp[k], hi, lo);
+                    *reinterpret_cast<f16x4*>(&Ph[l_o0 + 512 * k]) = hi;
+                    *reinterpret_cast<f16x4*>(&Pl[l_o0 + 512 * k]) = lo;
+                }
+            }
+            return;
+        }
         if constexpr (!GLDS) {
 #pragma unroll
             for (int k = 0; k < NB; ++k) {

@@ -176,6 +176,36 @@ def test_nine_tap_patch_tiles_in_either_matrix_core_form(G, m16):
     assert r.returncode == 0 and "conv_fuzz: 40 cases" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_patch_tiles_on_views_beyond_2_gib(G):
+    """A full-resolution layer of a 4K frame is a 2.7 GB view (2176 x 3840 pixels x 80 floats): byte offsets use all 32 bits, there
+    is no flag bit to spare (round 6: the lean staging of the nine-tap tiles first marked outside pixels with bit 31 and zeroed
+    every NORMALISED pixel beyond 2 GiB -- found by the 4K frame test).  The 64-filter tile with fused input normalisation on such a
+    view: its last rows must equal, bit for bit, the same convolution run on a small view of the same rows."""
+    from otvm_amd import lib as L
+    from otvm_amd.engine import Act, conv_params
+    lib = L.load()
+    H, W, Cin, ld, Cout = 2176, 3840, 64, 80, 64
+    g = torch.Generator(device=G.DEV).manual_seed(5)
+    x = Act(torch.randn(H * W * ld + 16, device=G.DEV, generator=g), H, W, Cin, ld, 0)
+    assert H * W * ld * 4 > (1 << 31)
+    w = rnd(Cout, Cin, 3, 3, seed=7, scale=1.0 / math.sqrt(Cin * 9))
+    cw = G.pack_weight(w)
+    sc, sh = (rnd(Cin, seed=8).abs() + 0.5).to(G.DEV), (rnd(Cin, seed=9) * 0.3).to(G.DEV)
+    out = G.empty_act(H, W, Cout)
+    p = conv_params(x, cw, out, None, 1, 1, 1, 0, 0, None, L.PREC_F16X3, (sc.data_ptr(), sh.data_ptr(), 2))
+    L.check(lib.otvm_conv2d(C.byref(p), G.stream()), "patch conv on a 2.7 GB view")
+    rows = 40                                                   # the last rows of the map, plus one row of context above them
+    xs = Act(x.t, rows + 1, W, Cin, ld, (H - rows - 1) * W * ld)
+    outs = G.empty_act(rows + 1, W, Cout)
+    ps = conv_params(xs, cw, outs, None, 1, 1, 1, 0, 0, None, L.PREC_F16X3, (sc.data_ptr(), sh.data_ptr(), 2))
+    L.check(lib.otvm_conv2d(C.byref(ps), G.stream()), "the same rows as a small view")
+    torch.cuda.synchronize()
+    big = out.torch()[H - rows:]
+    small = outs.torch()[1:]                                    # (row 0 of the small view sees zero padding above: not comparable)
+    assert torch.isfinite(big).all() and float(big.abs().max()) > 0.1
+    assert torch.equal(big, small), float((big - small).abs().max())
+
+
 def test_tile_walk_is_bit_identical(G):
     """csrc/common.h: the spatially tiled kernels (patch convs, stems, head conv, fused bottleneck) walk their tiles in XCD-aware
     bands by default (round 5: halo lines are fetched once per XCD L2 instead of once per neighbour).  The walk decides which

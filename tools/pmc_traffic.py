@@ -19,7 +19,7 @@ def agg(path, counter):
         if r["Counter_Name"] != counter:
             continue
         k = r["Kernel_Name"]
-        key = "conv" if any(t in k for t in ("conv_igemm", "conv_patch", "conv_stem", "conv_wave", "stm_bottleneck", "splitk_finish")) else "other"
+        key = "conv" if any(t in k for t in ("conv_igemm", "conv_patch", "conv_stem", "conv_head", "conv_wave", "stm_bottleneck", "splitk_finish")) else "other"
         d[key][0] += 1
         d[key][1] += float(r["Counter_Value"])
     return d
@@ -32,7 +32,7 @@ def main():
     rd = 2.0 * F["conv"][1] * 1024.0            # gfx950 correction: x2
     wr = W["conv"][1] * 1024.0
     out = {
-        "kernel": "conv_igemm_f16x3 + conv_patch_f16x3 + conv_stem_f16x3 + stm_bottleneck_f16x3 + splitk_finish kernels (everything the plan counts as a convolution launch)",
+        "kernel": "conv_igemm_f16x3 + conv_patch_f16x3 + conv_stem_f16x3 + conv_head16_f16x3 + stm_bottleneck(128)_f16x3 + splitk_finish kernels (everything the plan counts as a convolution launch)",
         "launches": n, "frames": frames, "launches_per_frame": n / frames,
         "read_bytes_per_launch": rd / n, "write_bytes_per_launch": wr / max(1, W["conv"][0]),
         "traffic_bytes_per_launch": rd / n + wr / max(1, W["conv"][0]),
