@@ -177,8 +177,8 @@ def frame_kwargs(t, T, skip, max_num, stress_bank=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=97)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=80)        # (with BASELINE's 100-frame clip: 15 lead-in + 5 warm-up frames in front,
+    ap.add_argument("--warmup", type=int, default=5)        #  every timed frame reads the full five-slot bank)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--clip-frames", type=int, default=0,
