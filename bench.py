@@ -134,6 +134,15 @@ def live_traffic(H, W, extra_args=(), kernels=CONV_KERNELS, calls_key="conv_call
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def clip_plan(H, W, steps, warmup, clip_frames=0):
+    """(frames of the clip, untimed lead-in frames): BASELINE's clip length for the resolution (or `clip_frames`), never fewer than
+    warmup + steps; frames [0, lead_in) are the lead-in, [lead_in, lead_in + warmup) the warm-up, the LAST `steps` frames are
+    timed -- so the driver's `--steps 20 --warmup 5` times frames 80 .. 99 of the 100-frame clip (it used to matte a
+    25-frame clip whose timed frames read 2 - 5 slots)."""
+    T = max(clip_frames if clip_frames > 0 else BASELINE_CLIP.get((H, W), 0), warmup + steps)
+    return T, T - warmup - steps
+
+
 def device_clip(H, W, T, seed, dev):
     """Smooth random video generated on the device (synthetic-data plumbing, not the measured path):
     bilinear-upsampled low-res noise with per-frame drift + a moving disc; uint8-quantised BGR as fp32."""
@@ -228,9 +237,7 @@ def main():
         affinity = pin_rank_affinity(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world)))
 
     H, W, K, Wm = args.height, args.width, args.steps, args.warmup
-    # frames of the clip: BASELINE's length; [0, lead_in) untimed lead-in, [lead_in, lead_in + Wm) warm-up, the last K timed
-    T = max(args.clip_frames if args.clip_frames > 0 else BASELINE_CLIP.get((H, W), 0), Wm + K)
-    lead_in = T - Wm - K
+    T, lead_in = clip_plan(H, W, K, Wm, args.clip_frames)
     from otvm_amd.synth_data import disc_trimap
     model, sd = build_model(dev, precision=args.precision)
     if dist is not None:

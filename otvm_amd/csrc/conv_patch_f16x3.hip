@@ -48,6 +48,9 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #ifndef OTVM_PATCH_NO_LEAN
 #define OTVM_PATCH_NO_LEAN 0   // (A/B build, results right) M16 tiles on the generic staging code of round 5
 #endif
+#ifndef OTVM_PATCH_SETPRIO
+#define OTVM_PATCH_SETPRIO 0   // (A/B build) M16 tiles: s_setprio 1 around a stage's fragment reads + MFMAs, 0 around its staging
+#endif
 #ifndef OTVM_PM16_NOKXP
 #define OTVM_PM16_NOKXP 0      // (A/B build, results right) M16 tiles: taps paired (t, t + 1) on every dilation
 #endif
@@ -417,6 +420,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
             // third of the LDS fragment reads per MFMA with 4 rows per wave -- 64->64 at 1088x1920 0.543 vs 0.526 ms,
             // 64->32 0.300 vs 0.304, 320->64 at 544x960 0.591 vs 0.520: the kernel is not bound by LDS fragment reads)
             if constexpr (M16) {
+                if (OTVM_PATCH_SETPRIO) __builtin_amdgcn_s_setprio(OTVM_PATCH_SETPRIO);
                 const int l15 = lane & 15, oct = (lane >> 4) & 1, hs = lane >> 5;
                 const int abase = (oct * PLANE + wave_m * TM * PW + pi16(l15)) * 8;
                 const int bbase = (l15 + 32 * oct) * 8;
@@ -486,6 +490,7 @@ void conv_patch_f16x3_kernel(const PatchArgs pa) {
                     pass(ax, bl0);
                     pass(ax, bhh);
                 }
+                if (OTVM_PATCH_SETPRIO) __builtin_amdgcn_s_setprio(0);
             } else
 #pragma unroll
             for (int tl = 0; tl < TAPG; ++tl) {

@@ -34,17 +34,18 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
 
 def test_ctypes_struct_matches_c_layout():
     """sizeof(otvm_conv_params) / otvm_preprocess_params / otvm_ppm_head_params as compiled by gcc == the ctypes mirrors."""
-    src = ('#include <stdio.h>\n#include "otvm_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(otvm_conv_params), '
+    src = ('#include <stdio.h>\n#include "otvm_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(otvm_conv_params), '
            'sizeof(otvm_preprocess_params), sizeof(otvm_ppm_head_params), sizeof(otvm_gn_apply_params), sizeof(otvm_gram_params), '
-           'sizeof(otvm_gn_predict_params));return 0;}\n')
+           'sizeof(otvm_gn_predict_params), sizeof(otvm_stm_bottleneck_params));return 0;}\n')
     exe = os.path.join(ROOT, "otvm_amd", "csrc", "build", "abi_sizes")
     os.makedirs(os.path.dirname(exe), exist_ok=True)
     subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
-    a, b, c, d, e, f = (int(v) for v in subprocess.check_output([exe]).split())
+    a, b, c, d, e, f, g = (int(v) for v in subprocess.check_output([exe]).split())
     from otvm_amd import lib as L
     assert ctypes.sizeof(L.ConvParams) == a and ctypes.sizeof(L.PreprocessParams) == b and ctypes.sizeof(L.PpmHeadParams) == c
     assert ctypes.sizeof(L.GnApplyParams) == d
     assert ctypes.sizeof(L.GramParams) == e and ctypes.sizeof(L.GnPredictParams) == f      # (ABI 18: + diag)
+    assert ctypes.sizeof(L.StmBottleneckParams) == g                                         # (ABI 19: + tile)
 
 
 def test_bank_policy_engine_equals_oracle():
@@ -433,6 +434,32 @@ def test_batch_groups_and_sharded_runner_with_batches():
     s = run_sharded(seqs, single, batch=2, matte_batch_fn=batched, key_fn=lambda sq: sq["res"])
     assert s["frames"] == 32 and sorted(s["outputs"]) == [0, 1, 2, 3, 4]
     assert sorted(calls, key=str) == sorted([("batch", [9, 7]), ("single", 5), ("batch", [8, 3])], key=str)
+
+
+def test_bench_clip_is_baselines_length_whatever_the_step_count():
+    """bench.py::clip_plan (round 6): the clip is BASELINE's -- 100 frames at 1920x1080 (configs[2]), 50 at 832x480 (configs[1]), 200
+    at 4K (configs[4]) -- the last --steps frames are timed, the frames in front of warm-up are an untimed lead-in; and the memory
+    schedule of eval.py:188-189 (memory every 5 of at most 5 slots) then has every timed frame read a full bank."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test2", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.clip_plan(1080, 1920, 20, 5) == (100, 75)          # the driver's command
+    assert bench.clip_plan(1080, 1920, 80, 5) == (100, 15)          # the default command
+    assert bench.clip_plan(1080, 1920, 97, 3) == (100, 0) and bench.clip_plan(1080, 1920, 200, 5) == (205, 0)
+    assert bench.clip_plan(480, 832, 47, 3) == (50, 0) and bench.clip_plan(2160, 3840, 197, 3) == (200, 0)
+    assert bench.clip_plan(1080, 1920, 8, 3, clip_frames=11) == (11, 0) and bench.clip_plan(720, 1280, 20, 5) == (25, 0)
+    # slots read by frame t under the reference's policy (engine.bank_update == alpha/model.py:472-493), memory every 5, max 5
+    from otvm_amd.engine import bank_update
+    T, lead = bench.clip_plan(1080, 1920, 20, 5)
+    bank, reads = [], []
+    for t in range(T):
+        reads.append(len(bank))
+        kw = bench.frame_kwargs(t, T, 5, 5)
+        if not kw["last_frame"]:
+            bank, _ = bank_update(bank, object(), kw["first_frame"], kw["memorize"], kw["max_memory_num"])
+    assert reads[0] == 0 and set(reads[lead + 5:]) == {5} and min(reads[16:]) == 5, reads[:20]
 
 
 def test_bench_sums_the_conv_rows_of_a_counter_file(tmp_path):
