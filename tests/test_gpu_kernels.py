@@ -1674,7 +1674,7 @@ def test_stm_bottleneck_fused_kernel(G, Cin, H, W):
 
 
 @pytest.mark.parametrize("tile", [1, 2, 3, 0], ids=["8x16", "8x8", "4x8", "auto"])
-@pytest.mark.parametrize("H,W", [(8, 16), (19, 45), (34, 60), (68, 120)])
+@pytest.mark.parametrize("H,W", [(5, 7), (8, 16), (9, 33), (19, 45), (34, 60), (68, 120)])
 def test_stm_bottleneck128_fused_kernel(G, H, W, tile):
     """otvm_stm_bottleneck_f16x3 with Cin = 512 (ABI 19, csrc/bottleneck128_f16x3.hip): an identity bottleneck of the STM encoders'
     1/8-resolution stage (planes 128: STM.py:43-51,79-87 with torchvision's Bottleneck, BatchNorm folded) as ONE launch ==
