@@ -67,6 +67,7 @@ FUSE_STM_BLOCK = os.environ.get("OTVM_FUSE_STM_BLOCK", "1") != "0"
 # launches is TIMED at plan time per map size (FramePlan._resolve_stm128; cached with the conv tuner's choices).
 # OTVM_FUSE_STM_BLOCK128: 0 = never, 1 = timed (default), 2 = always (tile from the map size)
 FUSE_STM_BLOCK128 = int(os.environ.get("OTVM_FUSE_STM_BLOCK128", "1"))
+STM128_TILE = int(os.environ.get("OTVM_STM128_TILE", "0"))       # (experiments, with OTVM_FUSE_STM_BLOCK128=2: force pixel tile 1 / 2 / 3)
 FUSE_PPM_HEAD = os.environ.get("OTVM_PPM_HEAD", "1") != "0"
 # round 4 (ABI 17): the GroupNorm statistics of conv3's OUTPUT in the FBA bottlenecks predicted from its input (channel sums +
 # Gram matrix, csrc/gram.hip), so conv3's epilogue normalises, adds the identity, applies the ReLU and writes the block output:
@@ -1149,7 +1150,7 @@ class FramePlan:
                 _, fused, U, q, name = st
                 key = (-128, q.H, q.W, max(1, q.batch), q.x_ld, q.y_ld)
                 if FUSE_STM_BLOCK128 >= 2 or not timed:
-                    choice = _TUNE_CACHE.get(key, -1) if FUSE_STM_BLOCK128 < 2 else -1
+                    choice = _TUNE_CACHE.get(key, -1) if FUSE_STM_BLOCK128 < 2 else (STM128_TILE or -1)
                 elif key in _TUNE_CACHE:
                     choice = _TUNE_CACHE[key]
                 else:
